@@ -1,0 +1,148 @@
+/* opentf_amd.h — C ABI of the MI355X-native engine for OpeNTF's fnn/bnn minibatch hot path.
+ *
+ * The reference (fani-lab/OpeNTF) is pure Python and has no FFI; the boundary it offers is the model
+ * plugin API of src/mdl/ntf.py:5-31 (constructor, learn, test).  This library is what a C-ABI
+ * replacement of the body of that API binds (last row).  Each entry point names the
+ * reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative NTF_E* code on failure; ntf_last_error() gives
+ *     the message (per engine; for a failed create, pass NULL).  No exceptions cross the ABI.
+ *   - plain pointers and sizes only.  "host" pointers are ordinary host memory, copied in/out.
+ *     "dev" pointers are HBM addresses owned by the engine (exposed for RCCL all-reduce).
+ *   - an engine is bound to one GPU and one HIP stream; it is not thread-safe; no global state.
+ *   - there is no CPU fallback: without a usable HIP device ntf_engine_create fails.
+ */
+#ifndef OPENTF_AMD_H
+#define OPENTF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTF_ABI_VERSION 1
+#define NTF_MAX_LAYERS 8
+
+enum { NTF_OK = 0, NTF_EINVAL = -1, NTF_EHIP = -2, NTF_ESTATE = -3, NTF_ENOMEM = -4 };
+
+/* how a minibatch's input rows X[B, D] are produced on the device */
+enum ntf_input_mode {
+    NTF_INPUT_DENSE = 0,   /* rows of a resident dense [N, D] f32 matrix (D2v vectors; src/mdl/ntf.py:24 else-branch) */
+    NTF_INPUT_MEANPOOL = 1,/* mean of the team's skill-embedding rows: CSR(skill) @ E / nnz (src/mdl/emb/gnn.py:484-486) */
+    NTF_INPUT_MULTIHOT = 2 /* multi-hot skill row (src/mdl/ntf.py:23); layer 0 becomes a CSR gather-sum of W0 columns */
+};
+
+/* negative sampling distribution, src/mdl/fnn.py:34-36 */
+enum ntf_nsd { NTF_NSD_NONE = 0, NTF_NSD_UNIFORM = 1, NTF_NSD_UNIGRAM = 2, NTF_NSD_UNIGRAM_B = 3 };
+
+/* parameter kinds of one layer; Fnn uses WEIGHT/BIAS, Bnn all four in the state_dict order
+ * mu_weight, rho_weight, mu_bias, rho_bias (src/mdl/bnn.py:25 via bayesian-torch LinearFlipout) */
+enum ntf_param_kind { NTF_P_WEIGHT = 0, NTF_P_BIAS = 1, NTF_P_RHO_WEIGHT = 2, NTF_P_RHO_BIAS = 3 };
+
+typedef struct ntf_config {
+    int32_t abi_version;        /* NTF_ABI_VERSION */
+    int32_t device;             /* HIP device ordinal ("cuda:N" of src/__config__.yaml:10) */
+    void*   stream;             /* hipStream_t to run on, or NULL: the engine creates its own */
+    int32_t n_layers;           /* number of Linear layers = len(h) + 1 (src/mdl/fnn.py:20-22) */
+    int32_t dims[NTF_MAX_LAYERS + 1]; /* D, h[0], ..., h[-1], M */
+    int32_t bayesian;           /* 0 = Fnn, 1 = Bnn/Flipout (src/mdl/bnn.py:17-27) */
+    int32_t input_mode;         /* enum ntf_input_mode */
+    int32_t max_batch;          /* cfg.b (src/mdl/__config__.yaml:1) */
+    int32_t ns;                 /* cfg.ns */
+    int32_t nsd;                /* enum ntf_nsd */
+    float   tpw, tnw;           /* cfg.tpw, cfg.tnw (src/mdl/fnn.py:45) */
+    float   lr;                 /* cfg.lr; Adam defaults beta 0.9/0.999 eps 1e-8 (src/mdl/fnn.py:104) */
+    uint64_t seed;              /* seed of the device-side generators (negatives, Flipout eps and signs) */
+    int32_t fused;              /* 1 = use the fused output-layer kernels when the shape allows, 0 = generic path */
+    int32_t reserved[7];
+} ntf_config;
+
+/* Random tensors of one step, injected instead of generated (parity tests).  Any pointer may be NULL
+ * (= generate on device).  All are HOST pointers.  Layouts follow bayesian-torch LinearFlipout.forward:
+ * eps_w[l] [out,in], eps_b[l] [out], s_in[l] [B,in] (+1/-1 as f32), s_out[l] [B,out] (+1/-1 as f32);
+ * neg_idx [B, ns] int64 as returned by src/mdl/fnn.py:48-76. */
+typedef struct ntf_inject {
+    const int64_t* neg_idx;
+    const float* eps_w[NTF_MAX_LAYERS];
+    const float* eps_b[NTF_MAX_LAYERS];
+    const float* s_in[NTF_MAX_LAYERS];
+    const float* s_out[NTF_MAX_LAYERS];
+} ntf_inject;
+
+typedef struct ntf_engine ntf_engine;
+
+/* ---- lifetime:  Fnn.init / Bnn.init + model.to(device)            src/mdl/fnn.py:15-30,100-102 */
+int  ntf_engine_create(const ntf_config* cfg, ntf_engine** out);
+void ntf_engine_destroy(ntf_engine* e);
+const char* ntf_last_error(const ntf_engine* e);
+int  ntf_abi_version(void);
+
+/* ---- data residency (once per learn/test call): replaces NtfDataset's per-sample densify
+ *      src/mdl/ntf.py:16-25.  CSR = int64 indptr [n_rows+1], int32 indices [nnz]; values are 1. */
+int ntf_set_member_csr(ntf_engine* e, const int64_t* indptr, const int32_t* indices, int64_t n_rows);
+int ntf_set_skill_csr(ntf_engine* e, const int64_t* indptr, const int32_t* indices, int64_t n_rows);
+int ntf_set_skill_table(ntf_engine* e, const float* table, int64_t n_skills, int32_t d); /* E of gnn.py:485 */
+int ntf_set_dense_input(ntf_engine* e, const float* X, int64_t n_rows, int32_t d);
+int ntf_set_unigram(ntf_engine* e, const double* freq, int64_t n);                         /* src/mdl/fnn.py:82 */
+
+/* ---- state:  state_dict() / load_state_dict()                     src/mdl/fnn.py:101,160,168,187 */
+int ntf_set_param(ntf_engine* e, int layer, int kind, const float* host, int64_t count);
+int ntf_get_param(ntf_engine* e, int layer, int kind, float* host, int64_t count);
+int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int64_t count); /* p.grad after backward, fnn.py:137 */
+int ntf_reset_optimizer(ntf_engine* e);                  /* fresh Adam per fold, src/mdl/fnn.py:104 */
+int ntf_set_lr(ntf_engine* e, float lr);                 /* ReduceLROnPlateau result, fnn.py:105,163 */
+int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step);
+
+/* ---- the step:  body of the hot loop                              src/mdl/fnn.py:118-151
+ * rows = B global team ids (host).  loss_out may be NULL: then nothing is synchronised and the loss is
+ * only added to the epoch accumulator (ntf_epoch_loss). */
+int ntf_train_step(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* loss_out);
+int ntf_eval_step(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* loss_out);
+/* split form for data parallelism: backward leaves d(loss_sum_over_rows / global_B)/dparam in the flat
+ * gradient buffer (sum over ranks = the single-process gradient); apply runs Adam. */
+int ntf_backward(ntf_engine* e, const int64_t* rows, int32_t B, int32_t global_B, const ntf_inject* inj, float* loss_out);
+int ntf_apply(ntf_engine* e);
+/* whole phase without host round trips: `for batch in loader` of src/mdl/fnn.py:118 run natively.
+ * order = n row ids in the order the loader yields them; mean of batch losses is returned (fnn.py:153). */
+int ntf_train_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss);
+int ntf_eval_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss);
+int ntf_epoch_loss(ntf_engine* e, double* sum, int64_t* steps); /* reads and clears the accumulator */
+
+/* ---- inference:  Fnn.test batch body                              src/mdl/fnn.py:200-211
+ * probs_host [B, M] = sigmoid(forward) (Bnn: mean over nmc stochastic forwards);
+ * pred_unc/model_unc [B] = predictive entropy / mutual information (may be NULL). */
+int ntf_forward(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, const ntf_inject* inj_per_mc,
+                float* probs_host, float* pred_unc, float* model_unc);
+/* pre-sigmoid post-leaky_relu logits of ONE forward (the quantity the 1e-4 parity bar is stated on) */
+int ntf_logits(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* logits_host);
+/* top-K per row of the probabilities, without moving [B, M] to the host   src/pkgmgr.py:125-134 */
+int ntf_forward_topk(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, int32_t K,
+                     float* values_host, int32_t* indices_host, float* pred_unc, float* model_unc);
+
+/* ---- the team2vec gather on its own:  Gnn.get_dense_vecs           src/mdl/emb/gnn.py:484-486
+ * out_host [n, d] (may be NULL to keep the result on the device only); rows NULL = 0..n-1. */
+int ntf_gather_meanpool(ntf_engine* e, const int64_t* rows, int64_t n, float* out_host);
+
+/* ---- raw device views for RCCL (torch.distributed) and measurement */
+int ntf_grad_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
+int ntf_param_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
+int ntf_synchronize(ntf_engine* e);
+/* HIP-event timing of the kernels launched by the engine since the last reset, by kernel family:
+ * names[i] (static strings), ms[i] total, calls[i].  Returns the number of families (<= cap). */
+int ntf_kernel_times(ntf_engine* e, int enable, const char** names, double* ms, int64_t* calls, int cap);
+
+/* ---- stateless kernels on caller-owned device memory (used by tests and micro-benchmarks) */
+int ntf_k_gemm_f32(void* stream, int m, int n, int k, const float* A, int64_t sam, int64_t sak,
+                   const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc);
+
+/* device generators behind Flipout's eps / signs (dev_out = device pointers), for statistical tests */
+int ntf_k_fill_normal(void* stream, uint64_t seed, uint64_t step, int layer, int64_t n, float* dev_out);
+int ntf_k_fill_sign(void* stream, uint64_t seed, uint64_t step, int layer, int rows, int cols, float* dev_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENTF_AMD_H */

@@ -1,0 +1,106 @@
+// Device-side helpers shared by the gfx950 kernels: counter-based generators, sign hash, BCE terms,
+// wave64 / workgroup reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ntf_kernels.h"
+
+namespace ntf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+
+// +1/-1 at (row, col) of a sign tensor: bayesian-torch draws uniform_(-1,1).sign(); here a two-stage
+// murmur finaliser of (row, col) under a per-(step, layer, tensor) key, or the injected array.
+__device__ __forceinline__ float sign_hash(uint32_t k0, uint32_t k1, uint32_t r, uint32_t c) {
+    uint32_t h = fmix32(r * 0x9E3779B1u + k0);
+    h = fmix32(h ^ (c * 0x85EBCA77u + k1));
+    return (h & 0x00010000u) ? -1.0f : 1.0f;
+}
+__device__ __forceinline__ float sign_at(const SignSpec& s, int64_t r, int64_t c) {
+    if (s.inj) return s.inj[r * s.ld + c];
+    return sign_hash(s.k0, s.k1, (uint32_t)r, (uint32_t)c);
+}
+
+// Philox4x32-10 (Salmon et al., SC'11)
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // in (0,1)
+
+// four N(0,1) values for elements 4q .. 4q+3 of a tensor
+__device__ __forceinline__ void normal4(const NormalSpec& s, int64_t q, int64_t e0, int64_t n, float z[4]) {
+    if (s.inj) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = (e0 + j < n) ? s.inj[e0 + j] : 0.f;
+        return;
+    }
+    const uint4 r = philox4x32(make_uint4((uint32_t)q, (uint32_t)(q >> 32), s.tag, s.step), make_uint2(s.k0, s.k1));
+    const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincospif(2.f * u01(r.y), &s0, &c0);
+    sincospif(2.f * u01(r.w), &s1, &c1);
+    z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}
+
+__device__ __forceinline__ float softplus_rho(float rho) { return log1pf(expf(rho)); }  // sigma = log1p(exp(rho))
+
+// terms of binary_cross_entropy_with_logits on l = leaky_relu(z) (src/mdl/fnn.py:25,46):
+//   sp = softplus(l) = bce(l, y=0);  sg = sigmoid(l);  dact = d leaky_relu / dz
+__device__ __forceinline__ void bce_terms(float z, float& sp, float& sg, float& dact) {
+    const bool pos = z > 0.f;
+    const float l = pos ? z : z * kLeakySlope;
+    dact = pos ? 1.f : kLeakySlope;
+    const float e = expf(-fabsf(l));
+    sp = fmaxf(l, 0.f) + logf(1.f + e);
+    const float inv = 1.f / (1.f + e);
+    sg = (l >= 0.f) ? inv : e * inv;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over a workgroup of up to 1024 threads; result valid in thread 0 (deterministic order)
+__device__ __forceinline__ float block_reduce_sum(float v) {
+    __shared__ float sh_f[16];
+    v = wave_reduce_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh_f[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x == 0) for (int i = 0; i < nw; ++i) s += sh_f[i];
+    return s;
+}
+__device__ __forceinline__ double block_reduce_sum_d(double v) {
+    __shared__ double sh_d[16];
+    v = wave_reduce_sum_d(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh_d[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < nw; ++i) s += sh_d[i];
+    return s;
+}
+
+}  // namespace ntf

@@ -1,0 +1,861 @@
+// C-ABI engine (include/opentf_amd.h): owns the HBM-resident state of one Fnn/Bnn model on one MI355X
+// and runs the minibatch hot loop of src/mdl/fnn.py:118-151 (reference) natively.
+#include "../../include/opentf_amd.h"
+#include "ntf_kernels.h"
+#include "ntf_fused.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ntf;
+
+static thread_local std::string g_create_error;
+
+struct LayerInfo {
+    int in = 0, out = 0;
+    int64_t off[4] = {0, 0, 0, 0};  // offsets (floats) of WEIGHT, BIAS, RHO_WEIGHT, RHO_BIAS in the flat buffers
+    int64_t nw() const { return (int64_t)in * out; }
+};
+
+enum Fam { F_GATHER = 0, F_GEMM_HIDDEN, F_FLIPOUT_OPERAND, F_OUT_FWD, F_LOSS, F_OUT_BWD_DW, F_OUT_BWD_DA, F_BIAS_GRAD,
+           F_FLIPOUT_FINAL, F_KL, F_ADAM, F_SAMPLER, F_INFER, F_OUT_FUSED_FWD, F_OUT_FUSED_DW, F_COUNT };
+static const char* kFamNames[F_COUNT] = {"gather", "gemm_hidden", "flipout_operand", "out_fwd_gemm", "loss", "out_bwd_dw_gemm",
+                                         "out_bwd_da_gemm", "bias_grad", "flipout_grad_finalize", "kl", "adam", "sampler", "infer",
+                                         "out_fused_fwd_loss_dh", "out_fused_dw_adam"};
+
+struct TimeRec { int fam; hipEvent_t a, b; };
+
+struct ntf_engine {
+    ntf_config cfg{};
+    hipStream_t st = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int L = 0;
+    std::vector<LayerInfo> layers;
+    int64_t n_params = 0;
+    float *P = nullptr, *G = nullptr, *M1 = nullptr, *V2 = nullptr;
+    int64_t adam_t = 0;
+    float lr = 1e-3f;
+    // resident data
+    int64_t* m_indptr = nullptr; int32_t* m_indices = nullptr; int64_t m_rows = 0;
+    std::vector<int64_t> h_m_indptr; std::vector<int32_t> h_m_indices;
+    int64_t* s_indptr = nullptr; int32_t* s_indices = nullptr; int64_t s_rows = 0;
+    float* table = nullptr; int64_t n_skills = 0; int table_d = 0;
+    float* Xall = nullptr; int64_t x_rows = 0;
+    float* al_prob = nullptr; int32_t* al_alias = nullptr; double* al_weight = nullptr; double al_total = 0; int64_t al_n = 0;
+    // per-step buffers
+    int64_t* d_rows = nullptr; int64_t* d_order = nullptr; int64_t order_cap = 0;
+    int64_t* d_neg = nullptr;
+    std::vector<float*> act;          // act[0] = X [B, D], act[l] = leaky_relu output of layer l-1 (hidden)
+    float *Zout = nullptr, *dZout = nullptr, *Pbuf = nullptr;
+    float *Zh = nullptr;              // [B, max hidden] pre-activation scratch for hidden flipout layers
+    float* dAct[2] = {nullptr, nullptr};
+    std::vector<float*> Wp, bp;       // flipout perturbation operands per layer
+    float *partial = nullptr, *row_fix = nullptr, *d_loss = nullptr, *ent_mc = nullptr, *ent_mean = nullptr;
+    float *dh_slab = nullptr;         // fused path: partial d(hidden) slabs
+    double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
+    float* tk_vals = nullptr; int32_t* tk_idx = nullptr; int64_t tk_cap = 0;
+    // injection staging (device)
+    std::vector<float*> inj_eps_w, inj_eps_b, inj_s_in, inj_s_out;
+    uint64_t seed = 0, step = 0;
+    int maxhid = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimeRec> recs;
+    std::vector<hipEvent_t> pool;
+    double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
+    int last_global_B = 0; int last_B = 0;
+};
+
+#define HIPCHK(e, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _s = (call);                                                                           \
+        if (_s != hipSuccess) {                                                                           \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_s);                                 \
+            return NTF_EHIP;                                                                              \
+        }                                                                                                 \
+    } while (0)
+#define FAIL(e, code, msg) do { (e)->err = (msg); return (code); } while (0)
+
+struct Scope {
+    ntf_engine* e; int fam; hipEvent_t a = nullptr, b = nullptr;
+    Scope(ntf_engine* e_, int f) : e(e_), fam(f) {
+        if (!e->timing) return;
+        auto get = [&]() { hipEvent_t ev; if (!e->pool.empty()) { ev = e->pool.back(); e->pool.pop_back(); } else hipEventCreate(&ev); return ev; };
+        a = get(); b = get();
+        hipEventRecord(a, e->st);
+    }
+    ~Scope() {
+        if (!e->timing) return;
+        hipEventRecord(b, e->st);
+        e->recs.push_back({fam, a, b});
+    }
+};
+
+static void drain_times(ntf_engine* e) {
+    if (e->recs.empty()) return;
+    hipStreamSynchronize(e->st);
+    for (auto& r : e->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { e->fam_ms[r.fam] += ms; e->fam_calls[r.fam] += 1; }
+        e->pool.push_back(r.a); e->pool.push_back(r.b);
+    }
+    e->recs.clear();
+}
+
+static uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// per-(seed, step, layer, tensor) key of the device generators
+static void make_key(const ntf_engine* e, uint64_t step, int layer, int tensor, uint32_t& k0, uint32_t& k1) {
+    uint64_t h = splitmix64(e->seed ^ splitmix64(step * 0x100 + (uint64_t)layer * 8 + (uint64_t)tensor));
+    k0 = (uint32_t)h; k1 = (uint32_t)(h >> 32);
+}
+enum { T_EPS_W = 0, T_EPS_B = 1, T_S_IN = 2, T_S_OUT = 3, T_NEG = 4 };
+
+template <typename T> static int dmalloc(ntf_engine* e, T** p, int64_t n) {
+    *p = nullptr;
+    if (n <= 0) return NTF_OK;
+    hipError_t s = hipMalloc((void**)p, (size_t)n * sizeof(T));
+    if (s != hipSuccess) { e->err = std::string("hipMalloc: ") + hipGetErrorString(s); return NTF_ENOMEM; }
+    return NTF_OK;
+}
+#define DM(e, p, n) do { int _r = dmalloc(e, p, n); if (_r) return _r; } while (0)
+template <typename T> static void dfree(T*& p) { if (p) { hipFree(p); p = nullptr; } }
+
+extern "C" int ntf_abi_version(void) { return NTF_ABI_VERSION; }
+extern "C" const char* ntf_last_error(const ntf_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+static bool fused_ok(const ntf_engine* e) {
+    if (!e->cfg.fused) return false;
+    return fused_supported(e->layers[e->L - 1].in);
+}
+
+extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
+    if (!out) { g_create_error = "out is NULL"; return NTF_EINVAL; }
+    *out = nullptr;
+    if (!cfg || cfg->abi_version != NTF_ABI_VERSION) { g_create_error = "bad config / abi_version"; return NTF_EINVAL; }
+    if (cfg->n_layers < 1 || cfg->n_layers > NTF_MAX_LAYERS || cfg->max_batch < 1 || cfg->ns < 0) { g_create_error = "bad n_layers/max_batch/ns"; return NTF_EINVAL; }
+    for (int i = 0; i <= cfg->n_layers; ++i) if (cfg->dims[i] < 1) { g_create_error = "bad dims"; return NTF_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device: the engine has no CPU fallback"; return NTF_EHIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return NTF_EINVAL; }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return NTF_EHIP; }
+    ntf_engine* e = new ntf_engine();
+    e->cfg = *cfg;
+    e->L = cfg->n_layers;
+    e->lr = cfg->lr;
+    e->seed = cfg->seed;
+    if (cfg->stream) e->st = (hipStream_t)cfg->stream;
+    else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
+    int64_t off = 0;
+    auto seg = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
+    e->layers.resize(e->L);
+    for (int l = 0; l < e->L; ++l) {
+        LayerInfo& li = e->layers[l];
+        li.in = cfg->dims[l]; li.out = cfg->dims[l + 1];
+        li.off[NTF_P_WEIGHT] = seg(li.nw());
+        li.off[NTF_P_BIAS] = seg(li.out);
+        if (cfg->bayesian) { li.off[NTF_P_RHO_WEIGHT] = seg(li.nw()); li.off[NTF_P_RHO_BIAS] = seg(li.out); }
+        if (l < e->L - 1) e->maxhid = std::max(e->maxhid, li.out);
+    }
+    e->n_params = off;
+    const int B = cfg->max_batch, M = cfg->dims[e->L];
+    int rc = NTF_OK;
+    auto A = [&](int r) { if (rc == NTF_OK) rc = r; };
+    A(dmalloc(e, &e->P, off)); A(dmalloc(e, &e->G, off)); A(dmalloc(e, &e->M1, off)); A(dmalloc(e, &e->V2, off));
+    A(dmalloc(e, &e->d_rows, B)); A(dmalloc(e, &e->d_neg, (int64_t)B * std::max(1, cfg->ns)));
+    e->act.assign(e->L, nullptr);
+    for (int l = 0; l < e->L; ++l) A(dmalloc(e, &e->act[l], (int64_t)B * cfg->dims[l]));
+    A(dmalloc(e, &e->Zout, (int64_t)B * M)); A(dmalloc(e, &e->dZout, (int64_t)M * fused_ldb(B)));
+    if (e->maxhid) { A(dmalloc(e, &e->Zh, (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[0], (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[1], (int64_t)B * e->maxhid)); }
+    e->Wp.assign(e->L, nullptr); e->bp.assign(e->L, nullptr);
+    if (cfg->bayesian) for (int l = 0; l < e->L; ++l) { A(dmalloc(e, &e->Wp[l], e->layers[l].nw())); A(dmalloc(e, &e->bp[l], e->layers[l].out)); }
+    A(dmalloc(e, &e->partial, (int64_t)B * std::max(loss_dense_nchunk(M), fused_loss_slots(M)))); A(dmalloc(e, &e->row_fix, B));
+    A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 2)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
+    A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B));
+    if (rc == NTF_OK && fused_ok(e)) A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
+    e->inj_eps_w.assign(e->L, nullptr); e->inj_eps_b.assign(e->L, nullptr); e->inj_s_in.assign(e->L, nullptr); e->inj_s_out.assign(e->L, nullptr);
+    if (rc != NTF_OK) { g_create_error = e->err; ntf_engine_destroy(e); return rc; }
+    hipMemsetAsync(e->P, 0, off * 4, e->st); hipMemsetAsync(e->G, 0, off * 4, e->st);
+    hipMemsetAsync(e->M1, 0, off * 4, e->st); hipMemsetAsync(e->V2, 0, off * 4, e->st);
+    hipMemsetAsync(e->d_acc, 0, 16, e->st); hipMemsetAsync(e->d_acc_steps, 0, 16, e->st);
+    if (hipStreamSynchronize(e->st) != hipSuccess) { g_create_error = "device initialisation failed"; ntf_engine_destroy(e); return NTF_EHIP; }
+    *out = e;
+    return NTF_OK;
+}
+
+extern "C" void ntf_engine_destroy(ntf_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->st) hipStreamSynchronize(e->st);
+    dfree(e->P); dfree(e->G); dfree(e->M1); dfree(e->V2);
+    dfree(e->m_indptr); dfree(e->m_indices); dfree(e->s_indptr); dfree(e->s_indices); dfree(e->table); dfree(e->Xall);
+    dfree(e->al_prob); dfree(e->al_alias); dfree(e->al_weight);
+    dfree(e->d_rows); dfree(e->d_order); dfree(e->d_neg);
+    for (auto& p : e->act) dfree(p);
+    dfree(e->Zout); dfree(e->dZout); dfree(e->Pbuf); dfree(e->Zh); dfree(e->dAct[0]); dfree(e->dAct[1]);
+    for (auto& p : e->Wp) dfree(p);
+    for (auto& p : e->bp) dfree(p);
+    dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_acc); dfree(e->d_acc_steps);
+    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->tk_vals); dfree(e->tk_idx);
+    for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
+    for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto ev : e->pool) hipEventDestroy(ev);
+    if (e->own_stream && e->st) hipStreamDestroy(e->st);
+    delete e;
+}
+
+// ------------------------------------------------------------------------------------------ data
+static int upload_csr(ntf_engine* e, const int64_t* indptr, const int32_t* indices, int64_t n_rows, int64_t** d_ip, int32_t** d_ix, int width) {
+    if (!indptr || n_rows < 0) FAIL(e, NTF_EINVAL, "csr: bad arguments");
+    const int64_t nnz = indptr[n_rows];
+    if (nnz < 0 || (nnz > 0 && !indices)) FAIL(e, NTF_EINVAL, "csr: bad arguments");
+    for (int64_t i = 0; i < n_rows; ++i) if (indptr[i + 1] < indptr[i]) FAIL(e, NTF_EINVAL, "csr: indptr not monotone");
+    for (int64_t p = 0; p < nnz; ++p) if (indices[p] < 0 || indices[p] >= width) FAIL(e, NTF_EINVAL, "csr: column id out of range");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    dfree(*d_ip); dfree(*d_ix);
+    DM(e, d_ip, n_rows + 1); DM(e, d_ix, std::max<int64_t>(nnz, 1));
+    HIPCHK(e, hipMemcpy(*d_ip, indptr, (n_rows + 1) * 8, hipMemcpyHostToDevice));
+    if (nnz) HIPCHK(e, hipMemcpy(*d_ix, indices, nnz * 4, hipMemcpyHostToDevice));
+    return NTF_OK;
+}
+extern "C" int ntf_set_member_csr(ntf_engine* e, const int64_t* indptr, const int32_t* indices, int64_t n_rows) {
+    if (!e) return NTF_EINVAL;
+    int r = upload_csr(e, indptr, indices, n_rows, &e->m_indptr, &e->m_indices, e->cfg.dims[e->L]);
+    if (r) return r;
+    e->m_rows = n_rows;
+    e->h_m_indptr.assign(indptr, indptr + n_rows + 1);
+    e->h_m_indices.assign(indices, indices + indptr[n_rows]);
+    return NTF_OK;
+}
+extern "C" int ntf_set_skill_csr(ntf_engine* e, const int64_t* indptr, const int32_t* indices, int64_t n_rows) {
+    if (!e) return NTF_EINVAL;
+    const int width = e->cfg.input_mode == NTF_INPUT_MULTIHOT ? e->cfg.dims[0] : (e->n_skills ? (int)e->n_skills : INT32_MAX);
+    int r = upload_csr(e, indptr, indices, n_rows, &e->s_indptr, &e->s_indices, width);
+    if (r) return r;
+    e->s_rows = n_rows;
+    return NTF_OK;
+}
+extern "C" int ntf_set_skill_table(ntf_engine* e, const float* table, int64_t n_skills, int32_t d) {
+    if (!e || !table || n_skills < 1 || d < 1) return NTF_EINVAL;
+    if (e->cfg.input_mode == NTF_INPUT_MEANPOOL && d != e->cfg.dims[0]) FAIL(e, NTF_EINVAL, "skill table width != dims[0]");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    dfree(e->table);
+    DM(e, &e->table, n_skills * d);
+    HIPCHK(e, hipMemcpy(e->table, table, n_skills * d * 4, hipMemcpyHostToDevice));
+    e->n_skills = n_skills; e->table_d = d;
+    return NTF_OK;
+}
+extern "C" int ntf_set_dense_input(ntf_engine* e, const float* X, int64_t n_rows, int32_t d) {
+    if (!e || !X || n_rows < 1) return NTF_EINVAL;
+    if (d != e->cfg.dims[0]) FAIL(e, NTF_EINVAL, "dense input width != dims[0]");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    dfree(e->Xall);
+    DM(e, &e->Xall, n_rows * d);
+    HIPCHK(e, hipMemcpy(e->Xall, X, n_rows * d * 4, hipMemcpyHostToDevice));
+    e->x_rows = n_rows;
+    return NTF_OK;
+}
+
+// Vose alias table over weights w[0..n)
+static void build_alias(const double* w, int64_t n, std::vector<float>& prob, std::vector<int32_t>& alias, double& total) {
+    total = 0; for (int64_t i = 0; i < n; ++i) total += w[i];
+    prob.assign(n, 1.f); alias.resize(n);
+    for (int64_t i = 0; i < n; ++i) alias[i] = (int32_t)i;
+    if (!(total > 0)) return;
+    std::vector<double> sc(n);
+    std::vector<int64_t> small, large;
+    for (int64_t i = 0; i < n; ++i) { sc[i] = w[i] * (double)n / total; (sc[i] < 1.0 ? small : large).push_back(i); }
+    while (!small.empty() && !large.empty()) {
+        int64_t s = small.back(); small.pop_back();
+        int64_t l = large.back();
+        prob[s] = (float)sc[s]; alias[s] = (int32_t)l;
+        sc[l] = (sc[l] + sc[s]) - 1.0;
+        if (sc[l] < 1.0) { large.pop_back(); small.push_back(l); }
+    }
+    for (int64_t i : large) prob[i] = 1.f;
+    for (int64_t i : small) prob[i] = 1.f;
+}
+static int upload_alias(ntf_engine* e, const double* w, int64_t n) {
+    std::vector<float> prob; std::vector<int32_t> alias; double total;
+    build_alias(w, n, prob, alias, total);
+    if (e->al_n != n) { dfree(e->al_prob); dfree(e->al_alias); dfree(e->al_weight); DM(e, &e->al_prob, n); DM(e, &e->al_alias, n); DM(e, &e->al_weight, n); e->al_n = n; }
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    HIPCHK(e, hipMemcpy(e->al_prob, prob.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->al_alias, alias.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->al_weight, w, n * 8, hipMemcpyHostToDevice));
+    e->al_total = total;
+    return NTF_OK;
+}
+extern "C" int ntf_set_unigram(ntf_engine* e, const double* freq, int64_t n) {
+    if (!e || !freq) return NTF_EINVAL;
+    if (n != e->cfg.dims[e->L]) FAIL(e, NTF_EINVAL, "unigram length != number of experts");
+    for (int64_t i = 0; i < n; ++i) if (!(freq[i] >= 0)) FAIL(e, NTF_EINVAL, "unigram: negative or NaN weight");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    return upload_alias(e, freq, n);
+}
+
+// ------------------------------------------------------------------------------------------ state
+static int param_span(ntf_engine* e, int layer, int kind, int64_t& off, int64_t& n) {
+    if (layer < 0 || layer >= e->L || kind < 0 || kind > 3) FAIL(e, NTF_EINVAL, "param: bad layer/kind");
+    if (kind >= 2 && !e->cfg.bayesian) FAIL(e, NTF_EINVAL, "param: rho on a non-bayesian model");
+    off = e->layers[layer].off[kind];
+    n = (kind == NTF_P_WEIGHT || kind == NTF_P_RHO_WEIGHT) ? e->layers[layer].nw() : e->layers[layer].out;
+    return NTF_OK;
+}
+extern "C" int ntf_set_param(ntf_engine* e, int layer, int kind, const float* host, int64_t count) {
+    if (!e || !host) return NTF_EINVAL;
+    int64_t off, n; int r = param_span(e, layer, kind, off, n); if (r) return r;
+    if (count != n) FAIL(e, NTF_EINVAL, "param: element count mismatch");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    HIPCHK(e, hipMemcpy(e->P + off, host, n * 4, hipMemcpyHostToDevice));
+    return NTF_OK;
+}
+extern "C" int ntf_get_param(ntf_engine* e, int layer, int kind, float* host, int64_t count) {
+    if (!e || !host) return NTF_EINVAL;
+    int64_t off, n; int r = param_span(e, layer, kind, off, n); if (r) return r;
+    if (count != n) FAIL(e, NTF_EINVAL, "param: element count mismatch");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    HIPCHK(e, hipMemcpy(host, e->P + off, n * 4, hipMemcpyDeviceToHost));
+    return NTF_OK;
+}
+extern "C" int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int64_t count) {
+    if (!e || !host) return NTF_EINVAL;
+    int64_t off, n; int r = param_span(e, layer, kind, off, n); if (r) return r;
+    if (count != n) FAIL(e, NTF_EINVAL, "grad: element count mismatch");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    HIPCHK(e, hipMemcpy(host, e->G + off, n * 4, hipMemcpyDeviceToHost));
+    return NTF_OK;
+}
+extern "C" int ntf_reset_optimizer(ntf_engine* e) {
+    if (!e) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipMemsetAsync(e->M1, 0, e->n_params * 4, e->st));
+    HIPCHK(e, hipMemsetAsync(e->V2, 0, e->n_params * 4, e->st));
+    e->adam_t = 0; e->lr = e->cfg.lr;
+    return NTF_OK;
+}
+extern "C" int ntf_set_lr(ntf_engine* e, float lr) { if (!e) return NTF_EINVAL; e->lr = lr; return NTF_OK; }
+extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; return NTF_OK; }
+
+// ------------------------------------------------------------------------------------------ step
+struct StepCtx {
+    const int64_t* rows_dev = nullptr;
+    int B = 0; int global_B = 0;
+    const ntf_inject* inj = nullptr;
+    uint64_t step = 0;
+    bool train = false;
+};
+
+static int stage_rows(ntf_engine* e, const int64_t* rows, int B, bool rows_on_device, const int64_t** dev) {
+    if (!rows || B < 1 || B > e->cfg.max_batch) FAIL(e, NTF_EINVAL, "step: bad rows/B (B must be in [1, max_batch])");
+    if (rows_on_device) { *dev = rows; return NTF_OK; }
+    const int64_t limit = e->m_rows;
+    for (int i = 0; i < B; ++i) if (rows[i] < 0 || (limit && rows[i] >= limit)) FAIL(e, NTF_EINVAL, "step: row id out of range");
+    HIPCHK(e, hipMemcpyAsync(e->d_rows, rows, (size_t)B * 8, hipMemcpyHostToDevice, e->st));
+    // the host buffer may be reused by the caller right after return
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    *dev = e->d_rows;
+    return NTF_OK;
+}
+
+static int stage_inj(ntf_engine* e, float** slot, const float* host, int64_t n) {
+    if (!*slot) DM(e, slot, n);
+    HIPCHK(e, hipMemcpyAsync(*slot, host, (size_t)n * 4, hipMemcpyHostToDevice, e->st));
+    return NTF_OK;
+}
+
+static SignSpec sign_spec(ntf_engine* e, const StepCtx& c, int layer, int tensor, int ld) {
+    SignSpec s; s.enabled = 1; s.ld = ld;
+    float* inj = tensor == T_S_IN ? e->inj_s_in[layer] : e->inj_s_out[layer];
+    const float* h = c.inj ? (tensor == T_S_IN ? c.inj->s_in[layer] : c.inj->s_out[layer]) : nullptr;
+    s.inj = h ? inj : nullptr;
+    make_key(e, c.step, layer, tensor, s.k0, s.k1);
+    return s;
+}
+static NormalSpec normal_spec(ntf_engine* e, const StepCtx& c, int layer, int tensor) {
+    NormalSpec s;
+    float* inj = tensor == T_EPS_W ? e->inj_eps_w[layer] : e->inj_eps_b[layer];
+    const float* h = c.inj ? (tensor == T_EPS_W ? c.inj->eps_w[layer] : c.inj->eps_b[layer]) : nullptr;
+    s.inj = h ? inj : nullptr;
+    make_key(e, c.step, layer, tensor, s.k0, s.k1);
+    s.tag = (uint32_t)(layer * 8 + tensor); s.step = (uint32_t)c.step;
+    return s;
+}
+
+static int check_ready(ntf_engine* e, bool need_labels) {
+    if (need_labels && !e->m_indptr) FAIL(e, NTF_ESTATE, "member CSR not set (ntf_set_member_csr)");
+    switch (e->cfg.input_mode) {
+        case NTF_INPUT_DENSE: if (!e->Xall) FAIL(e, NTF_ESTATE, "dense input not set (ntf_set_dense_input)"); break;
+        case NTF_INPUT_MEANPOOL: if (!e->table || !e->s_indptr) FAIL(e, NTF_ESTATE, "skill CSR / table not set"); break;
+        case NTF_INPUT_MULTIHOT: if (!e->s_indptr) FAIL(e, NTF_ESTATE, "skill CSR not set"); break;
+        default: FAIL(e, NTF_EINVAL, "bad input_mode");
+    }
+    return NTF_OK;
+}
+
+static int stage_all_inj(ntf_engine* e, const StepCtx& c) {
+    if (!c.inj) return NTF_OK;
+    for (int l = 0; l < e->L; ++l) {
+        const LayerInfo& li = e->layers[l];
+        int r;
+        if (c.inj->eps_w[l] && (r = stage_inj(e, &e->inj_eps_w[l], c.inj->eps_w[l], li.nw()))) return r;
+        if (c.inj->eps_b[l] && (r = stage_inj(e, &e->inj_eps_b[l], c.inj->eps_b[l], li.out))) return r;
+        if (c.inj->s_in[l]) { if (!e->inj_s_in[l]) DM(e, &e->inj_s_in[l], (int64_t)e->cfg.max_batch * li.in);
+            HIPCHK(e, hipMemcpyAsync(e->inj_s_in[l], c.inj->s_in[l], (size_t)c.B * li.in * 4, hipMemcpyHostToDevice, e->st)); }
+        if (c.inj->s_out[l]) { if (!e->inj_s_out[l]) DM(e, &e->inj_s_out[l], (int64_t)e->cfg.max_batch * li.out);
+            HIPCHK(e, hipMemcpyAsync(e->inj_s_out[l], c.inj->s_out[l], (size_t)c.B * li.out * 4, hipMemcpyHostToDevice, e->st)); }
+    }
+    if (c.inj->neg_idx && e->cfg.ns > 0)
+        HIPCHK(e, hipMemcpyAsync(e->d_neg, c.inj->neg_idx, (size_t)c.B * e->cfg.ns * 8, hipMemcpyHostToDevice, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return NTF_OK;
+}
+
+// X = act[0] for the batch (A1/A2 of SURVEY.md §8a)
+static int make_input(ntf_engine* e, const StepCtx& c) {
+    Scope t(e, F_GATHER);
+    const int D = e->cfg.dims[0];
+    if (e->cfg.input_mode == NTF_INPUT_DENSE) launch_gather_dense_rows(e->st, e->Xall, D, c.rows_dev, c.B, e->act[0]);
+    else if (e->cfg.input_mode == NTF_INPUT_MEANPOOL) launch_gather_meanpool(e->st, e->s_indptr, e->s_indices, e->table, c.rows_dev, c.B, D, 1, e->act[0]);
+    else launch_densify_rows(e->st, e->s_indptr, e->s_indices, c.rows_dev, c.B, D, e->act[0]);
+    return NTF_OK;
+}
+
+// forward through every layer.  want_logits: the last layer's leaky_relu output goes to dZout (inference);
+// otherwise its pre-activation goes to Zout (loss).  hidden_only stops before the last layer (fused path).
+static int forward_layers(ntf_engine* e, const StepCtx& c, bool want_logits, bool hidden_only) {
+    const int B = c.B;
+    for (int l = 0; l < e->L; ++l) {
+        const LayerInfo& li = e->layers[l];
+        const bool last = (l == e->L - 1);
+        if (last && hidden_only) break;
+        const float* in = e->act[l];
+        float* W = e->P + li.off[NTF_P_WEIGHT]; float* b = e->P + li.off[NTF_P_BIAS];
+        if (e->cfg.bayesian) {
+            Scope t(e, F_FLIPOUT_OPERAND);
+            launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_WEIGHT], li.nw(), normal_spec(e, c, l, T_EPS_W), e->Wp[l]);
+            launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_BIAS], li.out, normal_spec(e, c, l, T_EPS_B), e->bp[l]);
+        }
+        Scope t(e, last ? F_OUT_FWD : F_GEMM_HIDDEN);
+        GemmArgs g;
+        g.M = B; g.N = li.out; g.K = li.in;
+        g.A = in; g.sam = li.in; g.sak = 1;
+        g.B = W; g.sbk = 1; g.sbn = li.in;
+        g.bias = b;
+        float* zbuf = last ? e->Zout : e->Zh;
+        float* actdst = last ? (want_logits ? e->dZout : nullptr) : e->act[l + 1];
+        if (!e->cfg.bayesian) {
+            g.C = last ? (want_logits ? nullptr : zbuf) : nullptr; g.ldc = li.out;
+            g.Act = actdst; g.ldact = li.out;
+            launch_gemm(e->st, g);
+        } else {
+            g.C = zbuf; g.ldc = li.out;
+            launch_gemm(e->st, g);
+            GemmArgs p = g;
+            p.B = e->Wp[l]; p.bias = e->bp[l];
+            p.sa = sign_spec(e, c, l, T_S_IN, li.in); p.sa_t = 0;
+            p.sc = sign_spec(e, c, l, T_S_OUT, li.out);
+            p.accumulate = 1;
+            p.Act = actdst; p.ldact = li.out;
+            launch_gemm(e->st, p);
+        }
+    }
+    return NTF_OK;
+}
+
+static int sample_negatives(ntf_engine* e, const StepCtx& c) {
+    if (e->cfg.nsd == NTF_NSD_NONE || e->cfg.ns == 0) return NTF_OK;
+    if (c.inj && c.inj->neg_idx) return NTF_OK;  // staged already
+    Scope t(e, F_SAMPLER);
+    uint32_t k0, k1; make_key(e, c.step, 0, T_NEG, k0, k1);
+    const int M = e->cfg.dims[e->L];
+    if (e->cfg.nsd == NTF_NSD_UNIFORM) {
+        launch_ns_uniform(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, k0, k1, (uint32_t)c.step, e->d_neg);
+    } else if (e->cfg.nsd == NTF_NSD_UNIGRAM) {
+        if (!e->al_prob) FAIL(e, NTF_ESTATE, "unigram table not set (ntf_set_unigram)");
+        launch_ns_alias(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, e->al_prob, e->al_alias, e->al_weight, e->al_total,
+                        k0, k1, (uint32_t)c.step, e->d_neg);
+    } else FAIL(e, NTF_EINVAL, "bad nsd");
+    return NTF_OK;
+}
+
+// unigram_b (src/mdl/fnn.py:74-76): per-batch expert frequency y.sum(0)/B over the GLOBAL batch rows (host ids)
+static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int n) {
+    const int M = e->cfg.dims[e->L];
+    std::vector<double> w(M, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const int64_t t = global_rows_host[i];
+        for (int64_t p = e->h_m_indptr[t]; p < e->h_m_indptr[t + 1]; ++p) w[e->h_m_indices[p]] += 1.0;
+    }
+    const float invn = 1.0f / (float)n;  // the reference keeps this table in f32
+    for (int c = 0; c < M; ++c) w[c] = (double)((float)w[c] * invn);
+    return upload_alias(e, w.data(), M);
+}
+
+static int kl_value(ntf_engine* e) {
+    if (!e->cfg.bayesian) return NTF_OK;
+    Scope t(e, F_KL);
+    HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 8, e->st));
+    for (int l = 0; l < e->L; ++l) {
+        const LayerInfo& li = e->layers[l];
+        launch_kl_value(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], li.nw(), 1.0 / (double)li.nw(), e->d_kl);
+        launch_kl_value(e->st, e->P + li.off[NTF_P_BIAS], e->P + li.off[NTF_P_RHO_BIAS], li.out, 1.0 / (double)li.out, e->d_kl);
+    }
+    return NTF_OK;
+}
+
+// forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
+static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
+    int r;
+    const int B = c.B, M = e->cfg.dims[e->L];
+    const float inv_B = 1.0f / (float)c.global_B;
+    const LayerInfo& lo = e->layers[e->L - 1];
+    const bool fused = fused_ok(e);
+    if ((r = make_input(e, c))) return r;
+    if ((r = sample_negatives(e, c))) return r;
+    if ((r = kl_value(e))) return r;
+    const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
+    int nslots;
+    if (fused) {
+        if ((r = forward_layers(e, c, false, true))) return r;
+        FusedOut f;
+        f.B = B; f.H = lo.in; f.M = M; f.bayes = e->cfg.bayesian; f.train = c.train;
+        f.h = e->act[e->L - 1];
+        f.mu = e->P + lo.off[NTF_P_WEIGHT]; f.mu_b = e->P + lo.off[NTF_P_BIAS];
+        f.tnw = e->cfg.tnw; f.tpw = e->cfg.tpw; f.inv_B = inv_B;
+        f.dzT = e->dZout; f.dh_slab = e->dh_slab; f.loss_partial = e->partial;
+        f.dh = e->L > 1 ? e->dAct[(e->L - 1) & 1] : nullptr;
+        f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
+        if (e->cfg.bayesian) {
+            { Scope t(e, F_FLIPOUT_OPERAND);
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1]);
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1]); }
+            f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
+            f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
+        }
+        f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
+        { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f); }
+        nslots = fused_loss_slots(M);
+    } else {
+        if ((r = forward_layers(e, c, false, false))) return r;
+        Scope t(e, F_LOSS);
+        nslots = loss_dense_nchunk(M);
+        launch_loss_dense(e->st, e->Zout, M, B, M, e->cfg.tnw, inv_B, c.train ? e->dZout : nullptr, e->partial, nslots);
+        launch_loss_special(e->st, e->Zout, M, B, M, c.rows_dev, e->m_indptr, e->m_indices, neg, e->cfg.ns, e->cfg.tpw, e->cfg.tnw, inv_B,
+                            c.train ? e->dZout : nullptr, e->row_fix);
+    }
+    {
+        Scope t(e, F_LOSS);
+        const double kl_scale = ((double)B / (double)c.global_B) / (double)c.global_B;
+        launch_loss_finalize(e->st, e->partial, nslots, e->row_fix, B, inv_B, e->cfg.bayesian ? e->d_kl : nullptr, kl_scale, e->d_loss,
+                             accumulate_epoch ? e->d_acc : nullptr, e->d_acc_steps);
+    }
+    if (!c.train) return NTF_OK;
+
+    // ---------------- backward
+    const float kl_share = (float)B / (float)c.global_B;
+    for (int l = e->L - 1; l >= 0; --l) {
+        const LayerInfo& li = e->layers[l];
+        const bool last = (l == e->L - 1);
+        const float* in = e->act[l];
+        float* gW = e->G + li.off[NTF_P_WEIGHT]; float* gb = e->G + li.off[NTF_P_BIAS];
+        float* gRW = e->cfg.bayesian ? e->G + li.off[NTF_P_RHO_WEIGHT] : nullptr;
+        float* gRb = e->cfg.bayesian ? e->G + li.off[NTF_P_RHO_BIAS] : nullptr;
+        SignSpec sin_, sout_;
+        if (e->cfg.bayesian) { sin_ = sign_spec(e, c, l, T_S_IN, li.in); sout_ = sign_spec(e, c, l, T_S_OUT, li.out); }
+        if (last && fused) {
+            FusedDw f;
+            f.B = B; f.H = li.in; f.M = M; f.bayes = e->cfg.bayesian;
+            f.dzT = e->dZout; f.h = in; f.g_mu = gW; f.g_wp = gRW; f.g_b = gb; f.g_bp = gRb; f.s_in = sin_; f.s_out = sout_;
+            Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f);
+        } else {
+            const float* dZ = last ? e->dZout : e->dAct[(l + 1) & 1];
+            { Scope t(e, F_BIAS_GRAD); launch_bias_grad(e->st, dZ, li.out, B, li.out, sout_, gb, gRb); }
+            {
+                Scope t(e, last ? F_OUT_BWD_DW : F_GEMM_HIDDEN);
+                GemmArgs g;
+                g.M = li.out; g.N = li.in; g.K = B;
+                g.A = dZ; g.sam = 1; g.sak = li.out;
+                g.B = in; g.sbk = li.in; g.sbn = 1;
+                g.C = gW; g.ldc = li.in;
+                launch_gemm(e->st, g);
+                if (e->cfg.bayesian) { g.sa = sout_; g.sa_t = 1; g.sb = sin_; g.sb_t = 0; g.C = gRW; launch_gemm(e->st, g); }
+            }
+            if (l > 0) {
+                Scope t(e, last ? F_OUT_BWD_DA : F_GEMM_HIDDEN);
+                float* dA = e->dAct[l & 1];
+                GemmArgs g;
+                g.M = B; g.N = li.in; g.K = li.out;
+                g.A = dZ; g.sam = li.out; g.sak = 1;
+                g.B = e->P + li.off[NTF_P_WEIGHT]; g.sbk = li.in; g.sbn = 1;
+                g.C = dA; g.ldc = li.in;
+                g.mask = e->act[l]; g.ldmask = li.in;
+                const int tiles = ((B + 63) / 64) * ((li.in + 63) / 64);
+                int ks = 1;
+                if (li.out >= 4096) ks = std::max(1, std::min(64, 1024 / tiles));
+                g.ksplit = ks;
+                if (ks > 1) HIPCHK(e, hipMemsetAsync(dA, 0, (size_t)B * li.in * 4, e->st));
+                launch_gemm(e->st, g);
+                if (e->cfg.bayesian) {
+                    g.B = e->Wp[l]; g.sa = sout_; g.sa_t = 0; g.sc = sin_;
+                    if (ks == 1) g.accumulate = 1;
+                    launch_gemm(e->st, g);
+                }
+            }
+        }
+        if (e->cfg.bayesian) {
+            Scope t(e, F_FLIPOUT_FINAL);
+            launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], gW, gRW, li.nw(),
+                                         normal_spec(e, c, l, T_EPS_W), kl_share / ((float)li.nw() * (float)c.global_B));
+            launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_BIAS], e->P + li.off[NTF_P_RHO_BIAS], gb, gRb, li.out,
+                                         normal_spec(e, c, l, T_EPS_B), kl_share / ((float)li.out * (float)c.global_B));
+        }
+    }
+    return NTF_OK;
+}
+
+static int apply_adam(ntf_engine* e) {
+    Scope t(e, F_ADAM);
+    e->adam_t += 1;
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - std::pow(b1, (double)e->adam_t), bc2 = 1.0 - std::pow(b2, (double)e->adam_t);
+    launch_adam(e->st, e->P, e->G, e->M1, e->V2, e->n_params, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
+    return NTF_OK;
+}
+
+static int read_loss(ntf_engine* e, float* loss_out) {
+    if (!loss_out) return NTF_OK;
+    HIPCHK(e, hipMemcpyAsync(loss_out, e->d_loss, 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return NTF_OK;
+}
+
+static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t global_B, const ntf_inject* inj, float* loss_out, bool train,
+                       bool apply, bool rows_on_device, const int64_t* global_rows_host, int n_global) {
+    if (!e) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int r;
+    if ((r = check_ready(e, true))) return r;
+    if (global_B < B) FAIL(e, NTF_EINVAL, "global_B < B");
+    StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
+    if ((r = stage_rows(e, rows, B, rows_on_device, &c.rows_dev))) return r;
+    if ((r = stage_all_inj(e, c))) return r;
+    if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && !(inj && inj->neg_idx)) {
+        if (!global_rows_host) FAIL(e, NTF_EINVAL, "unigram_b needs the batch rows on the host");
+        if ((r = set_batch_unigram(e, global_rows_host, n_global))) return r;
+    }
+    const int saved = e->cfg.nsd;
+    if (saved == NTF_NSD_UNIGRAM_B) e->cfg.nsd = NTF_NSD_UNIGRAM;
+    r = run_step(e, c, true);
+    e->cfg.nsd = saved;
+    if (r) return r;
+    e->last_B = B; e->last_global_B = global_B;
+    if (train && apply && (r = apply_adam(e))) return r;
+    if ((r = read_loss(e, loss_out))) return r;
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
+    return NTF_OK;
+}
+
+extern "C" int ntf_train_step(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* loss_out) {
+    return step_common(e, rows, B, B, inj, loss_out, true, true, false, rows, B);
+}
+extern "C" int ntf_eval_step(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* loss_out) {
+    return step_common(e, rows, B, B, inj, loss_out, false, false, false, rows, B);
+}
+extern "C" int ntf_backward(ntf_engine* e, const int64_t* rows, int32_t B, int32_t global_B, const ntf_inject* inj, float* loss_out) {
+    return step_common(e, rows, B, global_B, inj, loss_out, true, false, false, rows, B);
+}
+extern "C" int ntf_apply(ntf_engine* e) {
+    if (!e) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    return apply_adam(e);
+}
+
+static int run_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss, bool train) {
+    if (!e || !order || n < 1 || B < 1 || B > e->cfg.max_batch) { if (e) e->err = "epoch: bad arguments"; return NTF_EINVAL; }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    for (int64_t i = 0; i < n; ++i) if (order[i] < 0 || (e->m_rows && order[i] >= e->m_rows)) FAIL(e, NTF_EINVAL, "epoch: row id out of range");
+    if (e->order_cap < n) { dfree(e->d_order); DM(e, &e->d_order, n); e->order_cap = n; }
+    HIPCHK(e, hipMemcpyAsync(e->d_order, order, (size_t)n * 8, hipMemcpyHostToDevice, e->st));
+    HIPCHK(e, hipMemsetAsync(e->d_acc, 0, 8, e->st));
+    HIPCHK(e, hipMemsetAsync(e->d_acc_steps, 0, 8, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    for (int64_t o = 0; o < n; o += B) {
+        const int b = (int)std::min<int64_t>(B, n - o);
+        int r = step_common(e, e->d_order + o, b, b, nullptr, nullptr, train, train, true, order + o, b);
+        if (r) return r;
+    }
+    double sum = 0; int64_t steps = 0;
+    int r = ntf_epoch_loss(e, &sum, &steps);
+    if (r) return r;
+    if (mean_loss) *mean_loss = steps ? (float)(sum / (double)steps) : 0.f;
+    return NTF_OK;
+}
+extern "C" int ntf_train_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss) { return run_epoch(e, order, n, B, mean_loss, true); }
+extern "C" int ntf_eval_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss) { return run_epoch(e, order, n, B, mean_loss, false); }
+extern "C" int ntf_epoch_loss(ntf_engine* e, double* sum, int64_t* steps) {
+    if (!e) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    double s = 0; int64_t k = 0;
+    HIPCHK(e, hipMemcpyAsync(&s, e->d_acc, 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipMemcpyAsync(&k, e->d_acc_steps, 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipMemsetAsync(e->d_acc, 0, 8, e->st));
+    HIPCHK(e, hipMemsetAsync(e->d_acc_steps, 0, 8, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    if (sum) *sum = s;
+    if (steps) *steps = k;
+    return NTF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ inference
+static int infer_pass(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, StepCtx& c) {
+    int r;
+    if ((r = check_ready(e, false))) return r;
+    c.B = B; c.global_B = B; c.inj = inj; c.train = false; c.step = e->step++;
+    if ((r = stage_rows(e, rows, B, false, &c.rows_dev))) return r;
+    StepCtx ci = c;
+    ntf_inject noneg;
+    if (inj) { noneg = *inj; noneg.neg_idx = nullptr; ci.inj = &noneg; }
+    if ((r = stage_all_inj(e, ci))) return r;
+    if ((r = make_input(e, c))) return r;
+    return forward_layers(e, c, true, false);  // logits (post leaky_relu) in dZout
+}
+
+extern "C" int ntf_logits(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* logits_host) {
+    if (!e || !logits_host) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    StepCtx c; int r = infer_pass(e, rows, B, inj, c); if (r) return r;
+    HIPCHK(e, hipMemcpyAsync(logits_host, e->dZout, (size_t)B * e->cfg.dims[e->L] * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return NTF_OK;
+}
+
+static int infer_probs(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, const ntf_inject* inj_per_mc, bool want_unc) {
+    const int M = e->cfg.dims[e->L];
+    if (!e->Pbuf) DM(e, &e->Pbuf, (int64_t)e->cfg.max_batch * M);
+    const int passes = e->cfg.bayesian ? std::max(1, nmc) : 1;
+    if (want_unc) HIPCHK(e, hipMemsetAsync(e->ent_mc, 0, (size_t)B * 4, e->st));
+    for (int p = 0; p < passes; ++p) {
+        StepCtx c; int r = infer_pass(e, rows, B, inj_per_mc ? &inj_per_mc[p] : nullptr, c); if (r) return r;
+        Scope t(e, F_INFER);
+        launch_sigmoid_acc(e->st, e->dZout, B, M, 1.0f / (float)passes, p > 0, e->Pbuf, want_unc ? e->ent_mc : nullptr);
+    }
+    if (want_unc) { Scope t(e, F_INFER); launch_row_entropy(e->st, e->Pbuf, B, M, e->ent_mean); }
+    return NTF_OK;
+}
+
+static int copy_unc(ntf_engine* e, int B, float* pred_unc, float* model_unc) {
+    if (!pred_unc && !model_unc) return NTF_OK;
+    std::vector<float> em(B), ec(B);
+    HIPCHK(e, hipMemcpyAsync(em.data(), e->ent_mean, (size_t)B * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipMemcpyAsync(ec.data(), e->ent_mc, (size_t)B * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    for (int i = 0; i < B; ++i) { if (pred_unc) pred_unc[i] = em[i]; if (model_unc) model_unc[i] = em[i] - ec[i]; }
+    return NTF_OK;
+}
+
+extern "C" int ntf_forward(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, const ntf_inject* inj_per_mc, float* probs_host,
+                           float* pred_unc, float* model_unc) {
+    if (!e || !probs_host) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int r = infer_probs(e, rows, B, nmc, inj_per_mc, pred_unc || model_unc); if (r) return r;
+    HIPCHK(e, hipMemcpyAsync(probs_host, e->Pbuf, (size_t)B * e->cfg.dims[e->L] * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return copy_unc(e, B, pred_unc, model_unc);
+}
+
+extern "C" int ntf_forward_topk(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, int32_t K, float* values_host,
+                                int32_t* indices_host, float* pred_unc, float* model_unc) {
+    if (!e || !values_host || !indices_host) return NTF_EINVAL;
+    const int M = e->cfg.dims[e->L];
+    if (K < 1 || K > M || K > 2048) FAIL(e, NTF_EINVAL, "topk: K must be in [1, min(M, 2048)]");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int r = infer_probs(e, rows, B, nmc, nullptr, pred_unc || model_unc); if (r) return r;
+    if (e->tk_cap < (int64_t)e->cfg.max_batch * K) { dfree(e->tk_vals); dfree(e->tk_idx); e->tk_cap = (int64_t)e->cfg.max_batch * K; DM(e, &e->tk_vals, e->tk_cap); DM(e, &e->tk_idx, e->tk_cap); }
+    { Scope t(e, F_INFER); launch_topk_rows(e->st, e->Pbuf, B, M, K, e->tk_vals, e->tk_idx, nullptr); }
+    HIPCHK(e, hipMemcpyAsync(values_host, e->tk_vals, (size_t)B * K * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipMemcpyAsync(indices_host, e->tk_idx, (size_t)B * K * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return copy_unc(e, B, pred_unc, model_unc);
+}
+
+extern "C" int ntf_gather_meanpool(ntf_engine* e, const int64_t* rows, int64_t n, float* out_host) {
+    if (!e || n < 1) return NTF_EINVAL;
+    if (!e->table || !e->s_indptr) FAIL(e, NTF_ESTATE, "skill CSR / table not set");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (!rows && n > e->s_rows) FAIL(e, NTF_EINVAL, "gather: n exceeds the CSR rows");
+    int64_t* drows = nullptr; float* dout = nullptr;
+    if (rows) {
+        for (int64_t i = 0; i < n; ++i) if (rows[i] < 0 || rows[i] >= e->s_rows) FAIL(e, NTF_EINVAL, "gather: row id out of range");
+        DM(e, &drows, n); HIPCHK(e, hipMemcpy(drows, rows, n * 8, hipMemcpyHostToDevice));
+    }
+    int rc = dmalloc(e, &dout, n * e->table_d);
+    if (rc) { dfree(drows); return rc; }
+    { Scope t(e, F_GATHER); launch_gather_meanpool(e->st, e->s_indptr, e->s_indices, e->table, drows, n, e->table_d, 1, dout); }
+    hipError_t s = hipStreamSynchronize(e->st);
+    if (s == hipSuccess && out_host) s = hipMemcpy(out_host, dout, n * e->table_d * 4, hipMemcpyDeviceToHost);
+    dfree(drows); dfree(dout);
+    if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("gather: ") + hipGetErrorString(s));
+    return NTF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ views
+extern "C" int ntf_grad_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats) {
+    if (!e || !dev_ptr || !n_floats) return NTF_EINVAL; *dev_ptr = e->G; *n_floats = e->n_params; return NTF_OK;
+}
+extern "C" int ntf_param_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats) {
+    if (!e || !dev_ptr || !n_floats) return NTF_EINVAL; *dev_ptr = e->P; *n_floats = e->n_params; return NTF_OK;
+}
+extern "C" int ntf_synchronize(ntf_engine* e) {
+    if (!e) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return NTF_OK;
+}
+extern "C" int ntf_kernel_times(ntf_engine* e, int enable, const char** names, double* ms, int64_t* calls, int cap) {
+    if (!e) return NTF_EINVAL;
+    hipSetDevice(e->cfg.device);
+    drain_times(e);
+    int n = std::min(cap, (int)F_COUNT);
+    for (int i = 0; i < n; ++i) { if (names) names[i] = kFamNames[i]; if (ms) ms[i] = e->fam_ms[i]; if (calls) calls[i] = e->fam_calls[i]; }
+    for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_calls[i] = 0; }
+    e->timing = enable != 0;
+    return F_COUNT;
+}
+
+extern "C" int ntf_k_gemm_f32(void* stream, int m, int n, int k, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+                              int64_t sbn, float* C, int64_t ldc) {
+    if (m < 1 || n < 1 || k < 1 || !A || !B || !C) return NTF_EINVAL;
+    GemmArgs g; g.M = m; g.N = n; g.K = k; g.A = A; g.sam = sam; g.sak = sak; g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc;
+    launch_gemm((hipStream_t)stream, g);
+    return hipGetLastError() == hipSuccess ? NTF_OK : NTF_EHIP;
+}
+
+extern "C" int ntf_k_fill_normal(void* stream, uint64_t seed, uint64_t step, int layer, int64_t n, float* dev_out) {
+    if (n < 1 || !dev_out) return NTF_EINVAL;
+    ntf_engine tmp; tmp.seed = seed;
+    NormalSpec s; make_key(&tmp, step, layer, T_EPS_W, s.k0, s.k1); s.tag = (uint32_t)(layer * 8 + T_EPS_W); s.step = (uint32_t)step;
+    launch_fill_normal((hipStream_t)stream, s, n, dev_out);
+    return hipGetLastError() == hipSuccess ? NTF_OK : NTF_EHIP;
+}
+extern "C" int ntf_k_fill_sign(void* stream, uint64_t seed, uint64_t step, int layer, int rows, int cols, float* dev_out) {
+    if (rows < 1 || cols < 1 || !dev_out) return NTF_EINVAL;
+    ntf_engine tmp; tmp.seed = seed;
+    SignSpec s; s.enabled = 1; s.ld = cols; make_key(&tmp, step, layer, T_S_OUT, s.k0, s.k1);
+    launch_fill_sign((hipStream_t)stream, s, rows, cols, dev_out);
+    return hipGetLastError() == hipSuccess ? NTF_OK : NTF_EHIP;
+}

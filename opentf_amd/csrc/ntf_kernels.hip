@@ -1,0 +1,621 @@
+// gfx950 kernels of the OpeNTF fnn/bnn hot path: generic f32-MFMA GEMM, CSR gathers, Flipout operand
+// producers, sparse-label weighted-BCE, negative samplers, KL, Adam.  The fused output-layer kernels
+// live in ntf_fused.hip.  Written for CDNA4 only (wave64, v_mfma_f32_32x32x2_f32).
+#include "ntf_kernels.h"
+#include "ntf_device.h"
+#include <algorithm>
+
+namespace ntf {
+
+// =====================================================================================
+// Generic GEMM  C(m,n) = sum_k A(m,k) B(k,n)  on v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain).
+// 64x64 block tile, 4 waves each owning a 32x32 accumulator, K staged 32 deep through LDS as
+// [row][k] images with an odd row stride (33) so that both the staging writes and the fragment reads
+// (32 lanes = 32 rows, same k) are bank-conflict free.  Arbitrary strides: each operand is read along
+// whichever of its two axes is contiguous.  Used for the hidden layers, for odd shapes, and as the
+// unfused reference path of the output layer.
+// =====================================================================================
+constexpr int GBM = 64, GBN = 64, GBK = 32, GLD = GBK + 1;
+
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+    __shared__ float As[GBM * GLD];
+    __shared__ float Bs[GBN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    int kper = (a.K + a.ksplit - 1) / a.ksplit;
+    kper = (kper + GBK - 1) / GBK * GBK;
+    const int kbeg = blockIdx.z * kper;
+    const int kend = min(a.K, kbeg + kper);
+    const bool a_kc = (a.sak == 1), b_nc = (a.sbn == 1);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        float ra[8], rb[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            int mm, kk;
+            if (a_kc) { kk = tid & 31; mm = (tid >> 5) + p * 8; } else { mm = tid & 63; kk = (tid >> 6) + p * 4; }
+            const int gm = m0 + mm, gk = k0 + kk;
+            float v = 0.f;
+            if (gm < a.M && gk < kend) {
+                v = a.A[(int64_t)gm * a.sam + (int64_t)gk * a.sak];
+                if (a.sa.enabled) v *= a.sa_t ? sign_at(a.sa, gk, gm) : sign_at(a.sa, gm, gk);
+            }
+            ra[p] = v;
+            int nn, kb;
+            if (b_nc) { nn = tid & 63; kb = (tid >> 6) + p * 4; } else { kb = tid & 31; nn = (tid >> 5) + p * 8; }
+            const int gn = n0 + nn, gkb = k0 + kb;
+            float w = 0.f;
+            if (gn < a.N && gkb < kend) {
+                w = a.B[(int64_t)gkb * a.sbk + (int64_t)gn * a.sbn];
+                if (a.sb.enabled) w *= a.sb_t ? sign_at(a.sb, gn, gkb) : sign_at(a.sb, gkb, gn);
+            }
+            rb[p] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            int mm, kk;
+            if (a_kc) { kk = tid & 31; mm = (tid >> 5) + p * 8; } else { mm = tid & 63; kk = (tid >> 6) + p * 4; }
+            As[mm * GLD + kk] = ra[p];
+            int nn, kb;
+            if (b_nc) { nn = tid & 63; kb = (tid >> 6) + p * 4; } else { kb = tid & 31; nn = (tid >> 5) + p * 8; }
+            Bs[nn * GLD + kb] = rb[p];
+        }
+        __syncthreads();
+        const float* ap = &As[(wm * 32 + (lane & 31)) * GLD + (lane >> 5)];
+        const float* bp = &Bs[(wn * 32 + (lane & 31)) * GLD + (lane >> 5)];
+#pragma unroll
+        for (int kk = 0; kk < GBK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[2 * kk], acc, 0, 0, 0);
+    }
+
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= a.N) return;
+    const float bias = (a.bias && blockIdx.z == 0) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M) continue;
+        float v = acc[r] * a.alpha + bias;
+        if (a.sc.enabled) v *= sign_at(a.sc, row, col);
+        if (a.mask) v *= (a.mask[(int64_t)row * a.ldmask + col] > 0.f) ? 1.f : kLeakySlope;
+        if (a.ksplit > 1) {
+            atomicAdd(&a.C[(int64_t)row * a.ldc + col], v);
+        } else {
+            if (a.accumulate) v += a.C[(int64_t)row * a.ldc + col];
+            if (a.C) a.C[(int64_t)row * a.ldc + col] = v;
+            if (a.Act) a.Act[(int64_t)row * a.ldact + col] = v > 0.f ? v : v * kLeakySlope;
+        }
+    }
+}
+
+void launch_gemm(hipStream_t st, const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0) return;
+    dim3 grid((a.N + GBN - 1) / GBN, (a.M + GBM - 1) / GBM, a.ksplit > 1 ? a.ksplit : 1);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, a);
+}
+
+// =====================================================================================
+// CSR gathers.  One team per sub-group of G lanes (G*4 >= d floats, 16-byte loads), the team's column ids
+// are read coalesced by the sub-group and broadcast with shuffles; up to 8 table rows are in flight per
+// sub-group before the (CSR-ordered, f32) accumulation, which keeps the result bit-identical to the
+// sequential host sum.  mean=1: Gnn.get_dense_vecs (src/mdl/emb/gnn.py:485); mean=0: multi-hot @ W^T.
+// =====================================================================================
+template <int G>
+__global__ __launch_bounds__(256) void k_gather_pool(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                     const float* __restrict__ table, const int64_t* __restrict__ rows,
+                                                     int64_t n, int d, int mean, int vec, float* __restrict__ out) {
+    constexpr int TPW = 64 / G;  // teams per wave
+    const int lane = threadIdx.x & 63, sub = lane / G, sl = lane % G;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t t = wave_global * TPW + sub;
+    const bool live = t < n;
+    const int64_t team = live ? (rows ? rows[t] : t) : 0;
+    const int64_t beg = live ? indptr[team] : 0, end = live ? indptr[team + 1] : 0;
+    const int nnz = (int)(end - beg);
+    const int nchunk = (d + 4 * G - 1) / (4 * G);  // float4 chunks per lane (1 when d <= 4G)
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c0 = (ch * G + sl) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = 0; base < nnz; base += G) {
+            const int mine = base + sl;
+            const int my_idx = (mine < nnz) ? indices[beg + mine] : 0;
+            const int cnt = min(G, nnz - base);
+            for (int j0 = 0; j0 < cnt; j0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    const int s = __shfl(my_idx, sub * G + (j < cnt ? j : 0), 64);
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < cnt) {
+                        const float* rp = table + (int64_t)s * d + c0;
+                        if (vec && c0 + 3 < d) v[u] = *reinterpret_cast<const float4*>(rp);
+                        else { if (c0 < d) v[u].x = rp[0]; if (c0 + 1 < d) v[u].y = rp[1]; if (c0 + 2 < d) v[u].z = rp[2]; if (c0 + 3 < d) v[u].w = rp[3]; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < cnt) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+        }
+        if (live && c0 < d) {
+            if (mean) { const float c = (float)nnz; acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c; }
+            float* op = out + t * d + c0;
+            if (vec && c0 + 3 < d) *reinterpret_cast<float4*>(op) = acc;
+            else { op[0] = acc.x; if (c0 + 1 < d) op[1] = acc.y; if (c0 + 2 < d) op[2] = acc.z; if (c0 + 3 < d) op[3] = acc.w; }
+        }
+    }
+}
+
+void launch_gather_meanpool(hipStream_t st, const int64_t* indptr, const int32_t* indices, const float* table,
+                            const int64_t* rows, int64_t n, int d, int mean, float* out) {
+    if (n <= 0) return;
+    const bool vec_ok = (d % 4 == 0);
+    // sub-group width: smallest power of two >= d/4, within [16, 64]; unaligned d falls back to G=64 scalar tails
+    int G = 16;
+    while (G < 64 && G * 4 < d) G *= 2;
+    if (!vec_ok) G = 64;
+    const int tpw = 64 / G;
+    const int64_t waves = (n + tpw - 1) / tpw;
+    const int64_t blocks = (waves + 3) / 4;
+    if (G == 16) hipLaunchKernelGGL(k_gather_pool<16>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, indices, table, rows, n, d, mean, vec_ok ? 1 : 0, out);
+    else if (G == 32) hipLaunchKernelGGL(k_gather_pool<32>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, indices, table, rows, n, d, mean, vec_ok ? 1 : 0, out);
+    else hipLaunchKernelGGL(k_gather_pool<64>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, indices, table, rows, n, d, mean, vec_ok ? 1 : 0, out);
+}
+
+__global__ void k_gather_dense_rows(const float* __restrict__ X, int d, const int64_t* __restrict__ rows, int64_t n, float* __restrict__ out) {
+    const int64_t i = blockIdx.x;
+    const float* src = X + rows[i] * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[i * d + c] = src[c];
+}
+void launch_gather_dense_rows(hipStream_t st, const float* X, int d, const int64_t* rows, int64_t n, float* out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_dense_rows, dim3((unsigned)n), dim3(d >= 256 ? 256 : 64), 0, st, X, d, rows, n, out);
+}
+
+__global__ void k_densify_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const int64_t* __restrict__ rows,
+                               int width, float* __restrict__ out) {
+    const int64_t i = blockIdx.x, team = rows[i];
+    for (int c = threadIdx.x; c < width; c += blockDim.x) out[i * width + c] = 0.f;
+    __syncthreads();
+    for (int64_t p = indptr[team] + threadIdx.x; p < indptr[team + 1]; p += blockDim.x) out[i * width + indices[p]] = 1.f;
+}
+void launch_densify_rows(hipStream_t st, const int64_t* indptr, const int32_t* indices, const int64_t* rows, int64_t n, int width, float* out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_densify_rows, dim3((unsigned)n), dim3(256), 0, st, indptr, indices, rows, width, out);
+}
+
+// =====================================================================================
+// Flipout operand producer / gradient finaliser / KL  (bayesian-torch LinearFlipout + kl_div, restated)
+// =====================================================================================
+__global__ void k_flipout_perturb(const float* __restrict__ rho, int64_t n, NormalSpec eps, float* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // quad index
+    const int64_t e0 = q * 4;
+    if (e0 >= n) return;
+    float z[4];
+    normal4(eps, q, e0, n, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (e0 + j < n) out[e0 + j] = softplus_rho(rho[e0 + j]) * z[j];
+}
+void launch_flipout_perturb(hipStream_t st, const float* rho, int64_t n, NormalSpec eps, float* out) {
+    if (n <= 0) return;
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(k_flipout_perturb, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rho, n, eps, out);
+}
+
+__global__ void k_flipout_grad_finalize(const float* __restrict__ mu, const float* __restrict__ rho, float* __restrict__ g_mu,
+                                        float* __restrict__ g_rho, int64_t n, NormalSpec eps, float klw) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e0 = q * 4;
+    if (e0 >= n) return;
+    float z[4];
+    normal4(eps, q, e0, n, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t e = e0 + j;
+        if (e >= n) break;
+        const float r = rho[e];
+        const float sg = 1.f / (1.f + expf(-r));  // d softplus / d rho
+        const float sigma = softplus_rho(r);
+        g_rho[e] = g_rho[e] * z[j] * sg + klw * (sigma - 1.f / sigma) * sg;
+        g_mu[e] += klw * mu[e];
+    }
+}
+void launch_flipout_grad_finalize(hipStream_t st, const float* mu, const float* rho, float* g_mu, float* g_rho, int64_t n,
+                                  NormalSpec eps, float klw) {
+    if (n <= 0) return;
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(k_flipout_grad_finalize, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, mu, rho, g_mu, g_rho, n, eps, klw);
+}
+
+__global__ void k_kl_value(const float* __restrict__ mu, const float* __restrict__ rho, int64_t n, double w, double* out) {
+    double s = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float sigma = softplus_rho(rho[e]);
+        const float m = mu[e];
+        s += (double)(-logf(sigma) + 0.5f * (sigma * sigma + m * m) - 0.5f);
+    }
+    s = block_reduce_sum_d(s);
+    if (threadIdx.x == 0) atomicAdd(out, s * w);
+}
+void launch_kl_value(hipStream_t st, const float* mu, const float* rho, int64_t n, double w, double* out) {
+    if (n <= 0) return;
+    int blocks = (int)std::min<int64_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_kl_value, dim3(blocks), dim3(256), 0, st, mu, rho, n, w, out);
+}
+
+// =====================================================================================
+// Output-layer loss with sparse labels (src/mdl/fnn.py:32-46,135): dense pass + sparse fix-up.
+// =====================================================================================
+constexpr int LCH = 1024;  // columns per block in the dense pass
+int loss_dense_nchunk(int M) { return (M + LCH - 1) / LCH; }
+
+__global__ __launch_bounds__(256) void k_loss_dense(const float* __restrict__ Z, int64_t ld, int M, float tnw, float inv_B,
+                                                    float* __restrict__ dZ, float* __restrict__ partial, int nchunk) {
+    const int i = blockIdx.y, ch = blockIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LCH / 256; ++j) {
+        const int c = ch * LCH + j * 256 + threadIdx.x;
+        if (c < M) {
+            const float z = Z[(int64_t)i * ld + c];
+            float sp, sg, dact;
+            bce_terms(z, sp, sg, dact);
+            s += sp;
+            if (dZ) dZ[(int64_t)i * ld + c] = tnw * sg * dact * inv_B;
+        }
+    }
+    s = block_reduce_sum(s);
+    if (threadIdx.x == 0) partial[(int64_t)i * nchunk + ch] = tnw * s;
+}
+void launch_loss_dense(hipStream_t st, const float* Z, int64_t ld, int B, int M, float tnw, float inv_B, float* dZ, float* partial, int nchunk) {
+    hipLaunchKernelGGL(k_loss_dense, dim3(nchunk, B), dim3(256), 0, st, Z, ld, M, tnw, inv_B, dZ, partial, nchunk);
+}
+
+// one wave per row; lane j takes special j (positives first, then the selected negatives)
+__global__ __launch_bounds__(64) void k_loss_special(const float* __restrict__ Z, int64_t ld, int M, const int64_t* __restrict__ rows,
+                                                     const int64_t* __restrict__ m_indptr, const int32_t* __restrict__ m_indices,
+                                                     const int64_t* __restrict__ neg, int ns, float tpw, float tnw, float inv_B,
+                                                     float* __restrict__ dZ, float* __restrict__ row_fix) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int64_t team = rows[i];
+    const int64_t pb = m_indptr[team];
+    const int npos = (int)(m_indptr[team + 1] - pb);
+    const int total = npos + (neg ? ns : 0);
+    float fix = 0.f;
+    for (int j = lane; j < total; j += 64) {
+        int c; float y; bool skip = false;
+        if (j < npos) { c = m_indices[pb + j]; y = 1.f; }
+        else {
+            const int q = j - npos;
+            c = (int)neg[(int64_t)i * ns + q]; y = 0.f;
+            for (int p = 0; p < npos; ++p) if (m_indices[pb + p] == c) skip = true;       // selected a positive: stays y=1, handled above
+            for (int p = 0; p < q; ++p) if ((int)neg[(int64_t)i * ns + p] == c) skip = true;  // duplicate pick
+        }
+        if (skip || c < 0 || c >= M) continue;
+        const float z = Z[(int64_t)i * ld + c];
+        float sp, sg, dact;
+        bce_terms(z, sp, sg, dact);
+        const float l = z > 0.f ? z : z * kLeakySlope;
+        fix += tpw * (sp - l * y) - tnw * sp;
+        if (dZ) dZ[(int64_t)i * ld + c] = tpw * (sg - y) * dact * inv_B;
+    }
+    fix = wave_reduce_sum(fix);
+    if (lane == 0) row_fix[i] = fix;
+}
+void launch_loss_special(hipStream_t st, const float* Z, int64_t ld, int B, int M, const int64_t* rows, const int64_t* m_indptr,
+                         const int32_t* m_indices, const int64_t* neg, int ns, float tpw, float tnw, float inv_B, float* dZ, float* row_fix) {
+    hipLaunchKernelGGL(k_loss_special, dim3(B), dim3(64), 0, st, Z, ld, M, rows, m_indptr, m_indices, neg, ns, tpw, tnw, inv_B, dZ, row_fix);
+}
+
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ partial, int nchunk, const float* __restrict__ row_fix, int B,
+                                                       float inv_B, const double* __restrict__ kl, double kl_scale, float* out,
+                                                       double* acc, int64_t* acc_steps) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        float r = 0.f;
+        for (int c = 0; c < nchunk; ++c) r += partial[(int64_t)i * nchunk + c];
+        s += (double)(r + row_fix[i]);
+    }
+    s = block_reduce_sum_d(s);
+    if (threadIdx.x == 0) {
+        double loss = s * (double)inv_B + (kl ? kl[0] * kl_scale : 0.0);
+        out[0] = (float)loss;
+        if (acc) { acc[0] += (double)(float)loss; acc_steps[0] += 1; }
+    }
+}
+void launch_loss_finalize(hipStream_t st, const float* partial, int nchunk, const float* row_fix, int B, float inv_B, const double* kl,
+                          double kl_scale, float* out, double* acc, int64_t* acc_steps) {
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, st, partial, nchunk, row_fix, B, inv_B, kl, kl_scale, out, acc, acc_steps);
+}
+
+__global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dZ, int64_t ld, int B, int N, SignSpec sout,
+                                                   float* __restrict__ g_b, float* __restrict__ g_pert) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float v = dZ[(int64_t)b * ld + n];
+        s1 += v;
+        if (g_pert) s2 += v * sign_at(sout, b, n);
+    }
+    g_b[n] = s1;
+    if (g_pert) g_pert[n] = s2;
+}
+void launch_bias_grad(hipStream_t st, const float* dZ, int64_t ld, int B, int N, SignSpec sout, float* g_b, float* g_pert) {
+    hipLaunchKernelGGL(k_bias_grad, dim3((N + 255) / 256), dim3(256), 0, st, dZ, ld, B, N, sout, g_b, g_pert);
+}
+
+// =====================================================================================
+// Negative samplers as index generators (src/mdl/fnn.py:48-76).  One thread per row.
+// Sequential sampling without replacement == draw with replacement and reject members / repeats, which
+// is the distribution of rand+topk (uniform) and of multinomial(replacement=False) (weighted).
+// =====================================================================================
+__device__ __forceinline__ bool is_member(const int32_t* mi, int npos, int c) {
+    for (int p = 0; p < npos; ++p) if (mi[p] == c) return true;
+    return false;
+}
+
+__global__ void k_ns_uniform(const int64_t* __restrict__ rows, int B, int M, int ns, const int64_t* __restrict__ m_indptr,
+                             const int32_t* __restrict__ m_indices, uint32_t k0, uint32_t k1, uint32_t step, int64_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t team = rows[i];
+    const int32_t* mi = m_indices + m_indptr[team];
+    const int npos = (int)(m_indptr[team + 1] - m_indptr[team]);
+    int64_t* o = out + (int64_t)i * ns;
+    uint32_t ctr = 0;
+    for (int q = 0; q < ns; ++q) {
+        int pick = -1;
+        for (int tries = 0; tries < 4096 && pick < 0; ++tries) {
+            const uint4 r = philox4x32(make_uint4((uint32_t)i, ctr++, step, 0x4e533031u), make_uint2(k0, k1));
+            const uint32_t cand[4] = {r.x, r.y, r.z, r.w};
+            for (int u = 0; u < 4 && pick < 0; ++u) {
+                const int c = (int)__umulhi(cand[u], (uint32_t)M);
+                bool bad = is_member(mi, npos, c);
+                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) pick = c;
+            }
+        }
+        if (pick < 0) {  // fewer than ns negatives in the row: topk then returns positives (fnn.py:54); any unused column
+            for (int c = 0; c < M && pick < 0; ++c) {
+                bool bad = false;
+                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad && !is_member(mi, npos, c)) pick = c;
+            }
+            for (int c = 0; c < M && pick < 0; ++c) {
+                bool bad = false;
+                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) pick = c;
+            }
+        }
+        o[q] = pick;
+    }
+}
+void launch_ns_uniform(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
+                       uint32_t k0, uint32_t k1, uint32_t step, int64_t* out) {
+    hipLaunchKernelGGL(k_ns_uniform, dim3((B + 63) / 64), dim3(64), 0, st, rows, B, M, ns, m_indptr, m_indices, k0, k1, step, out);
+}
+
+__global__ void k_ns_alias(const int64_t* __restrict__ rows, int B, int M, int ns, const int64_t* __restrict__ m_indptr,
+                           const int32_t* __restrict__ m_indices, const float* __restrict__ prob, const int32_t* __restrict__ alias,
+                           const double* __restrict__ weight, double total_weight, uint32_t k0, uint32_t k1, uint32_t step,
+                           int64_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t team = rows[i];
+    const int32_t* mi = m_indices + m_indptr[team];
+    const int npos = (int)(m_indptr[team + 1] - m_indptr[team]);
+    int64_t* o = out + (int64_t)i * ns;
+    double negw = total_weight;
+    for (int p = 0; p < npos; ++p) negw -= weight[mi[p]];
+    const bool fallback = !(negw > 1e-12 * total_weight);  // all sampling weight sits on the row's members (fnn.py:67-69)
+    uint32_t ctr = 0;
+    for (int q = 0; q < ns; ++q) {
+        int pick = -1;
+        for (int tries = 0; tries < 8192 && pick < 0; ++tries) {
+            const uint4 r = philox4x32(make_uint4((uint32_t)i, ctr++, step, 0x4e533032u), make_uint2(k0, k1));
+            for (int u = 0; u < 2 && pick < 0; ++u) {
+                const uint32_t a = u ? r.z : r.x, b = u ? r.w : r.y;
+                int c = (int)__umulhi(a, (uint32_t)M);
+                bool bad;
+                if (fallback) bad = false;  // uniform over ALL columns, members included
+                else {
+                    if (u01(b) >= prob[c]) c = alias[c];
+                    bad = is_member(mi, npos, c) || !(weight[c] > 0.0);
+                }
+                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) pick = c;
+            }
+        }
+        if (pick < 0) {  // fewer than ns columns with weight: multinomial would raise; take any unused column
+            for (int c = 0; c < M && pick < 0; ++c) {
+                bool bad = false;
+                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) pick = c;
+            }
+        }
+        o[q] = pick;
+    }
+}
+void launch_ns_alias(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
+                     const float* prob, const int32_t* alias, const double* weight, double total_weight, uint32_t k0, uint32_t k1,
+                     uint32_t step, int64_t* out) {
+    hipLaunchKernelGGL(k_ns_alias, dim3((B + 63) / 64), dim3(64), 0, st, rows, B, M, ns, m_indptr, m_indices, prob, alias, weight,
+                       total_weight, k0, k1, step, out);
+}
+
+// =====================================================================================
+// Adam (torch.optim.Adam defaults, src/mdl/fnn.py:104,139) over the flat parameter buffer
+// =====================================================================================
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                       float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float gg = g[e];
+        const float mm = m[e] + (1.f - b1) * (gg - m[e]);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vv = v[e] * b2 + (1.f - b2) * gg * gg;          // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[e] = mm; v[e] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[e] = p[e] - lr_over_bc1 * (mm / denom);
+    }
+}
+void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                 float bc1, float bc2_sqrt) {
+    if (n <= 0) return;
+    int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr / bc1, b1, b2, eps, bc2_sqrt);
+}
+
+__global__ void k_fill(float* p, int64_t n, float v) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
+}
+void launch_fill(hipStream_t st, float* p, int64_t n, float v) {
+    if (n <= 0) return;
+    int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, st, p, n, v);
+}
+
+// =====================================================================================
+// Inference helpers (src/mdl/fnn.py:200-211): sigmoid, MC mean, predictive entropy / mutual information
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_sigmoid_acc(const float* __restrict__ Act, int M, float scale, int accumulate,
+                                                     float* __restrict__ out, float* __restrict__ ent_rows) {
+    const int64_t i = blockIdx.y;
+    float ent = 0.f;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < M; c += gridDim.x * 256) {
+        const float l = Act[i * M + c];
+        const float p = 1.f / (1.f + expf(-l));
+        const float prev = accumulate ? out[i * M + c] : 0.f;
+        out[i * M + c] = prev + p * scale;
+        ent -= p * logf(p + 1e-15f);
+    }
+    if (ent_rows) {
+        ent = block_reduce_sum(ent);
+        if (threadIdx.x == 0) atomicAdd(&ent_rows[i], ent * scale);
+    }
+}
+void launch_sigmoid_acc(hipStream_t st, const float* Act, int64_t n_rows, int M, float scale, int accumulate, float* out, float* ent_rows) {
+    int bx = min((M + 255) / 256, 64);
+    hipLaunchKernelGGL(k_sigmoid_acc, dim3(bx, (unsigned)n_rows), dim3(256), 0, st, Act, M, scale, accumulate, out, ent_rows);
+}
+__global__ __launch_bounds__(256) void k_row_entropy(const float* __restrict__ P, int M, float* __restrict__ ent) {
+    const int64_t i = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < M; c += 256) { const float p = P[i * M + c]; s -= p * logf(p + 1e-15f); }
+    s = block_reduce_sum(s);
+    if (threadIdx.x == 0) ent[i] = s;
+}
+void launch_row_entropy(hipStream_t st, const float* P, int n_rows, int M, float* ent) {
+    hipLaunchKernelGGL(k_row_entropy, dim3(n_rows), dim3(256), 0, st, P, M, ent);
+}
+
+// =====================================================================================
+// Row-wise top-K of the probabilities (src/pkgmgr.py:125-134 topk): per row a 3-pass radix select on the
+// f32 bit pattern (probabilities are positive, so the unsigned order is the value order) finds the K-th
+// value, then the row is compacted and the K survivors are sorted (descending value, ascending index for
+// ties) by a bitonic sort in LDS.  One workgroup per row.
+// =====================================================================================
+constexpr int TK_MAX = 2048;
+size_t topk_workspace_bytes(int, int, int) { return 0; }
+
+__global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ P, int M, int K, float* __restrict__ vals, int32_t* __restrict__ idx) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long keys[TK_MAX];
+    __shared__ unsigned s_prefix, s_remaining, s_count;
+    const int64_t i = blockIdx.x;
+    const float* row = P + i * M;
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, prefix_mask = 0, remaining = K;
+    // bits [31:21], [20:10], [9:0]
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = shifts[pass], nb = 1 << widths[pass];
+        for (int b = tid; b < nb; b += 256) hist[b] = 0;
+        __syncthreads();
+        for (int c = tid; c < M; c += 256) {
+            const unsigned u = __float_as_uint(row[c]);
+            if ((u & prefix_mask) == prefix) atomicAdd(&hist[(u >> sh) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned rem = remaining; int b = nb - 1;
+            for (; b > 0; --b) { if (hist[b] >= rem) break; rem -= hist[b]; }
+            s_prefix = prefix | ((unsigned)b << sh); s_remaining = rem;
+        }
+        __syncthreads();
+        prefix = s_prefix; remaining = s_remaining;
+        prefix_mask |= (unsigned)(nb - 1) << sh;
+        __syncthreads();
+    }
+    // prefix = bit pattern of the K-th largest value; `remaining` = how many copies of it belong to the top K
+    if (tid == 0) s_count = 0;
+    for (int k = tid; k < TK_MAX; k += 256) keys[k] = 0ull;
+    __syncthreads();
+    const unsigned thr = prefix;
+    for (int c = tid; c < M; c += 256) {
+        const unsigned u = __float_as_uint(row[c]);
+        if (u > thr) { const unsigned p = atomicAdd(&s_count, 1u); keys[p] = ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - c); }
+    }
+    __syncthreads();
+    // ties at the threshold: smallest column ids first (deterministic)
+    if (tid == 0) {
+        unsigned need = remaining, p = s_count;
+        for (int c = 0; c < M && need > 0; ++c)
+            if (__float_as_uint(row[c]) == thr) { keys[p++] = ((unsigned long long)thr << 32) | (unsigned)(0x7fffffff - c); --need; }
+        s_count = p;
+    }
+    __syncthreads();
+    // bitonic sort, descending on (value bits, -col)
+    int n2 = 1; while (n2 < K) n2 <<= 1;
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < n2 / 2; t += 256) {
+                const int lo = (t / stride) * stride * 2 + (t % stride), hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int k = tid; k < K; k += 256) {
+        vals[i * K + k] = __uint_as_float((unsigned)(keys[k] >> 32));
+        idx[i * K + k] = 0x7fffffff - (int)(keys[k] & 0xffffffffu);
+    }
+}
+void launch_topk_rows(hipStream_t st, const float* P, int n_rows, int M, int K, float* vals, int32_t* idx, void*) {
+    hipLaunchKernelGGL(k_topk_rows, dim3(n_rows), dim3(256), 0, st, P, M, K, vals, idx);
+}
+
+// =====================================================================================
+// generator test hooks
+// =====================================================================================
+__global__ void k_fill_normal(NormalSpec s, int64_t n, float* out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e0 = q * 4;
+    if (e0 >= n) return;
+    float z[4];
+    normal4(s, q, e0, n, z);
+    for (int j = 0; j < 4; ++j) if (e0 + j < n) out[e0 + j] = z[j];
+}
+void launch_fill_normal(hipStream_t st, NormalSpec s, int64_t n, float* out) {
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(k_fill_normal, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, s, n, out);
+}
+__global__ void k_fill_sign(SignSpec s, int rows, int cols, float* out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)rows * cols) return;
+    out[e] = sign_at(s, e / cols, e % cols);
+}
+void launch_fill_sign(hipStream_t st, SignSpec s, int rows, int cols, float* out) {
+    const int64_t n = (int64_t)rows * cols;
+    hipLaunchKernelGGL(k_fill_sign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, rows, cols, out);
+}
+
+}  // namespace ntf

@@ -1,0 +1,343 @@
+"""ctypes binding of libopentf_amd.so (include/opentf_amd.h) and a thin `Engine` object over the handle.
+
+There is no CPU fallback: if the shared library is missing or the HIP device cannot be opened, this
+module raises.  Build the library with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C opentf_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+NTF_ABI_VERSION = 1
+NTF_MAX_LAYERS = 8
+INPUT_DENSE, INPUT_MEANPOOL, INPUT_MULTIHOT = 0, 1, 2
+NSD = {None: 0, "": 0, "None": 0, "uniform": 1, "unigram": 2, "unigram_b": 3}
+P_WEIGHT, P_BIAS, P_RHO_WEIGHT, P_RHO_BIAS = 0, 1, 2, 3
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libopentf_amd.so")
+
+
+class NtfError(RuntimeError):
+    pass
+
+
+class ntf_config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p), ("n_layers", C.c_int32),
+                ("dims", C.c_int32 * (NTF_MAX_LAYERS + 1)), ("bayesian", C.c_int32), ("input_mode", C.c_int32),
+                ("max_batch", C.c_int32), ("ns", C.c_int32), ("nsd", C.c_int32), ("tpw", C.c_float), ("tnw", C.c_float),
+                ("lr", C.c_float), ("seed", C.c_uint64), ("fused", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class ntf_inject(C.Structure):
+    _fields_ = [("neg_idx", C.c_void_p), ("eps_w", C.c_void_p * NTF_MAX_LAYERS), ("eps_b", C.c_void_p * NTF_MAX_LAYERS),
+                ("s_in", C.c_void_p * NTF_MAX_LAYERS), ("s_out", C.c_void_p * NTF_MAX_LAYERS)]
+
+
+# every symbol declared in include/opentf_amd.h: name -> (restype, argtypes)
+_P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+SYMBOLS = {
+    "ntf_engine_create": (C.c_int, [C.POINTER(ntf_config), C.POINTER(_P)]),
+    "ntf_engine_destroy": (None, [_P]),
+    "ntf_last_error": (C.c_char_p, [_P]),
+    "ntf_abi_version": (C.c_int, []),
+    "ntf_set_member_csr": (C.c_int, [_P, _P, _P, _I64]),
+    "ntf_set_skill_csr": (C.c_int, [_P, _P, _P, _I64]),
+    "ntf_set_skill_table": (C.c_int, [_P, _P, _I64, _I32]),
+    "ntf_set_dense_input": (C.c_int, [_P, _P, _I64, _I32]),
+    "ntf_set_unigram": (C.c_int, [_P, _P, _I64]),
+    "ntf_set_param": (C.c_int, [_P, C.c_int, C.c_int, _P, _I64]),
+    "ntf_get_param": (C.c_int, [_P, C.c_int, C.c_int, _P, _I64]),
+    "ntf_get_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, _I64]),
+    "ntf_reset_optimizer": (C.c_int, [_P]),
+    "ntf_set_lr": (C.c_int, [_P, _F]),
+    "ntf_set_seed": (C.c_int, [_P, _U64, _U64]),
+    "ntf_train_step": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "ntf_eval_step": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "ntf_backward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
+    "ntf_apply": (C.c_int, [_P]),
+    "ntf_train_epoch": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "ntf_eval_epoch": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "ntf_epoch_loss": (C.c_int, [_P, _P, _P]),
+    "ntf_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P]),
+    "ntf_logits": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "ntf_forward_topk": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "ntf_gather_meanpool": (C.c_int, [_P, _P, _I64, _P]),
+    "ntf_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "ntf_param_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "ntf_synchronize": (C.c_int, [_P]),
+    "ntf_kernel_times": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
+    "ntf_k_gemm_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
+    "ntf_k_fill_normal": (C.c_int, [_P, _U64, _U64, C.c_int, _I64, _P]),
+    "ntf_k_fill_sign": (C.c_int, [_P, _U64, _U64, C.c_int, C.c_int, C.c_int, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NtfError(f"{_LIB_PATH} is missing: build it (make -C opentf_amd/csrc). There is no CPU fallback.")
+        l = C.CDLL(_LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if l.ntf_abi_version() != NTF_ABI_VERSION:
+            raise NtfError("libopentf_amd.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class DeviceView:
+    """`__cuda_array_interface__` view of an engine-owned HBM buffer (for torch.as_tensor / RCCL)."""
+
+    def __init__(self, ptr, n, owner):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class Engine:
+    """One Fnn/Bnn model resident on one MI355X.  dims = [D, *h, M]."""
+
+    def __init__(self, dims, bayesian=False, input_mode=INPUT_DENSE, max_batch=1000, ns=5, nsd="uniform", tpw=10.0, tnw=1.0,
+                 lr=1e-3, seed=0, device=0, stream=None, fused=True):
+        self.dims = [int(d) for d in dims]
+        self.L = len(self.dims) - 1
+        if not 1 <= self.L <= NTF_MAX_LAYERS:
+            raise NtfError("between 1 and 8 layers supported")
+        self.bayesian = bool(bayesian)
+        self.ns = int(ns) if NSD[nsd] else 0
+        self.max_batch = int(max_batch)
+        cfg = ntf_config()
+        cfg.abi_version, cfg.device, cfg.stream, cfg.n_layers = NTF_ABI_VERSION, int(device), stream, self.L
+        for i, d in enumerate(self.dims):
+            cfg.dims[i] = d
+        cfg.bayesian, cfg.input_mode, cfg.max_batch = int(self.bayesian), int(input_mode), self.max_batch
+        cfg.ns, cfg.nsd, cfg.tpw, cfg.tnw, cfg.lr, cfg.seed, cfg.fused = max(self.ns, 0), NSD[nsd], float(tpw), float(tnw), float(lr), int(seed) & (2**64 - 1), int(bool(fused))
+        self._h = C.c_void_p()
+        rc = lib().ntf_engine_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = lib().ntf_last_error(None)
+            self._h = None
+            raise NtfError(f"ntf_engine_create failed ({rc}): {msg.decode() if msg else ''}")
+        self._keep = []
+
+    # ---- plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise NtfError(f"libopentf_amd error {rc}: {lib().ntf_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ntf_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data
+    @staticmethod
+    def _csr(mat_or_tuple):
+        if isinstance(mat_or_tuple, tuple):
+            indptr, indices = mat_or_tuple
+        else:
+            import scipy.sparse
+            m = scipy.sparse.csr_matrix(mat_or_tuple)
+            m.sort_indices()
+            indptr, indices = m.indptr, m.indices
+        return np.ascontiguousarray(indptr, dtype=np.int64), np.ascontiguousarray(indices, dtype=np.int32)
+
+    def set_member(self, member):
+        ip, ix = self._csr(member)
+        self._ck(lib().ntf_set_member_csr(self._h, _ptr(ip), _ptr(ix), len(ip) - 1))
+
+    def set_skill_csr(self, skill):
+        ip, ix = self._csr(skill)
+        self._ck(lib().ntf_set_skill_csr(self._h, _ptr(ip), _ptr(ix), len(ip) - 1))
+
+    def set_skill_table(self, table):
+        t = _f32(table)
+        self._ck(lib().ntf_set_skill_table(self._h, _ptr(t), t.shape[0], t.shape[1]))
+
+    def set_dense_input(self, X):
+        x = _f32(X)
+        self._ck(lib().ntf_set_dense_input(self._h, _ptr(x), x.shape[0], x.shape[1]))
+
+    def set_unigram(self, freq):
+        f = np.ascontiguousarray(np.asarray(freq, dtype=np.float64).reshape(-1))
+        self._ck(lib().ntf_set_unigram(self._h, _ptr(f), len(f)))
+
+    # ---- state (reference state_dict layout, src/mdl/fnn.py:20-22 / bayesian-torch LinearFlipout)
+    def _kinds(self):
+        return ([("mu_weight", P_WEIGHT), ("rho_weight", P_RHO_WEIGHT), ("mu_bias", P_BIAS), ("rho_bias", P_RHO_BIAS)] if self.bayesian
+                else [("weight", P_WEIGHT), ("bias", P_BIAS)])
+
+    def _shape(self, layer, kind):
+        o, i = self.dims[layer + 1], self.dims[layer]
+        return (o, i) if kind in (P_WEIGHT, P_RHO_WEIGHT) else (o,)
+
+    def load_state_dict(self, sd):
+        for l in range(self.L):
+            for name, kind in self._kinds():
+                a = sd[f"layers.{l}.{name}"]
+                a = _f32(a.detach().cpu().numpy() if hasattr(a, "detach") else a)
+                if a.shape != self._shape(l, kind):
+                    raise NtfError(f"layers.{l}.{name}: shape {a.shape} != {self._shape(l, kind)}")
+                self._ck(lib().ntf_set_param(self._h, l, kind, _ptr(a), a.size))
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for l in range(self.L):
+            for name, kind in self._kinds():
+                a = np.empty(self._shape(l, kind), dtype=np.float32)
+                self._ck(lib().ntf_get_param(self._h, l, kind, _ptr(a), a.size))
+                sd[f"layers.{l}.{name}"] = a
+        return sd
+
+    def grads(self):
+        """p.grad of every parameter after backward()/train_step() (state_dict key order)."""
+        sd = OrderedDict()
+        for l in range(self.L):
+            for name, kind in self._kinds():
+                a = np.empty(self._shape(l, kind), dtype=np.float32)
+                self._ck(lib().ntf_get_grad(self._h, l, kind, _ptr(a), a.size))
+                sd[f"layers.{l}.{name}"] = a
+        return sd
+
+    def reset_optimizer(self):
+        self._ck(lib().ntf_reset_optimizer(self._h))
+
+    def set_lr(self, lr):
+        self._ck(lib().ntf_set_lr(self._h, float(lr)))
+
+    def set_seed(self, seed, step=0):
+        self._ck(lib().ntf_set_seed(self._h, int(seed) & (2**64 - 1), int(step)))
+
+    # ---- steps
+    def _inject(self, inject, B):
+        if not inject:
+            return None, []
+        keep, st = [], ntf_inject()
+        if inject.get("neg_idx") is not None:
+            a = np.ascontiguousarray(np.asarray(inject["neg_idx"], dtype=np.int64)); keep.append(a)
+            assert a.shape == (B, self.ns), (a.shape, B, self.ns)
+            st.neg_idx = a.ctypes.data
+        for key in ("eps_w", "eps_b", "s_in", "s_out"):
+            for l, a in enumerate(inject.get(key) or []):
+                if a is None:
+                    continue
+                a = _f32(a.detach().cpu().numpy() if hasattr(a, "detach") else a); keep.append(a)
+                getattr(st, key)[l] = a.ctypes.data
+        return st, keep
+
+    @staticmethod
+    def _rows(rows):
+        return np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1))
+
+    def train_step(self, rows, inject=None, want_loss=True):
+        r = self._rows(rows); st, keep = self._inject(inject, len(r)); loss = C.c_float()
+        self._ck(lib().ntf_train_step(self._h, _ptr(r), len(r), C.byref(st) if st else None, C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def eval_step(self, rows, inject=None, want_loss=True):
+        r = self._rows(rows); st, keep = self._inject(inject, len(r)); loss = C.c_float()
+        self._ck(lib().ntf_eval_step(self._h, _ptr(r), len(r), C.byref(st) if st else None, C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def backward(self, rows, global_B=None, inject=None, want_loss=True):
+        r = self._rows(rows); st, keep = self._inject(inject, len(r)); loss = C.c_float()
+        self._ck(lib().ntf_backward(self._h, _ptr(r), len(r), int(global_B or len(r)), C.byref(st) if st else None, C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def apply(self):
+        self._ck(lib().ntf_apply(self._h))
+
+    def train_epoch(self, order, B):
+        o = self._rows(order); loss = C.c_float()
+        self._ck(lib().ntf_train_epoch(self._h, _ptr(o), len(o), int(B), C.byref(loss)))
+        return loss.value
+
+    def eval_epoch(self, order, B):
+        o = self._rows(order); loss = C.c_float()
+        self._ck(lib().ntf_eval_epoch(self._h, _ptr(o), len(o), int(B), C.byref(loss)))
+        return loss.value
+
+    def epoch_loss(self):
+        s, k = C.c_double(), C.c_int64()
+        self._ck(lib().ntf_epoch_loss(self._h, C.byref(s), C.byref(k)))
+        return s.value, k.value
+
+    # ---- inference
+    def logits(self, rows, inject=None):
+        r = self._rows(rows); st, keep = self._inject(inject, len(r))
+        out = np.empty((len(r), self.dims[-1]), dtype=np.float32)
+        self._ck(lib().ntf_logits(self._h, _ptr(r), len(r), C.byref(st) if st else None, _ptr(out)))
+        return out
+
+    def forward(self, rows, nmc=1, injects=None, uncertainty=False):
+        r = self._rows(rows); B = len(r)
+        out = np.empty((B, self.dims[-1]), dtype=np.float32)
+        pu = np.empty(B, dtype=np.float32) if uncertainty else None
+        mu = np.empty(B, dtype=np.float32) if uncertainty else None
+        arr, keep = None, []
+        if injects:
+            arr = (ntf_inject * len(injects))()
+            for i, inj in enumerate(injects):
+                st, k = self._inject(inj, B); keep.append(k); arr[i] = st
+        self._ck(lib().ntf_forward(self._h, _ptr(r), B, int(nmc), arr, _ptr(out), _ptr(pu), _ptr(mu)))
+        return (out, pu, mu) if uncertainty else out
+
+    def forward_topk(self, rows, K, nmc=1, uncertainty=False):
+        r = self._rows(rows); B = len(r)
+        vals = np.empty((B, K), dtype=np.float32); idx = np.empty((B, K), dtype=np.int32)
+        pu = np.empty(B, dtype=np.float32) if uncertainty else None
+        mu = np.empty(B, dtype=np.float32) if uncertainty else None
+        self._ck(lib().ntf_forward_topk(self._h, _ptr(r), B, int(nmc), int(K), _ptr(vals), _ptr(idx), _ptr(pu), _ptr(mu)))
+        return (vals, idx, pu, mu) if uncertainty else (vals, idx)
+
+    def gather_meanpool(self, rows=None, n=None, to_host=True):
+        r = None if rows is None else self._rows(rows)
+        n = len(r) if r is not None else int(n)
+        out = np.empty((n, self._table_d()), dtype=np.float32) if to_host else None
+        self._ck(lib().ntf_gather_meanpool(self._h, _ptr(r), n, _ptr(out)))
+        return out
+
+    def _table_d(self):
+        return self.dims[0]
+
+    # ---- views / measurement
+    def grad_view(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(lib().ntf_grad_buffer(self._h, C.byref(p), C.byref(n)))
+        return DeviceView(p.value, n.value, self)
+
+    def param_view(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(lib().ntf_param_buffer(self._h, C.byref(p), C.byref(n)))
+        return DeviceView(p.value, n.value, self)
+
+    def synchronize(self):
+        self._ck(lib().ntf_synchronize(self._h))
+
+    def kernel_times(self, enable=True):
+        cap = 32
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); calls = (C.c_int64 * cap)()
+        n = lib().ntf_kernel_times(self._h, int(enable), names, ms, calls, cap)
+        return {names[i].decode(): (ms[i], calls[i]) for i in range(min(n, cap))}

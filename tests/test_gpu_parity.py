@@ -1,0 +1,309 @@
+"""Parity of the HIP engine (through the C ABI) against the oracle and the golden vectors, on a real
+MI355X.  Bars: gather bit-exact; logits within 1e-4 relative (north_star); losses/gradients within the
+tolerances written at each assert."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+import torch
+
+from conftest import GOLDEN, golden, params_from
+from oracle import ntf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LOGITS = 1e-4  # BASELINE.json north_star: expert-ranking logits within 1e-4 relative
+
+
+def _engine(*a, **k):
+    from opentf_amd.libntf import Engine
+    return Engine(*a, **k)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _close(a, b, rtol, atol):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def _csr_from_dense(y):
+    m = scipy.sparse.csr_matrix(np.asarray(y) != 0)
+    return m.indptr.astype(np.int64), m.indices.astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------ gather
+def test_gather_bitexact_vs_reference_golden():
+    from opentf_amd import libntf
+    g = golden("g9_gather_dblp")
+    S, d = g["table"].shape
+    e = _engine([d, 8, int(g["n_member"])], input_mode=libntf.INPUT_MEANPOOL, max_batch=64)
+    e.set_skill_table(g["table"]); e.set_skill_csr((g["indptr"], g["indices"]))
+    X = e.gather_meanpool(n=len(g["indptr"]) - 1)
+    assert np.array_equal(X, O.gather_meanpool_fast(g["indptr"], g["indices"], g["table"]))
+    _close(X, g["X"], 1e-6, 1e-7)  # the reference's own scipy result
+    rows = np.array([5, 0, 30, 7, 7])
+    assert np.array_equal(e.gather_meanpool(rows=rows), X[rows])
+
+
+@pytest.mark.parametrize("d,S,N,mean_nnz", [(128, 5000, 20000, 8.57), (256, 3000, 5000, 6.3), (32, 100, 777, 2.0), (100, 64, 300, 40.0), (30, 50, 200, 3.0)])
+def test_gather_bitexact_ragged(d, S, N, mean_nnz):
+    from opentf_amd import libntf
+    rng = np.random.default_rng(d)
+    nnz = 1 + rng.poisson(mean_nnz - 1, N)
+    nnz[::97] = 0  # empty teams: the reference divides 0/0 -> nan
+    nnz[5] = min(S, 200)  # a very long row
+    indptr = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int64)
+    indices = np.concatenate([rng.choice(S, k, replace=False) for k in nnz]).astype(np.int32)
+    table = rng.standard_normal((S, d)).astype(np.float32)
+    e = _engine([d, 8, 16], input_mode=libntf.INPUT_MEANPOOL, max_batch=64)
+    e.set_skill_table(table); e.set_skill_csr((indptr, indices))
+    X = e.gather_meanpool(n=N)
+    ref = O.gather_meanpool_fast(indptr, indices, table)
+    assert np.array_equal(np.isnan(X), np.isnan(ref))
+    assert np.array_equal(np.nan_to_num(X), np.nan_to_num(ref))
+
+
+# ------------------------------------------------------------------------------------------ Fnn
+@pytest.mark.parametrize("name", ["g1_forward_imdb", "g1_forward_mid", "g1_forward_2h"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_fnn_logits_vs_reference_golden(name, fused):
+    g = golden(name)
+    sd = params_from(g, "p.")
+    dims = [g["X"].shape[1]] + [sd[f"layers.{i}.weight"].shape[0] for i in range(O.n_layers(sd))]
+    e = _engine(dims, max_batch=len(g["X"]), fused=fused)
+    e.load_state_dict(sd); e.set_dense_input(g["X"])
+    out = e.logits(np.arange(len(g["X"])))
+    assert _rel(out, g["logits"]) < RTOL_LOGITS
+    _close(out, g["logits"], RTOL_LOGITS, 1e-6)
+
+
+@pytest.mark.parametrize("tag", ["imdb", "mid"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_fnn_train_steps_vs_reference_golden(tag, fused):
+    g = golden(f"g4_step_{tag}")
+    sd = params_from(g, "p0.")
+    X, y = g["X"], g["y"]
+    dims = [X.shape[1]] + [sd[f"layers.{i}.weight"].shape[0] for i in range(O.n_layers(sd))]
+    e = _engine(dims, max_batch=len(X), ns=5, nsd="uniform", tpw=float(g["tpw"]), tnw=float(g["tnw"]), lr=float(g["lr"]), fused=fused)
+    e.load_state_dict(sd); e.set_dense_input(X); e.set_member(_csr_from_dense(y))
+    rows = np.arange(len(X))
+    for s in range(3):
+        loss = e.train_step(rows, inject={"neg_idx": g[f"s{s}.idx"]})
+        assert abs(loss - float(g[f"s{s}.loss"])) <= 2e-5 * abs(loss), (s, loss, float(g[f"s{s}.loss"]))
+        grads, state = e.grads(), e.state_dict()
+        for k in sd:
+            ref_g = g[f"s{s}.g.{k}"]
+            assert _rel(grads[k], ref_g) < 2e-4, (s, k, _rel(grads[k], ref_g))
+            _close(state[k], g[f"s{s}.p.{k}"], 1e-3, 2e-5)  # Adam's m/sqrt(v) amplifies grad noise near zero grads
+
+
+# ------------------------------------------------------------------------------------------ Bnn (oracle, injected noise)
+def _bnn_case(D, H, M, B, seed):
+    torch.manual_seed(seed)
+    sd = O.bnn_init(D, H, M)
+    X = torch.randn(B, D)
+    y = (torch.rand(B, M) < 0.01).float(); y[torch.arange(B), torch.randint(0, M, (B,))] = 1
+    return sd, X, y
+
+
+@pytest.mark.parametrize("D,H,M,B", [(18, [32], 112, 19), (128, [128], 1500, 70), (40, [64, 32], 300, 33), (128, [128], 5000, 130)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
+    sd, X, y = _bnn_case(D, H, M, B, 5)
+    e = _engine([D] + H + [M], bayesian=True, max_batch=B, ns=5, nsd="uniform", lr=1e-3, fused=fused)
+    e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
+    rows = np.arange(B)
+    opt = O.Adam(sd, 1e-3)
+    for s in range(2):
+        noise = O.draw_flipout_noise(sd, B)
+        neg = O.ns_uniform(y, 5)
+        inj = {"neg_idx": neg.numpy(), "eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise],
+               "s_in": [n["s_in"] for n in noise], "s_out": [n["s_out"] for n in noise]}
+        ref_logits = O.bnn_forward(sd, X, noise).detach().numpy()
+        got = e.logits(rows, inject=inj)
+        assert _rel(got, ref_logits) < RTOL_LOGITS
+        _close(got, ref_logits, RTOL_LOGITS, 2e-6)
+        ref_eval = float(O.batch_loss(sd, X, y, neg, 10.0, 1.0, noise))
+        assert abs(e.eval_step(rows, inject=inj) - ref_eval) <= 2e-5 * abs(ref_eval)
+        ref_loss, ref_grads = O.train_step(sd, opt, X, y, neg, 10.0, 1.0, noise)
+        loss = e.train_step(rows, inject=inj)
+        assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss)
+        grads, state = e.grads(), e.state_dict()
+        for k in sd:
+            assert _rel(grads[k], ref_grads[k].numpy()) < 3e-4, (s, k, _rel(grads[k], ref_grads[k].numpy()))
+            _close(state[k], sd[k].numpy(), 1e-3, 2e-5)
+
+
+def test_split_backward_equals_train_step():
+    """ntf_backward over two row shards with global_B, gradients summed == one full-batch gradient."""
+    sd, X, y = _bnn_case(32, [32], 200, 24, 9)
+    def mk():
+        e = _engine([32, 32, 200], bayesian=True, max_batch=24, ns=3, nsd="uniform", fused=False)
+        e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy())); return e
+    noise = O.draw_flipout_noise(sd, 24); neg = O.ns_uniform(y, 3)
+    def inj(sl):
+        return {"neg_idx": neg.numpy()[sl], "eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise],
+                "s_in": [n["s_in"][sl] for n in noise], "s_out": [n["s_out"][sl] for n in noise]}
+    full = mk(); lf = full.backward(np.arange(24), inject=inj(slice(0, 24))); gf = full.grads()
+    a, b = mk(), mk()
+    la = a.backward(np.arange(0, 10), global_B=24, inject=inj(slice(0, 10)))
+    lb = b.backward(np.arange(10, 24), global_B=24, inject=inj(slice(10, 24)))
+    assert abs((la + lb) - lf) <= 1e-5 * abs(lf)
+    ga, gb = a.grads(), b.grads()
+    for k in gf:
+        assert _rel(ga[k] + gb[k], gf[k]) < 1e-4, k
+
+
+# ------------------------------------------------------------------------------------------ inputs
+def test_multihot_input_toy_imdb():
+    """BASELINE config 1 shapes: multi-hot skills (S=18) -> h=[32] -> 112 experts."""
+    from opentf_amd import libntf
+    toy = golden("toy_imdb")
+    n, S, M = [int(v) for v in toy["shape"]]
+    g = golden("g1_forward_imdb")
+    sd = params_from(g, "p.")
+    e = _engine([S, 32, M], input_mode=libntf.INPUT_MULTIHOT, max_batch=n)
+    e.load_state_dict(sd); e.set_skill_csr((toy["skill_indptr"], toy["skill_indices"]))
+    _close(e.logits(np.arange(n)), g["logits"], RTOL_LOGITS, 1e-6)
+
+
+def test_meanpool_input_feeds_the_model():
+    from opentf_amd import libntf
+    g = golden("g9_gather_dblp")
+    torch.manual_seed(3)
+    sd = O.fnn_init(128, [64], int(g["n_member"]))
+    n = len(g["indptr"]) - 1
+    e = _engine([128, 64, int(g["n_member"])], input_mode=libntf.INPUT_MEANPOOL, max_batch=n)
+    e.load_state_dict(sd); e.set_skill_table(g["table"]); e.set_skill_csr((g["indptr"], g["indices"]))
+    ref = O.fnn_forward(sd, torch.from_numpy(g["X"])).detach().numpy()
+    _close(e.logits(np.arange(n)), ref, RTOL_LOGITS, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ native generators
+def test_native_uniform_sampler_invariants_and_distribution():
+    B, M, ns = 256, 50, 5
+    rng = np.random.default_rng(0)
+    y = (rng.random((B, M)) < 0.1).astype(np.float32); y[:, 0] = 1
+    y[7] = 1; y[7, [3, 9]] = 0  # row with only 2 negatives < ns
+    torch.manual_seed(0); sd = O.fnn_init(8, [8], M)
+    # the picks are observable through the gradient of the output bias: with tnw=0 ONLY positives and picks get gradient
+    e2 = _engine([8, 8, M], max_batch=B, ns=ns, nsd="uniform", tpw=1.0, tnw=0.0, seed=7, fused=False)
+    sd2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    e2.load_state_dict(sd2); e2.set_dense_input(np.ones((B, 8), np.float32)); e2.set_member(_csr_from_dense(y))
+    hits = np.zeros(M)
+    for it in range(200):
+        # one row at a time isolates the row's picks in the bias gradient
+        r = it % B
+        e2.backward(np.array([r]))
+        gb = e2.grads()["layers.1.bias"]
+        picked = np.nonzero(gb > 0)[0]   # y=0, weight 1 -> +sigmoid(0)=0.5 ; positives give -0.5 ; others 0
+        negs_available = int((y[r] == 0).sum())
+        assert len(picked) == min(ns, negs_available), (r, picked)
+        assert (y[r, picked] == 0).all()
+        if negs_available >= ns and r != 7:
+            hits[picked] += 1
+    # column 0 is always a positive -> never picked; the rest roughly uniform
+    assert hits[0] == 0
+    expected = hits[1:].mean()
+    assert (np.abs(hits[1:] - expected) < 6 * np.sqrt(expected) + 5).all()
+
+
+def test_native_normal_and_sign_statistics():
+    from opentf_amd import libntf
+    n = 1 << 22
+    buf = torch.empty(n, device="cuda")
+    assert libntf.lib().ntf_k_fill_normal(None, 1234, 7, 1, n, buf.data_ptr()) == 0
+    torch.cuda.synchronize()
+    z = buf.double().cpu().numpy()
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1) < 0.01
+    assert abs((z ** 3).mean()) < 0.02 and abs((z ** 4).mean() - 3) < 0.05
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 5e-3 and abs(np.corrcoef(z[:-4], z[4:])[0, 1]) < 5e-3
+    assert np.abs(z).max() > 4.5  # tails are present
+    buf2 = torch.empty(n, device="cuda")
+    libntf.lib().ntf_k_fill_normal(None, 1234, 8, 1, n, buf2.data_ptr()); torch.cuda.synchronize()
+    assert abs(np.corrcoef(z, buf2.double().cpu().numpy())[0, 1]) < 5e-3  # steps are independent
+    rows, cols = 2048, 2048
+    s = torch.empty(rows * cols, device="cuda")
+    assert libntf.lib().ntf_k_fill_sign(None, 99, 3, 1, rows, cols, s.data_ptr()) == 0
+    torch.cuda.synchronize()
+    sg = s.cpu().numpy().reshape(rows, cols)
+    assert set(np.unique(sg)) == {-1.0, 1.0}
+    assert abs(sg.mean()) < 5 / np.sqrt(rows * cols)
+    assert np.abs(sg.mean(axis=0)).max() < 6 / np.sqrt(rows) and np.abs(sg.mean(axis=1)).max() < 6 / np.sqrt(cols)
+    assert abs((sg[:, :-1] * sg[:, 1:]).mean()) < 5e-3 and abs((sg[:-1] * sg[1:]).mean()) < 5e-3
+
+
+def test_native_flipout_matches_oracle_in_distribution():
+    """With native eps/signs the logits cannot match draw for draw; their mean over many passes must approach
+    the deterministic mu-only forward, and their variance the analytic flipout variance."""
+    torch.manual_seed(2)
+    D, H, M, B = 16, 16, 64, 8
+    sd = O.bnn_init(D, [H], M)
+    X = torch.randn(B, D)
+    e = _engine([D, H, M], bayesian=True, max_batch=B, seed=11)
+    e.load_state_dict(sd); e.set_dense_input(X.numpy())
+    outs = np.stack([e.logits(np.arange(B)) for _ in range(400)])
+    ref = np.stack([O.bnn_forward(sd, X, O.draw_flipout_noise(sd, B)).numpy() for _ in range(400)])
+    assert np.abs(outs.mean(0) - ref.mean(0)).max() < 6 * ref.std(0).max() / np.sqrt(400) + 1e-3
+    assert abs(outs.std(0).mean() / ref.std(0).mean() - 1) < 0.1
+
+
+# ------------------------------------------------------------------------------------------ inference
+def test_forward_probs_topk_and_uncertainty():
+    sd, X, y = _bnn_case(32, [32], 700, 20, 4)
+    e = _engine([32, 32, 700], bayesian=True, max_batch=20)
+    e.load_state_dict(sd); e.set_dense_input(X.numpy())
+    noises = [O.draw_flipout_noise(sd, 20) for _ in range(3)]
+    injs = [{"eps_w": [n["eps_w"] for n in nz], "eps_b": [n["eps_b"] for n in nz], "s_in": [n["s_in"] for n in nz],
+             "s_out": [n["s_out"] for n in nz]} for nz in noises]
+    mc = O.predict(sd, X, 3, noises).numpy()
+    probs, pu, mu = e.forward(np.arange(20), nmc=3, injects=injs, uncertainty=True)
+    _close(probs, mc.mean(0), 1e-5, 1e-7)
+    _close(pu, O.predictive_entropy(mc), 1e-4, 1e-4)
+    _close(mu, O.mutual_information(mc), 1e-3, 2e-4)
+    # Fnn path + GPU top-K against torch.topk
+    torch.manual_seed(1)
+    fsd = O.fnn_init(32, [32], 3000)
+    f = _engine([32, 32, 3000], max_batch=20)
+    f.load_state_dict(fsd); f.set_dense_input(X.numpy())
+    p = f.forward(np.arange(20))
+    _close(p, O.predict(fsd, X).numpy(), 1e-5, 1e-7)
+    vals, idx = f.forward_topk(np.arange(20), 50)
+    tv, ti = torch.topk(torch.from_numpy(p), 50, dim=1)
+    assert np.array_equal(vals, tv.numpy())
+    assert np.array_equal(np.sort(idx, axis=1), np.sort(ti.numpy(), axis=1))
+
+
+def test_epoch_api_matches_step_api():
+    sd, X, y = _bnn_case(16, [16], 90, 50, 1)
+    fsd = O.fnn_init(16, [16], 90)
+    def mk():
+        e = _engine([16, 16, 90], max_batch=16, ns=2, nsd="uniform", seed=5)
+        e.load_state_dict(fsd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy())); return e
+    order = np.random.default_rng(0).permutation(50)
+    a, b = mk(), mk()
+    mean_a = a.train_epoch(order, 16)
+    losses = [b.train_step(order[o:o + 16]) for o in range(0, 50, 16)]
+    assert abs(mean_a - np.mean(losses)) <= 1e-6 * abs(mean_a)
+    for k, v in a.state_dict().items():
+        assert np.array_equal(v, b.state_dict()[k])
+    assert abs(a.eval_epoch(order, 16) - np.mean([b.eval_step(order[o:o + 16]) for o in range(0, 50, 16)])) < 1e-5
+
+
+def test_errors_are_reported_not_swallowed():
+    from opentf_amd.libntf import NtfError
+    e = _engine([8, 8, 20], max_batch=4)
+    with pytest.raises(NtfError):
+        e.train_step(np.arange(4))           # nothing resident yet
+    e.set_dense_input(np.zeros((10, 8), np.float32)); e.set_member((np.arange(11), np.zeros(10, np.int32)))
+    with pytest.raises(NtfError):
+        e.train_step(np.arange(5))           # B > max_batch
+    with pytest.raises(NtfError):
+        e.train_step(np.array([0, 99]))      # row id out of range
+    with pytest.raises(NtfError):
+        e.set_member((np.array([0, 1]), np.array([20], np.int32)))  # column id out of range
