@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""teams/sec (train) of the Bnn `bnn_emb d=128` minibatch step on dblp-shaped data, on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one minibatch (B = 1000 teams per GPU) through the whole hot path of src/mdl/fnn.py:118-140:
+CSR mean-pool gather of the skill embeddings, Flipout MLP forward, sparse-label weighted BCE with uniform
+negative sampling, KL term, backward, (gradient all-reduce,) Adam.  Inputs (CSR matrices, embedding table,
+weights) are resident in HBM before the timed region; nothing is skipped inside it.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel (HIP
+events recorded on the engine's stream during the timed region) and `cpu_baseline` (the oracle's
+reference-shaped dense step, timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dataset", default="dblp")
+    ap.add_argument("--batch", type=int, default=1000, help="teams per GPU per step (cfg.b)")
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--model", default="bnn", choices=["bnn", "fnn"])
+    ap.add_argument("--nsd", default="uniform")
+    ap.add_argument("--rows", type=int, default=0, help="override the number of teams (debug)")
+    ap.add_argument("--experts", type=int, default=0, help="override the number of experts (debug)")
+    ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-bench", action="store_true", help="also time the whole-dataset gather (get_dense_vecs)")
+    return ap.parse_args()
+
+
+def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=2):
+    """The oracle's reference-shaped step (dense [B, M] labels, rand_like+topk negatives, autograd, Adam) on the host."""
+    import scipy.sparse
+    import torch
+    from oracle import ntf_oracle as O
+    from opentf_amd.synth import init_params
+    from collections import OrderedDict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = OrderedDict((k, torch.from_numpy(v.copy())) for k, v in init_params(dims, bayesian, 0).items())
+    opt = O.Adam(sd, cfg["lr"])
+    m_ip, m_ix = ds["member"]
+    member = scipy.sparse.csr_matrix((np.ones(len(m_ix), np.uint8), m_ix, m_ip), shape=(ds["N"], ds["M"]))
+    s_ip, s_ix = ds["skill"]
+    rng = np.random.default_rng(1)
+    O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], 32), member, cfg)  # warm
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], sample_rows), member, cfg)
+    dt = time.perf_counter() - t0
+    return {"value": steps * sample_rows / dt, "unit": "teams/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of B={sample_rows} at full M={ds['M']} (oracle/ntf_oracle.py reference_shaped_step, torch {torch.__version__} CPU)"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+
+    from opentf_amd import libntf
+    from opentf_amd.dp import DataParallel
+    from opentf_amd.synth import make_dataset, init_params
+
+    bayesian = a.model == "bnn"
+    ds = make_dataset(a.dataset, d=a.d, seed=0, n_rows=a.rows or None, n_experts=a.experts or None)
+    dims = [a.d, a.hidden, ds["M"]]
+    cfg = {"ns": 5, "nsd": a.nsd, "tpw": 10.0, "tnw": 1.0, "lr": 1e-3}
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
+                          lr=1e-3, seed=1234 + rank, device=local, stream=stream.cuda_stream, fused=not a.no_fused)
+        e.set_skill_table(ds["table"]); e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
+        e.load_state_dict(init_params(dims, bayesian, 0))
+        dp = DataParallel(e)
+        gB = a.batch * world                                   # weak scaling: B teams per GPU
+        rng = np.random.default_rng(7)
+        total_steps = a.warmup + a.steps
+        order = rng.integers(0, ds["N"], total_steps * gB).astype(np.int64)   # the loader's shuffled row order
+        if a.warmup:
+            dp.train_epoch(order[: a.warmup * gB], gB)
+        e.kernel_times(enable=True)
+        e.synchronize(); torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+        t0 = time.perf_counter()
+        mean_loss = dp.train_epoch(order[a.warmup * gB:], gB)
+        e.synchronize(); torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+        dt = time.perf_counter() - t0
+        times = e.kernel_times(enable=False)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1: dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+        gather = None
+        if a.gather_bench and rank == 0:
+            e.kernel_times(enable=True)
+            n = ds["N"]
+            e.gather_meanpool(n=n, to_host=False); e.kernel_times(enable=True)
+            for _ in range(3): e.gather_meanpool(n=n, to_host=False)
+            ms, calls = e.kernel_times(enable=False)["gather"]
+            nnz = ds["skill"][0][-1] / n
+            bytes_per_team = nnz * (4 * a.d + 4) + 8 + 4 * a.d
+            gather = {"bound": "hbm", "achieved": bytes_per_team * n / (ms / calls * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "bytes_per_team": bytes_per_team, "teams": n, "ms": ms / calls}
+            gather["frac"] = gather["achieved"] / gather["peak"]
+
+    if rank != 0:
+        if world > 1: dist.destroy_process_group()
+        return
+    B, H, M = a.batch, a.hidden, ds["M"]
+    gemm = 2.0 * B * H * M  # one [B,H]x[H,M]-sized product
+    k = 2 if bayesian else 1
+    # per timed scope: the unfused families launch one GEMM per Flipout half (k launches), the fused ones a single kernel
+    flops_per_launch = {"out_fwd_gemm": k * gemm, "out_bwd_dw_gemm": k * gemm, "out_bwd_da_gemm": k * gemm,
+                        "out_fused_fwd_loss_dh": 2 * k * gemm, "out_fused_dw_adam": k * gemm}
+    cand = {f: times[f] for f in flops_per_launch if f in times and times[f][1] > 0}
+    dom = max(cand, key=lambda f: cand[f][0]) if cand else None
+    roof = None
+    if dom:
+        ms, calls = cand[dom]
+        ach = flops_per_launch[dom] / (ms / calls * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                "traffic": None, "avg_ms": ms / calls, "launches": calls}
+    out = {
+        "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.dataset} mt10.ts2 shapes N={ds['N']} S={ds['S']} M={M}; {a.model} (Flipout) on mean-pooled skill table d={a.d}, "
+                               f"h=[{H}], b={B}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3", "global_batch": gB, "parallelism": f"dp{world}"},
+        "roofline": roof, "cpu_baseline": None, "mean_loss": mean_loss,
+        "kernel_ms_per_step": {f: round(v[0] / a.steps, 4) for f, v in times.items() if v[1] > 0},
+    }
+    if gather: out["roofline_gather"] = gather
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ds, dims, bayesian, cfg)
+    print(json.dumps(out))
+    if world > 1: dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

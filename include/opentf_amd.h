@@ -110,6 +110,11 @@ int ntf_apply(ntf_engine* e);
 int ntf_train_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss);
 int ntf_eval_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss);
 int ntf_epoch_loss(ntf_engine* e, double* sum, int64_t* steps); /* reads and clears the accumulator */
+/* the same without any per-step host copy: stage the epoch's row order once, then step by offset.  The local
+ * shard is order[offset, offset+B); the global minibatch it belongs to is order[global_offset, +global_B)
+ * (they coincide on one GPU).  apply != 0 runs Adam right after backward (single GPU). */
+int ntf_stage_order(ntf_engine* e, const int64_t* order, int64_t n);
+int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, int32_t train, int32_t apply, float* loss_out);
 
 /* ---- inference:  Fnn.test batch body                              src/mdl/fnn.py:200-211
  * probs_host [B, M] = sigmoid(forward) (Bnn: mean over nmc stochastic forwards);

@@ -17,10 +17,14 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 
 // +1/-1 at (row, col) of a sign tensor: bayesian-torch draws uniform_(-1,1).sign(); here a two-stage
 // murmur finaliser of (row, col) under a per-(step, layer, tensor) key, or the injected array.
-__device__ __forceinline__ float sign_hash(uint32_t k0, uint32_t k1, uint32_t r, uint32_t c) {
+// One 32-bit word carries the signs of 32 consecutive columns of a row (bit c&31 of word(r, c>>5)), so that the
+// fused kernels can fetch / regenerate 32 signs at a time; every path derives its signs from this definition.
+__device__ __forceinline__ uint32_t sign_word(uint32_t k0, uint32_t k1, uint32_t r, uint32_t cb) {
     uint32_t h = fmix32(r * 0x9E3779B1u + k0);
-    h = fmix32(h ^ (c * 0x85EBCA77u + k1));
-    return (h & 0x00010000u) ? -1.0f : 1.0f;
+    return fmix32(h ^ (cb * 0x85EBCA77u + k1));
+}
+__device__ __forceinline__ float sign_hash(uint32_t k0, uint32_t k1, uint32_t r, uint32_t c) {
+    return ((sign_word(k0, k1, r, c >> 5) >> (c & 31)) & 1u) ? -1.0f : 1.0f;
 }
 __device__ __forceinline__ float sign_at(const SignSpec& s, int64_t r, int64_t c) {
     if (s.inj) return s.inj[r * s.ld + c];

@@ -48,7 +48,7 @@ struct ntf_engine {
     float* Xall = nullptr; int64_t x_rows = 0;
     float* al_prob = nullptr; int32_t* al_alias = nullptr; double* al_weight = nullptr; double al_total = 0; int64_t al_n = 0;
     // per-step buffers
-    int64_t* d_rows = nullptr; int64_t* d_order = nullptr; int64_t order_cap = 0;
+    int64_t* d_rows = nullptr; int64_t* d_order = nullptr; int64_t order_cap = 0; std::vector<int64_t> h_order;
     int64_t* d_neg = nullptr;
     std::vector<float*> act;          // act[0] = X [B, D], act[l] = leaky_relu output of layer l-1 (hidden)
     float *Zout = nullptr, *dZout = nullptr, *Pbuf = nullptr;
@@ -57,6 +57,7 @@ struct ntf_engine {
     std::vector<float*> Wp, bp;       // flipout perturbation operands per layer
     float *partial = nullptr, *row_fix = nullptr, *d_loss = nullptr, *ent_mc = nullptr, *ent_mean = nullptr;
     float *dh_slab = nullptr;         // fused path: partial d(hidden) slabs
+    char* fws = nullptr;              // fused path: sign-bit images, h*s_in, loss partials
     double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
     float* tk_vals = nullptr; int32_t* tk_idx = nullptr; int64_t tk_cap = 0;
     // injection staging (device)
@@ -179,7 +180,10 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     A(dmalloc(e, &e->partial, (int64_t)B * std::max(loss_dense_nchunk(M), fused_loss_slots(M)))); A(dmalloc(e, &e->row_fix, B));
     A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 2)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
     A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B));
-    if (rc == NTF_OK && fused_ok(e)) A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
+    if (rc == NTF_OK && fused_ok(e)) {
+        A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
+        A(dmalloc(e, &e->fws, (int64_t)fused_workspace_bytes(B, e->layers[e->L - 1].in, M)));
+    }
     e->inj_eps_w.assign(e->L, nullptr); e->inj_eps_b.assign(e->L, nullptr); e->inj_s_in.assign(e->L, nullptr); e->inj_s_out.assign(e->L, nullptr);
     if (rc != NTF_OK) { g_create_error = e->err; ntf_engine_destroy(e); return rc; }
     hipMemsetAsync(e->P, 0, off * 4, e->st); hipMemsetAsync(e->G, 0, off * 4, e->st);
@@ -203,7 +207,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto& p : e->Wp) dfree(p);
     for (auto& p : e->bp) dfree(p);
     dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_acc); dfree(e->d_acc_steps);
-    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->tk_vals); dfree(e->tk_idx);
+    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws); dfree(e->tk_vals); dfree(e->tk_idx);
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
@@ -536,7 +540,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.h = e->act[e->L - 1];
         f.mu = e->P + lo.off[NTF_P_WEIGHT]; f.mu_b = e->P + lo.off[NTF_P_BIAS];
         f.tnw = e->cfg.tnw; f.tpw = e->cfg.tpw; f.inv_B = inv_B;
-        f.dzT = e->dZout; f.dh_slab = e->dh_slab; f.loss_partial = e->partial;
+        f.dzT = e->dZout; f.dh_slab = e->dh_slab; f.ws = e->fws;
         f.dh = e->L > 1 ? e->dAct[(e->L - 1) & 1] : nullptr;
         f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
         if (e->cfg.bayesian) {
@@ -579,7 +583,9 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if (last && fused) {
             FusedDw f;
             f.B = B; f.H = li.in; f.M = M; f.bayes = e->cfg.bayesian;
-            f.dzT = e->dZout; f.h = in; f.g_mu = gW; f.g_wp = gRW; f.g_b = gb; f.g_bp = gRb; f.s_in = sin_; f.s_out = sout_;
+            f.dzT = e->dZout; f.h = in; f.g_mu = gW; f.g_rho = gRW; f.g_b = gb; f.g_bp = gRb; f.ws = e->fws;
+            f.mu = e->P + li.off[NTF_P_WEIGHT];
+            if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
             Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f);
         } else {
             const float* dZ = last ? e->dZout : e->dAct[(l + 1) & 1];
@@ -618,8 +624,9 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         if (e->cfg.bayesian) {
             Scope t(e, F_FLIPOUT_FINAL);
-            launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], gW, gRW, li.nw(),
-                                         normal_spec(e, c, l, T_EPS_W), kl_share / ((float)li.nw() * (float)c.global_B));
+            if (!(last && fused))  // the fused dW kernel finalises the output layer's weights in its epilogue
+                launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], gW, gRW, li.nw(),
+                                             normal_spec(e, c, l, T_EPS_W), kl_share / ((float)li.nw() * (float)c.global_B));
             launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_BIAS], e->P + li.off[NTF_P_RHO_BIAS], gb, gRb, li.out,
                                          normal_spec(e, c, l, T_EPS_B), kl_share / ((float)li.out * (float)c.global_B));
         }
@@ -685,23 +692,38 @@ extern "C" int ntf_apply(ntf_engine* e) {
     return apply_adam(e);
 }
 
+extern "C" int ntf_stage_order(ntf_engine* e, const int64_t* order, int64_t n) {
+    if (!e || !order || n < 1) { if (e) e->err = "stage_order: bad arguments"; return NTF_EINVAL; }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    for (int64_t i = 0; i < n; ++i) if (order[i] < 0 || (e->m_rows && order[i] >= e->m_rows)) FAIL(e, NTF_EINVAL, "stage_order: row id out of range");
+    if (e->order_cap < n) { dfree(e->d_order); DM(e, &e->d_order, n); e->order_cap = n; }
+    e->h_order.assign(order, order + n);
+    HIPCHK(e, hipMemcpyAsync(e->d_order, e->h_order.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return NTF_OK;
+}
+extern "C" int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, int32_t train, int32_t apply,
+                               float* loss_out) {
+    if (!e) return NTF_EINVAL;
+    const int64_t n = (int64_t)e->h_order.size();
+    if (offset < 0 || B < 1 || offset + B > n || global_offset < 0 || global_offset + global_B > n || offset < global_offset ||
+        offset + B > global_offset + global_B)
+        FAIL(e, NTF_EINVAL, "step_staged: shard / batch outside the staged order");
+    return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, train != 0, apply != 0, true, e->h_order.data() + global_offset, global_B);
+}
+
 static int run_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss, bool train) {
     if (!e || !order || n < 1 || B < 1 || B > e->cfg.max_batch) { if (e) e->err = "epoch: bad arguments"; return NTF_EINVAL; }
-    HIPCHK(e, hipSetDevice(e->cfg.device));
-    for (int64_t i = 0; i < n; ++i) if (order[i] < 0 || (e->m_rows && order[i] >= e->m_rows)) FAIL(e, NTF_EINVAL, "epoch: row id out of range");
-    if (e->order_cap < n) { dfree(e->d_order); DM(e, &e->d_order, n); e->order_cap = n; }
-    HIPCHK(e, hipMemcpyAsync(e->d_order, order, (size_t)n * 8, hipMemcpyHostToDevice, e->st));
+    int r = ntf_stage_order(e, order, n);
+    if (r) return r;
     HIPCHK(e, hipMemsetAsync(e->d_acc, 0, 8, e->st));
     HIPCHK(e, hipMemsetAsync(e->d_acc_steps, 0, 8, e->st));
-    HIPCHK(e, hipStreamSynchronize(e->st));
     for (int64_t o = 0; o < n; o += B) {
         const int b = (int)std::min<int64_t>(B, n - o);
-        int r = step_common(e, e->d_order + o, b, b, nullptr, nullptr, train, train, true, order + o, b);
-        if (r) return r;
+        if ((r = ntf_step_staged(e, o, b, o, b, train, train, nullptr))) return r;
     }
     double sum = 0; int64_t steps = 0;
-    int r = ntf_epoch_loss(e, &sum, &steps);
-    if (r) return r;
+    if ((r = ntf_epoch_loss(e, &sum, &steps))) return r;
     if (mean_loss) *mean_loss = steps ? (float)(sum / (double)steps) : 0.f;
     return NTF_OK;
 }

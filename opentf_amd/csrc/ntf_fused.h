@@ -12,27 +12,32 @@ struct FusedOut {
     const float *wp = nullptr, *bp = nullptr;       // flipout perturbation operands sigma*eps [M, H], [M]
     SignSpec s_in, s_out;
     float tnw = 1.f, tpw = 1.f, inv_B = 1.f;
-    float* dzT = nullptr;                           // out: d loss / d z, TRANSPOSED [M, ldb]
+    float* dzT = nullptr;                           // out: d loss / d z, TRANSPOSED [M, ldb], ldb = fused_ldb(B)
     float* dh_slab = nullptr;                       // scratch: per column-group partial d(hidden)
     float* dh = nullptr;                            // out: [B, H] d loss / d(pre-activation of the hidden layer), may be null
-    const float* h_mask = nullptr;                  // leaky_relu' mask source for dh (= h)
+    const float* h_mask = nullptr;                  // leaky_relu' mask source for dh (= h), null: no mask
     float* loss_partial = nullptr;                  // [B, fused_loss_slots(M)]
+    void* ws = nullptr;                             // fused_workspace_bytes(B, H, M)
     // sparse fix-up
     const int64_t* rows = nullptr; const int64_t* m_indptr = nullptr; const int32_t* m_indices = nullptr;
     const int64_t* neg = nullptr; int ns = 0; float* row_fix = nullptr;
 };
 
-// weight / bias gradients of the output layer from dzT
+// weight / bias gradients of the output layer from dzT (K = batch); for Flipout the rho gradient is finalised here
+// (times eps * sigmoid(rho), plus the KL terms), eps being recovered as wp / softplus(rho).
 struct FusedDw {
     int B = 0, H = 0, M = 0, bayes = 0;
     const float* dzT = nullptr; const float* h = nullptr;
-    float *g_mu = nullptr, *g_wp = nullptr, *g_b = nullptr, *g_bp = nullptr;
-    SignSpec s_in, s_out;
+    const float *mu = nullptr, *rho = nullptr, *wp = nullptr;
+    float *g_mu = nullptr, *g_rho = nullptr, *g_b = nullptr, *g_bp = nullptr;
+    float klw = 0.f;
+    void* ws = nullptr;                             // the workspace launch_fused_out_fwd filled for this step
 };
 
 bool fused_supported(int H);
 int fused_loss_slots(int M);
 int64_t fused_dh_slab_floats(int B, int H, int M);
+size_t fused_workspace_bytes(int B, int H, int M);
 int fused_ldb(int B);
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);

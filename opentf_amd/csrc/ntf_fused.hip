@@ -1,9 +1,583 @@
+// Fused output-layer kernels for gfx950.  The output layer ([B,H] x [H,M], M = number of experts, up to
+// millions) carries >95 % of the step's FLOPs; it is computed by exact-f32 MFMA (v_mfma_f32_32x32x2_f32) in
+// two kernels that never materialise dense labels or logits:
+//
+//   k_out_fwd   persistent, one workgroup per CU = (128 batch rows) x (a contiguous group of 64-expert tiles).
+//               Per tile: zT = mu_tile . hT (+ Flipout perturbation product), bias, leaky_relu, BCE against the
+//               all-negative dense labelling, d(loss)/dz -> dzT (transposed, one write), and immediately
+//               dh += dz . mu_tile out of the same LDS tile and the accumulator registers (the 32x32 accumulator
+//               layout is exactly the A-operand layout of the next MFMA when it sums over the accumulator's rows).
+//               Weight tiles arrive by LDS-DMA (global_load_lds_dwordx4), double buffered, XOR-swizzled on the
+//               source address so that both the ds_read_b128 fragment reads and the DMA writes are conflict free.
+//   k_out_special  one wave per team: sparse fix-up for the positives / sampled negatives (labels stay CSR),
+//               reduction of the per-group dh slabs, leaky_relu' mask.
+//   k_out_dw    dmu = dzT . h, dWp = (dzT*s_out) . (h*s_in) with K = batch, bias gradients from the A operand,
+//               Flipout rho-gradient + KL finalised in the epilogue.
 #include "ntf_fused.h"
+#include "ntf_device.h"
+#include <algorithm>
+
 namespace ntf {
-bool fused_supported(int) { return false; }
-int fused_loss_slots(int) { return 1; }
-int64_t fused_dh_slab_floats(int, int, int) { return 0; }
-int fused_ldb(int B) { return (B + 127) / 128 * 128; }
-void launch_fused_out_fwd(hipStream_t, const FusedOut&) {}
-void launch_fused_out_dw(hipStream_t, const FusedDw&) {}
+
+constexpr int BM = 128;       // batch rows per workgroup: 4 waves x 32
+constexpr int BN = 64;        // experts per tile
+constexpr int NCG_MAX = 256;  // column groups (one workgroup per CU when the batch has a single row block)
+
+static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+int fused_ldb(int B) { return rup(B, BM); }
+bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
+int fused_loss_slots(int) { return 0; }
+
+struct Geom { int Bpad, NRB, T, NCG, nCB; };
+static Geom geom(int B, int M) {
+    Geom g;
+    g.Bpad = rup(B, BM); g.NRB = g.Bpad / BM; g.T = (M + BN - 1) / BN;
+    g.NCG = std::max(1, std::min(NCG_MAX / g.NRB, g.T));
+    g.nCB = rup((M + 31) / 32, 2);
+    return g;
 }
+int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)NCG_MAX * BM * H; }
+
+struct WsLayout { size_t sbits, sbitsT, sinbits, hs, lossp, total; };
+static WsLayout ws_layout(int Bmax, int H, int M) {
+    const int Bpad = rup(Bmax, BM), nCB = rup((M + 31) / 32, 2);
+    WsLayout w; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+    w.sbits = take((size_t)Bpad * nCB * 4);
+    w.sbitsT = take((size_t)nCB * 32 * (Bpad / 32) * 4);
+    w.sinbits = take((size_t)Bpad * (H / 32) * 4);
+    w.hs = take((size_t)Bpad * H * 4);
+    w.lossp = take((size_t)Bpad * NCG_MAX * 4);
+    w.total = o;
+    return w;
+}
+size_t fused_workspace_bytes(int B, int H, int M) { return ws_layout(B, H, M).total; }
+
+// ------------------------------------------------------------------------------------------------
+// sign bit images: sbits[i][cb] (bit c&31 of word cb = c>>5), its 32x32-block transpose sbitsT[c][i>>5],
+// sinbits[i][j>>5] and hs = h * s_in
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sign_bits(SignSpec so, int B, int M, int Bpad, int nCB, uint32_t* __restrict__ sbits,
+                                                  uint32_t* __restrict__ sbitsT) {
+    const int lane = threadIdx.x, il = lane & 31, half = lane >> 5;
+    const int cb = 2 * blockIdx.x + half, ib = blockIdx.y;
+    const int i = ib * 32 + il;
+    uint32_t w = 0;
+    if (i < B) {
+        if (so.inj) {
+            for (int b = 0; b < 32; ++b) { const int c = cb * 32 + b; if (c < M && so.inj[(int64_t)i * so.ld + c] < 0.f) w |= 1u << b; }
+        } else w = sign_word(so.k0, so.k1, (uint32_t)i, (uint32_t)cb);
+    }
+    sbits[(int64_t)i * nCB + cb] = w;
+    uint32_t tw = 0;
+    for (int b = 0; b < 32; ++b) {
+        const unsigned long long bal = __ballot((w >> b) & 1u);
+        const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        if (il == b) tw = mine;
+    }
+    sbitsT[(int64_t)(cb * 32 + il) * (Bpad / 32) + ib] = tw;
+}
+
+__global__ void k_sin_bits(SignSpec si, const float* __restrict__ h, int B, int H, int Bpad, uint32_t* __restrict__ sinbits, float* __restrict__ hs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wpr = H / 32;
+    if (t >= Bpad * wpr) return;
+    const int i = t / wpr, wj = t % wpr;
+    uint32_t w = 0;
+    if (i < B) {
+        if (si.inj) { for (int b = 0; b < 32; ++b) if (si.inj[(int64_t)i * si.ld + wj * 32 + b] < 0.f) w |= 1u << b; }
+        else w = sign_word(si.k0, si.k1, (uint32_t)i, (uint32_t)wj);
+    }
+    sinbits[t] = w;
+    for (int b = 0; b < 32; ++b) {
+        const int j = wj * 32 + b;
+        const float v = (i < B) ? h[(int64_t)i * H + j] : 0.f;
+        hs[(int64_t)i * H + j] = ((w >> b) & 1u) ? -v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int H> __device__ __forceinline__ int swz(int row) { return H >= 64 ? (row & 15) : ((row >> 1) & 7); }
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+struct OutFwdArgs {
+    int B, M, Bpad, NRB, NCG, T, nCB;
+    const float *h, *hs, *mu, *mu_b, *wp, *bp;
+    const uint32_t *sbits, *sinbits;
+    float tnw, inv_B;
+    float *dzT, *slab, *lossp;
+};
+
+template <int H, bool BAYES, bool TRAIN, bool DH>
+__global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = 4 * H;              // bytes per weight row
+    constexpr int TB = BN * ROWB;            // bytes per weight tile
+    constexpr int NMAT = BAYES ? 2 : 1;
+    constexpr int STAGE = NMAT * TB + 512;   // + two 64-float bias tiles
+    constexpr int NE = H / 2;                // operand elements per lane (k split over the two lane halves)
+    constexpr int NJT = H / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+
+    // XCD-aware block -> (column group, row block): blocks that stream the same weight tiles share an XCD's L2
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int cg = bid / p.NRB, rb = bid % p.NRB;
+    const int t_beg = (int)((int64_t)cg * p.T / p.NCG), t_end = (int)((int64_t)(cg + 1) * p.T / p.NCG);
+    const int i0 = rb * BM + wave * 32;
+    const int i = i0 + il;
+    const bool row_ok = i < p.B;
+
+    // B operand of zT = mu . hT : this lane's batch row, k = 8t + 4*half + e
+    float hf[NE];
+#pragma unroll
+    for (int t = 0; t < H / 8; ++t) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row_ok) v = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 8 * t + 4 * half);
+        hf[4 * t] = v.x; hf[4 * t + 1] = v.y; hf[4 * t + 2] = v.z; hf[4 * t + 3] = v.w;
+    }
+    // s_in sign words of this row, pre-shifted so that bit (8t + e) & 31 of word (8t + e) >> 5 is the sign of k = 8t + 4*half + e
+    uint32_t sinw[NJT];
+#pragma unroll
+    for (int w = 0; w < NJT; ++w) sinw[w] = BAYES ? (p.sinbits[(int64_t)i * NJT + w] >> (4 * half)) : 0u;
+
+    // LDS byte offsets (relative to the stage base) that depend on the lane; everything else is an immediate.
+    //   A fragment of zT: row u*32 + il, logical 16-byte chunk q = 2*tq + half, physical chunk q ^ swz(row)
+    //   B operand of dh : row u*32 + rowmap(s, half), float j = jt*32 + il
+    constexpr int QM = (H >= 64) ? 8 : 4;   // distinct values of the swizzled low chunk bits over tq
+    int aoff[QM];
+#pragma unroll
+    for (int k = 0; k < QM; ++k) {
+        if (H >= 64) aoff[k] = il * ROWB + 16 * (((2 * k + half) & 15) ^ (il & 15));
+        else aoff[k] = il * ROWB + 16 * ((2 * k + half) ^ ((il >> 1) & 7));
+    }
+    int boff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // swz(row) for row = u*32 + (s&3) + 8*(s>>2) + 4*half
+        if (H >= 64) boff[k] = 4 * half * ROWB + 16 * (((il >> 2) ^ (k + 4 * half)) & 7) + 4 * (il & 3);
+        else boff[k] = 4 * half * ROWB + 16 * (il >> 2) + 4 * (il & 3);  // H == 32: resolved per (s) below
+    }
+
+    f32x16 Y1[NJT], Y2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
+    float lsum = 0.f;
+
+    auto stage_tile = [&](int t, int buf) {
+        char* sb = smem + buf * STAGE;
+        const int c0 = t * BN;
+        constexpr int PER_WAVE = TB / 4096;  // 1 KiB wave-instructions per wave per matrix
+#pragma unroll
+        for (int n = 0; n < PER_WAVE; ++n) {
+            const int inst = wave * PER_WAVE + n;
+            const int off = inst * 1024 + lane * 16;
+            const int row = off / ROWB, pch = (off % ROWB) >> 4;
+            const int q = pch ^ swz<H>(row);
+            const int64_t grow = min(c0 + row, p.M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.mu + grow * H + 4 * q), (lds_ptr_t)(sb + inst * 1024), 16, 0, 0);
+            if (BAYES)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.wp + grow * H + 4 * q), (lds_ptr_t)(sb + TB + inst * 1024), 16, 0, 0);
+        }
+        if (wave == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.mu_b + min(c0 + lane, p.M - 1)), (lds_ptr_t)(sb + NMAT * TB), 4, 0, 0);
+        if (BAYES && wave == 1) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.bp + min(c0 + lane, p.M - 1)), (lds_ptr_t)(sb + NMAT * TB + 256), 4, 0, 0);
+    };
+
+    if (t_beg < t_end) stage_tile(t_beg, 0);
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
+        const char* sb = smem + buf * STAGE;
+        const int c0 = t * BN;
+
+        // ---- zT tile: rows = experts (two 32-row sub-tiles), cols = this wave's 32 batch rows
+        f32x16 X1[2], X2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { X1[u][r] = 0.f; X2[u][r] = 0.f; }
+#pragma unroll
+        for (int tq = 0; tq < H / 8; ++tq) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // chunk q = 2*tq + half: low bits through aoff[], the bits above the swizzle width as an immediate
+                const int imm = u * 32 * ROWB + ((H >= 64) ? ((2 * tq) & ~15) * 16 : 0);
+                const char* ap = sb + aoff[tq % QM] + imm;
+                const float4 a = *reinterpret_cast<const float4*>(ap);
+                const float av[4] = {a.x, a.y, a.z, a.w};
+                float awv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (BAYES) { const float4 aw = *reinterpret_cast<const float4*>(ap + TB); awv[0] = aw.x; awv[1] = aw.y; awv[2] = aw.z; awv[3] = aw.w; }
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = 4 * tq + e4;
+                    X1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e4], hf[e], X1[u], 0, 0, 0);
+                    if (BAYES) {
+                        const int kb = 8 * tq + e4;  // k without the lane half
+                        const uint32_t m = (sinw[kb >> 5] << (31 - (kb & 31))) & 0x80000000u;
+                        X2[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(awv[e4], __uint_as_float(__float_as_uint(hf[e]) ^ m), X2[u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue on the accumulator registers: lane = batch row i, register r <-> expert c0 + u*32 + rowmap(r, half)
+        uint32_t sw[2] = {0u, 0u};
+        if (BAYES) {
+            const uint2 w2 = *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);
+            sw[0] = w2.x >> (4 * half); sw[1] = w2.y >> (4 * half);
+        }
+        const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TB) + 4 * half;
+        const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TB + 256) + 4 * half;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = u * 32 + (r & 3) + 8 * (r >> 2);  // + 4*half folded into the bias pointers / shifted sign word
+                const int c = c0 + cr + 4 * half;
+                float z = X1[u][r] + bias_mu[cr];
+                bool neg = false;
+                if (BAYES) {
+                    neg = (sw[u] >> ((r & 3) + 8 * (r >> 2))) & 1u;
+                    const float x2 = X2[u][r] + bias_p[cr];
+                    z += neg ? -x2 : x2;
+                }
+                const bool valid = row_ok && (c < p.M);
+                const bool pos = z > 0.f;
+                const float l = pos ? z : z * kLeakySlope;
+                const float e = __expf(-fabsf(l));
+                const float tt = 1.f + e;
+                const float sp = fmaxf(l, 0.f) + __logf(tt);
+                lsum += valid ? sp : 0.f;
+                if (TRAIN) {
+                    const float inv = __frcp_rn(tt);
+                    const float sg = (l >= 0.f) ? inv : e * inv;
+                    const float dz = valid ? p.tnw * sg * (pos ? 1.f : kLeakySlope) * p.inv_B : 0.f;
+                    if (c < p.M) p.dzT[(int64_t)c * p.Bpad + i] = dz;
+                    X1[u][r] = dz;
+                    X2[u][r] = neg ? -dz : dz;
+                }
+            }
+        }
+
+        // ---- dh += dz . mu_tile : A operand = the accumulator registers as they stand, B operand from the same LDS tile
+        if (TRAIN && DH) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int rowc = u * 32 + (s & 3) + 8 * (s >> 2);  // row without the lane half
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) {
+                        const char* bp_;
+                        if (H >= 64) {
+                            // chunk (8*jt + il>>2) ^ swz(row), swz(row) = (s&3) + 4*half + 8*((s>>2)&1): low 3 bits in boff[s&3]
+                            bp_ = sb + boff[s & 3] + rowc * ROWB + 16 * ((8 * jt) ^ (8 * ((s >> 2) & 1)));
+                        } else {
+                            // H == 32: 8 chunks per row, swz(row) = (row >> 1) & 7 with row = rowc + 4*half
+                            const int szc = ((rowc >> 1) & 7);  // the half adds 2 to (row >> 1): xor handled through the lane term below
+                            bp_ = sb + rowc * ROWB + 4 * half * ROWB + 16 * (((il >> 2) ^ ((szc + 2 * half) & 7))) + 4 * (il & 3);
+                        }
+                        Y1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1[u][s], *reinterpret_cast<const float*>(bp_), Y1[jt], 0, 0, 0);
+                        if (BAYES)
+                            Y2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X2[u][s], *reinterpret_cast<const float*>(bp_ + TB), Y2[jt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // next tile landed (vmcnt(0)) and nobody still reads this one
+    }
+
+    // per-row loss partial of this column group
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+
+    if (TRAIN && DH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int irow = i0 + rowmap(r, half);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                float v = Y1[jt][r];
+                if (BAYES) {
+                    const uint32_t w = p.sinbits[(int64_t)irow * NJT + jt];
+                    const float y2 = Y2[jt][r];
+                    v += ((w >> il) & 1u) ? -y2 : y2;
+                }
+                p.slab[((int64_t)cg * p.Bpad + irow) * H + jt * 32 + il] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SpecialArgs {
+    int B, M, Bpad, NCG, nCB, ns;
+    const float *h, *hs, *mu, *mu_b, *wp, *bp, *slab, *lossp, *h_mask;
+    const uint32_t *sbits, *sinbits;
+    const int64_t *rows, *m_indptr, *neg; const int32_t* m_indices;
+    float tpw, tnw, inv_B;
+    float *dzT, *dh, *row_fix;
+};
+
+template <int H, bool BAYES, bool TRAIN, bool DH>
+__global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
+    constexpr int NM = (H + 63) / 64;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    float rl = 0.f;
+    for (int cg = lane; cg < p.NCG; cg += 64) rl += p.lossp[(int64_t)i * p.NCG + cg];
+    rl = wave_reduce_sum(rl);
+    float acc[NM], hr[NM], hsr[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int j = lane + 64 * m;
+        acc[m] = 0.f; hr[m] = 0.f; hsr[m] = 0.f;
+        if (j < H) {
+            hr[m] = p.h[(int64_t)i * H + j];
+            if (BAYES) hsr[m] = p.hs[(int64_t)i * H + j];
+            if (TRAIN && DH) for (int cg = 0; cg < p.NCG; ++cg) acc[m] += p.slab[((int64_t)cg * p.Bpad + i) * H + j];
+        }
+    }
+    const int64_t team = p.rows[i];
+    const int64_t pb = p.m_indptr[team];
+    const int npos = (int)(p.m_indptr[team + 1] - pb);
+    const int total = npos + (p.neg ? p.ns : 0);
+    float fix = 0.f;
+    for (int sidx = 0; sidx < total; ++sidx) {
+        int c; float y; bool skip = false;
+        if (sidx < npos) { c = p.m_indices[pb + sidx]; y = 1.f; }
+        else {
+            const int q = sidx - npos;
+            c = (int)p.neg[(int64_t)i * p.ns + q]; y = 0.f;
+            for (int k = 0; k < npos; ++k) if (p.m_indices[pb + k] == c) skip = true;
+            for (int k = 0; k < q; ++k) if ((int)p.neg[(int64_t)i * p.ns + k] == c) skip = true;
+        }
+        if (skip || c < 0 || c >= p.M) continue;
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int j = lane + 64 * m;
+            if (j < H) { d1 += hr[m] * p.mu[(int64_t)c * H + j]; if (BAYES) d2 += hsr[m] * p.wp[(int64_t)c * H + j]; }
+        }
+        d1 = wave_reduce_sum(d1);
+        float z = d1 + p.mu_b[c];
+        float so = 1.f;
+        if (BAYES) {
+            d2 = wave_reduce_sum(d2);
+            so = ((p.sbits[(int64_t)i * p.nCB + (c >> 5)] >> (c & 31)) & 1u) ? -1.f : 1.f;
+            z += (d2 + p.bp[c]) * so;
+        }
+        float sp, sg, dact;
+        bce_terms(z, sp, sg, dact);
+        const float l = z > 0.f ? z : z * kLeakySlope;
+        fix += p.tpw * (sp - l * y) - p.tnw * sp;
+        if (TRAIN) {
+            const float dzt = p.tpw * (sg - y) * dact * p.inv_B;
+            const float delta = dzt - p.tnw * sg * dact * p.inv_B;
+            if (lane == 0) p.dzT[(int64_t)c * p.Bpad + i] = dzt;
+            if (DH) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int j = lane + 64 * m;
+                    if (j < H) {
+                        acc[m] += delta * p.mu[(int64_t)c * H + j];
+                        if (BAYES) {
+                            const float si = ((p.sinbits[(int64_t)i * (H / 32) + (j >> 5)] >> (j & 31)) & 1u) ? -1.f : 1.f;
+                            acc[m] += delta * so * p.wp[(int64_t)c * H + j] * si;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) p.row_fix[i] = rl + fix;
+    if (TRAIN && DH) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int j = lane + 64 * m;
+            if (j < H) {
+                float v = acc[m];
+                if (p.h_mask) v *= (p.h_mask[(int64_t)i * H + j] > 0.f) ? 1.f : kLeakySlope;
+                p.dh[(int64_t)i * H + j] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DwArgs {
+    int B, M, Bpad;
+    const float *dzT, *h, *hs, *mu, *rho, *wp;
+    const uint32_t* sbitsT;
+    float *g_mu, *g_rho, *g_b, *g_bp;
+    float klw;
+};
+
+template <int H, bool BAYES>
+__global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
+    constexpr int NJT = H / 32;
+    constexpr int KB = 32;                  // batch rows per K block
+    constexpr int HROW = 4 * H;
+    __shared__ __attribute__((aligned(16))) char sA[128 * KB * 4];
+    __shared__ __attribute__((aligned(16))) char sH[KB * HROW];
+    __shared__ __attribute__((aligned(16))) char sHs[BAYES ? KB * HROW : 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    const int c0 = blockIdx.x * 128;
+    const int crow = wave * 32 + il;        // this lane's expert row inside the tile
+    const int c = c0 + crow;
+    const int cclamp = min(c, p.M - 1);
+    const int nib = p.Bpad / KB;
+
+    f32x16 acc1[NJT], acc2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
+    float sum1 = 0.f, sum2 = 0.f;
+
+    for (int ib = 0; ib < nib; ++ib) {
+        // stage dzT tile [128 experts][32 batch rows] (16-byte chunks XOR-swizzled) and the h / h*s_in tiles [32][H]
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int ch = tid + 256 * n;
+            const int row = ch >> 3, q = ch & 7;
+            const int grow = min(c0 + row, p.M - 1);
+            const float4 v = *reinterpret_cast<const float4*>(p.dzT + (int64_t)grow * p.Bpad + ib * KB + 4 * q);
+            *reinterpret_cast<float4*>(sA + row * 128 + 16 * (q ^ ((row >> 1) & 7))) = v;
+        }
+#pragma unroll
+        for (int n = 0; n < (KB * H / 4 + 255) / 256; ++n) {
+            const int ch = tid + 256 * n;
+            if (ch < KB * H / 4) {
+                const int row = ch / (H / 4), q = ch % (H / 4);
+                const int gi = ib * KB + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f), vs = v;
+                if (gi < p.B) {
+                    v = *reinterpret_cast<const float4*>(p.h + (int64_t)gi * H + 4 * q);
+                    if (BAYES) vs = *reinterpret_cast<const float4*>(p.hs + (int64_t)gi * H + 4 * q);
+                }
+                *reinterpret_cast<float4*>(sH + row * HROW + 16 * q) = v;
+                if (BAYES) *reinterpret_cast<float4*>(sHs + row * HROW + 16 * q) = vs;
+            }
+        }
+        uint32_t word = 0;
+        if (BAYES) word = p.sbitsT[(int64_t)cclamp * (p.Bpad / 32) + ib] >> (4 * half);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = 2 * t + half;
+            const float4 a = *reinterpret_cast<const float4*>(sA + crow * 128 + 16 * (q ^ ((crow >> 1) & 7)));
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int kk = 8 * t + e4;  // + 4*half : batch row inside the K block
+                const float a1 = av[e4];
+                sum1 += a1;
+                float a2 = a1;
+                if (BAYES) { a2 = ((word >> kk) & 1u) ? -a1 : a1; sum2 += a2; }
+                const char* hb = sH + (kk + 4 * half) * HROW + 4 * il;
+                const char* hsb = sHs + (kk + 4 * half) * HROW + 4 * il;
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, *reinterpret_cast<const float*>(hb + 128 * jt), acc1[jt], 0, 0, 0);
+                    if (BAYES) acc2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, *reinterpret_cast<const float*>(hsb + 128 * jt), acc2[jt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    sum1 += __shfl_xor(sum1, 32, 64);
+    sum2 += __shfl_xor(sum2, 32, 64);
+    if (half == 0 && c < p.M) { p.g_b[c] = sum1; if (BAYES) p.g_bp[c] = sum2; }
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cr = c0 + wave * 32 + rowmap(r, half);
+        if (cr >= p.M) continue;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int64_t idx = (int64_t)cr * H + jt * 32 + il;
+            if (!BAYES) { p.g_mu[idx] = acc1[jt][r]; }
+            else {
+                const float m = p.mu[idx], rh = p.rho[idx], w = p.wp[idx];
+                const float sigma = softplus_rho(rh);
+                const float sg = 1.f / (1.f + expf(-rh));
+                p.g_mu[idx] = acc1[jt][r] + p.klw * m;
+                p.g_rho[idx] = acc2[jt][r] * (w / sigma) * sg + p.klw * (sigma - 1.f / sigma) * sg;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int H, bool BAYES>
+static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid) {
+    constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
+    const size_t lds = 2 * STAGE;
+    const bool dh = f.dh != nullptr;
+#define NTF_LAUNCH_FWD(TR, DHF)                                                                                           \
+    do {                                                                                                                  \
+        auto kf = k_out_fwd<H, BAYES, TR, DHF>;                                                                           \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);                                                        \
+        hipLaunchKernelGGL((k_out_special<H, BAYES, TR, DHF>), dim3(f.B), dim3(64), 0, st, s);                            \
+    } while (0)
+    if (!f.train) NTF_LAUNCH_FWD(false, false);
+    else if (dh) NTF_LAUNCH_FWD(true, true);
+    else NTF_LAUNCH_FWD(true, false);
+#undef NTF_LAUNCH_FWD
+}
+
+void launch_fused_out_fwd(hipStream_t st, const FusedOut& f) {
+    const Geom g = geom(f.B, f.M);
+    const WsLayout w = ws_layout(f.B, f.H, f.M);
+    char* ws = static_cast<char*>(f.ws);
+    uint32_t* sbits = reinterpret_cast<uint32_t*>(ws + w.sbits);
+    uint32_t* sbitsT = reinterpret_cast<uint32_t*>(ws + w.sbitsT);
+    uint32_t* sinbits = reinterpret_cast<uint32_t*>(ws + w.sinbits);
+    float* hs = reinterpret_cast<float*>(ws + w.hs);
+    float* lossp = reinterpret_cast<float*>(ws + w.lossp);
+    if (f.bayes) {
+        hipLaunchKernelGGL(k_sign_bits, dim3(g.nCB / 2, g.Bpad / 32), dim3(64), 0, st, f.s_out, f.B, f.M, g.Bpad, g.nCB, sbits, sbitsT);
+        const int n = g.Bpad * (f.H / 32);
+        hipLaunchKernelGGL(k_sin_bits, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.h, f.B, f.H, g.Bpad, sinbits, hs);
+    }
+    OutFwdArgs a;
+    a.B = f.B; a.M = f.M; a.Bpad = g.Bpad; a.NRB = g.NRB; a.NCG = g.NCG; a.T = g.T; a.nCB = g.nCB;
+    a.h = f.h; a.hs = hs; a.mu = f.mu; a.mu_b = f.mu_b; a.wp = f.wp; a.bp = f.bp; a.sbits = sbits; a.sinbits = sinbits;
+    a.tnw = f.tnw; a.inv_B = f.inv_B; a.dzT = f.dzT; a.slab = f.dh_slab; a.lossp = lossp;
+    SpecialArgs s;
+    s.B = f.B; s.M = f.M; s.Bpad = g.Bpad; s.NCG = g.NCG; s.nCB = g.nCB; s.ns = f.ns;
+    s.h = f.h; s.hs = hs; s.mu = f.mu; s.mu_b = f.mu_b; s.wp = f.wp; s.bp = f.bp; s.slab = f.dh_slab; s.lossp = lossp; s.h_mask = f.h_mask;
+    s.sbits = sbits; s.sinbits = sinbits; s.rows = f.rows; s.m_indptr = f.m_indptr; s.neg = f.neg; s.m_indices = f.m_indices;
+    s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
+    const int grid = g.NRB * g.NCG;
+#define NTF_H(HH) do { if (f.bayes) fwd_dispatch<HH, true>(st, f, a, s, grid); else fwd_dispatch<HH, false>(st, f, a, s, grid); } while (0)
+    if (f.H == 128) NTF_H(128); else if (f.H == 64) NTF_H(64); else NTF_H(32);
+#undef NTF_H
+}
+
+void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
+    const Geom g = geom(f.B, f.M);
+    const WsLayout w = ws_layout(f.B, f.H, f.M);
+    char* ws = static_cast<char*>(f.ws);
+    DwArgs a;
+    a.B = f.B; a.M = f.M; a.Bpad = g.Bpad; a.dzT = f.dzT; a.h = f.h; a.hs = reinterpret_cast<const float*>(ws + w.hs);
+    a.mu = f.mu; a.rho = f.rho; a.wp = f.wp; a.sbitsT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
+    a.g_mu = f.g_mu; a.g_rho = f.g_rho; a.g_b = f.g_b; a.g_bp = f.g_bp; a.klw = f.klw;
+    const int grid = (f.M + 127) / 128;
+#define NTF_DW(HH) do { if (f.bayes) hipLaunchKernelGGL((k_out_dw<HH, true>), dim3(grid), dim3(256), 0, st, a); \
+                        else hipLaunchKernelGGL((k_out_dw<HH, false>), dim3(grid), dim3(256), 0, st, a); } while (0)
+    if (f.H == 128) NTF_DW(128); else if (f.H == 64) NTF_DW(64); else NTF_DW(32);
+#undef NTF_DW
+}
+
+}  // namespace ntf

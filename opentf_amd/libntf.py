@@ -62,6 +62,8 @@ SYMBOLS = {
     "ntf_train_epoch": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "ntf_eval_epoch": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "ntf_epoch_loss": (C.c_int, [_P, _P, _P]),
+    "ntf_stage_order": (C.c_int, [_P, _P, _I64]),
+    "ntf_step_staged": (C.c_int, [_P, _I64, _I32, _I64, _I32, _I32, _I32, _P]),
     "ntf_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P]),
     "ntf_logits": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_forward_topk": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
@@ -84,6 +86,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             raise NtfError(f"{_LIB_PATH} is missing: build it (make -C opentf_amd/csrc). There is no CPU fallback.")
+        import torch  # noqa: F401  (load torch's bundled HIP runtime first: this library must share it, not bring a second copy)
         l = C.CDLL(_LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
@@ -279,6 +282,16 @@ class Engine:
         self._ck(lib().ntf_eval_epoch(self._h, _ptr(o), len(o), int(B), C.byref(loss)))
         return loss.value
 
+    def stage_order(self, order):
+        o = self._rows(order)
+        self._ck(lib().ntf_stage_order(self._h, _ptr(o), len(o)))
+
+    def step_staged(self, offset, B, global_offset=None, global_B=None, train=True, apply=True, want_loss=False):
+        loss = C.c_float()
+        self._ck(lib().ntf_step_staged(self._h, int(offset), int(B), int(offset if global_offset is None else global_offset),
+                                       int(B if global_B is None else global_B), int(train), int(apply), C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
     def epoch_loss(self):
         s, k = C.c_double(), C.c_int64()
         self._ck(lib().ntf_epoch_loss(self._h, C.byref(s), C.byref(k)))
@@ -332,6 +345,11 @@ class Engine:
         p, n = C.c_void_p(), C.c_int64()
         self._ck(lib().ntf_param_buffer(self._h, C.byref(p), C.byref(n)))
         return DeviceView(p.value, n.value, self)
+
+    def grad_tensor(self):
+        """torch tensor aliasing the flat gradient buffer in HBM (what RCCL all-reduces)."""
+        import torch
+        return torch.as_tensor(self.grad_view(), device=f"cuda:{torch.cuda.current_device()}")
 
     def synchronize(self):
         self._ck(lib().ntf_synchronize(self._h))
