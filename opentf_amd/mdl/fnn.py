@@ -1,0 +1,244 @@
+"""`Fnn`: the reference's feed-forward multilabel team-formation classifier (src/mdl/fnn.py:13-219) with its
+minibatch hot loop running on one or more MI355X through libopentf_amd.so.
+
+What stays on the host, mirroring the reference line by line: parameter initialisation (same torch CPU draws in
+the same order, so a given seed gives the reference's initial weights), the loader's batch order (same RNG
+consumption as `DataLoader(..., shuffle=True)`), fold / epoch / early-stop / LR-plateau control, checkpoint and
+prediction files (same keys, same layouts).  What moves to the GPU: everything inside `for batch` —
+densification (labels stay CSR), forward, negative sampling, weighted BCE, backward, Adam.
+
+There is no CPU path: `device` must name a GPU ('cuda', 'cuda:N' or 'cuda:0,1,...'); 'cpu' raises.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import re
+import time
+from collections import OrderedDict
+
+import numpy as np
+import scipy.sparse
+
+from .earlystopping import EarlyStopping, PlateauLR
+from .ntf import Ntf, cfg2str, cfg_get
+
+log = logging.getLogger(__name__)
+
+
+def parse_devices(device):
+    """'cuda' -> [0]; 'cuda:3' -> [3]; 'cuda:0,1,2' -> [0,1,2] (the list form src/mdl/nmt.py:70 already parses)."""
+    d = str(device)
+    if not d.startswith("cuda"):
+        raise RuntimeError(f"opentf_amd runs the fnn/bnn hot path on MI355X only; acceleration='{device}' has no implementation "
+                           f"(no CPU fallback). Use the reference's mdl.fnn.Fnn for CPU runs.")
+    if ":" not in d:
+        return [0]
+    return [int(x) for x in d.split(":", 1)[1].split(",") if x != ""]
+
+
+def index_order(n, batch_size, shuffle):
+    """Row positions in the order the reference's loader yields them (src/mdl/fnn.py:95-96,118), drawing from torch's
+    global CPU generator exactly as `DataLoader(dataset, batch_size, shuffle)` does (one base-seed draw per iterator,
+    one more for the RandomSampler permutation)."""
+    import torch
+    dl = torch.utils.data.DataLoader(torch.arange(n), batch_size=batch_size, shuffle=shuffle)
+    parts = [t for t in dl]
+    return torch.cat(parts).numpy() if parts else np.empty(0, np.int64)
+
+
+def make_fnn(base):
+    class Fnn(base):
+        # ---- model definition, src/mdl/fnn.py:15-30
+        def init(self, input_size, output_size):
+            """Fresh parameters with the reference's draws: nn.Linear default init per layer in construction order, then
+            xavier_uniform_ on every weight.  Returns (and keeps in self.model) the CPU state_dict."""
+            import torch
+            h = list(cfg_get(self.cfg, "h"))
+            dims = [int(input_size)] + [int(x) for x in h] + [int(output_size)]
+            layers = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
+            for m in layers:
+                torch.nn.init.xavier_uniform_(m.weight)
+            sd = OrderedDict()
+            for i, m in enumerate(layers):
+                sd[f"layers.{i}.weight"] = m.weight.detach().clone()
+                sd[f"layers.{i}.bias"] = m.bias.detach().clone()
+            self.model = sd
+            self._dims = dims
+            return self.model
+
+        # ---- engine plumbing
+        def _engine(self, teamsvecs, max_batch):
+            from .. import libntf
+            skill, member = teamsvecs["skill"], teamsvecs["member"]
+            n_in, n_out = skill.shape[1], member.shape[1]
+            h = [int(x) for x in cfg_get(self.cfg, "h")]
+            dims = [int(n_in)] + h + [int(n_out)]
+            table = teamsvecs.get("skill_table") if hasattr(teamsvecs, "get") else None
+            if table is not None:
+                mode, dims[0] = libntf.INPUT_MEANPOOL, int(np.asarray(table).shape[1])
+            elif scipy.sparse.issparse(skill):
+                mode = libntf.INPUT_MULTIHOT
+            else:
+                mode = libntf.INPUT_DENSE
+            devs = parse_devices(self.device)
+            import torch
+            self._rank, self._world = 0, 1
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                # one process per GPU (torchrun): rank r drives the r-th listed GPU, or GPU LOCAL_RANK when one is listed
+                self._rank, self._world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+                local = int(os.environ.get("LOCAL_RANK", self._rank))
+                devs = [devs[local % len(devs)] if len(devs) > 1 else local]
+            torch.cuda.set_device(devs[0])
+            # data parallel: engine kernels and the RCCL all-reduce must be ordered on ONE stream -> run both on a torch stream
+            self._stream = torch.cuda.Stream() if self._world > 1 else None
+            nsd = cfg_get(self.cfg, "nsd")
+            e = libntf.Engine(dims, bayesian=self.is_bayesian, input_mode=mode, max_batch=max_batch, ns=int(cfg_get(self.cfg, "ns", 0) or 0),
+                              nsd=nsd if nsd else None, tpw=float(cfg_get(self.cfg, "tpw", 1)), tnw=float(cfg_get(self.cfg, "tnw", 1)),
+                              lr=float(cfg_get(self.cfg, "lr")), seed=int(self.seed or 0), device=devs[0],
+                              stream=self._stream.cuda_stream if self._stream is not None else None)
+            if mode == libntf.INPUT_MEANPOOL:
+                src = teamsvecs.get("original_skill", skill)
+                e.set_skill_table(np.asarray(table, dtype=np.float32)); e.set_skill_csr(src)
+            elif mode == libntf.INPUT_MULTIHOT:
+                e.set_skill_csr(skill)
+            else:
+                e.set_dense_input(np.asarray(skill, dtype=np.float32))  # ndarray from D2v, np.matrix from Gnn (main.py:150)
+            e.set_member(member)
+            return e, dims
+
+        @staticmethod
+        def _to_torch(sd):
+            import torch
+            return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items())
+
+        # ---- training, src/mdl/fnn.py:78-170
+        def learn(self, teamsvecs, splits, prev_model):
+            import contextlib
+            import torch
+            engine, dims = self._engine(teamsvecs, int(cfg_get(self.cfg, "b")))
+            with (torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()):
+                self._learn(engine, dims, teamsvecs, splits, prev_model)
+
+        def _learn(self, engine, dims, teamsvecs, splits, prev_model):
+            import torch
+            member = teamsvecs["member"]
+            b, lr = int(cfg_get(self.cfg, "b")), float(cfg_get(self.cfg, "lr"))
+            spe = cfg_get(self.cfg, "spe")
+            if cfg_get(self.cfg, "nsd") == "unigram":  # frequency of each expert over ALL teams, float64 (fnn.py:82)
+                engine.set_unigram(np.asarray(member.sum(axis=0), dtype=np.float64).reshape(-1) / member.shape[0])
+
+            runner = engine
+            if self._world > 1:  # data parallel over the node's GPUs: global minibatch = cfg.b rows, split over ranks (dp.py)
+                from ..dp import DataParallel
+                runner = DataParallel(engine)
+            w = self.writer(log_dir=f"{self.output}/logs4tboard/run_{int(time.time())}")
+            for foldidx in splits["folds"].keys():
+                tr = np.asarray(splits["folds"][foldidx]["train"], dtype=np.int64)
+                va = np.asarray(splits["folds"][foldidx]["valid"], dtype=np.int64)
+                self.init(input_size=dims[0], output_size=dims[-1])
+                if prev_model:
+                    self.model = torch.load(prev_model[foldidx], map_location="cpu", weights_only=False)["model_state_dict"]
+                engine.load_state_dict(self.model)
+                engine.reset_optimizer()                       # fresh Adam(lr) per fold (fnn.py:104)
+                scheduler = PlateauLR(lr, factor=0.1, patience=2)
+                earlystopping = EarlyStopping(patience=int(cfg_get(self.cfg, "es")), verbose=True, delta=lr, trace_func=log.info)
+                e = -1
+                t_loss = v_loss = 0.0
+                for e in range(int(cfg_get(self.cfg, "e"))):
+                    t_loss = runner.train_epoch(tr[index_order(len(tr), b, True)], b)
+                    v_loss = runner.eval_epoch(va[index_order(len(va), b, False)], b)
+                    w.add_scalar(tag=f"{foldidx}_t_loss", scalar_value=t_loss, global_step=e)
+                    w.add_scalar(tag=f"{foldidx}_v_loss", scalar_value=v_loss, global_step=e)
+                    log.info(f"Fold {foldidx}/{len(splits['folds']) - 1}, Epoch {e}, Train Loss: {t_loss:.4f}")
+                    log.info(f"Fold {foldidx}/{len(splits['folds']) - 1}, Epoch {e}, Valid Loss: {v_loss:.4f}")
+                    if spe and (e == 0 or ((e + 1) % spe) == 0):
+                        self._save(engine, foldidx, e, t_loss, v_loss, f"{self.output}/f{foldidx}.e{e}.pt")
+                    engine.set_lr(scheduler.step(v_loss))
+                    if earlystopping(v_loss, None).early_stop:
+                        log.info(f"Early stopping triggered at epoch: {e}")
+                        break
+                self._save(engine, foldidx, e, t_loss, v_loss, f"{self.output}/f{foldidx}.pt")
+                log.info(f"{self.name()} model with {cfg2str(self.cfg)} saved at {self.output}/f{foldidx}.pt")
+            w.close()
+            engine.close()
+
+        def _save(self, engine, foldidx, e, t_loss, v_loss, path):
+            """Same keys and order as src/mdl/fnn.py:160,168; tensors are CPU f32 so `map_location` loads work anywhere."""
+            import torch
+            self.model = self._to_torch(engine.state_dict())
+            if getattr(self, "_rank", 0) != 0:
+                return  # every rank holds the same weights; rank 0 writes the files
+            torch.save({"model_state_dict": self.model, "cfg": self.cfg, "f": foldidx, "e": e, "t_loss": t_loss, "v_loss": v_loss}, path)
+
+        # ---- inference, src/mdl/fnn.py:172-219
+        def test(self, teamsvecs, splits, testcfg):
+            import torch
+            assert os.path.isdir(self.output), f"No folder for {self.output} exist!"
+            b = int(cfg_get(self.cfg, "b"))
+            engine, dims = self._engine(teamsvecs, b)
+            M = dims[-1]
+            topK = cfg_get(testcfg, "topK")
+            nmc = int(cfg_get(self.cfg, "nmc", 1) or 1)
+            for foldidx in splits["folds"].keys():
+                modelfiles = [f"{self.output}/f{foldidx}.pt"]
+                if cfg_get(testcfg, "per_epoch"):
+                    modelfiles += [f"{self.output}/{_}" for _ in os.listdir(self.output) if re.match(rf"f{foldidx}.e\d+.pt", _)]
+                for modelfile in sorted(sorted(modelfiles), key=len):
+                    self.model = torch.load(modelfile, map_location="cpu", weights_only=False)["model_state_dict"]
+                    engine.load_state_dict(self.model)
+                    for pred_set in (["test", "train", "valid"] if cfg_get(testcfg, "on_train") else ["test"]):
+                        rows = np.asarray(splits["test"] if pred_set == "test" else splits["folds"][foldidx][pred_set], dtype=np.int64)
+                        sparse_out = bool(topK) and topK < M
+                        on_gpu_topk = sparse_out and topK <= 2048
+                        dense, vals, idxs = [], [], []
+                        pred_uncertainty, model_uncertainty = [], []
+                        for o in range(0, len(rows), b):
+                            rr = rows[o:o + b]
+                            if self.is_bayesian:
+                                pred_uncertainty, model_uncertainty = [], []  # re-initialised per batch, as the reference does (fnn.py:203)
+                            if on_gpu_topk:
+                                out = engine.forward_topk(rr, int(topK), nmc=nmc, uncertainty=self.is_bayesian)
+                                vals.append(out[0]); idxs.append(out[1])
+                            else:
+                                out = engine.forward(rr, nmc=nmc, uncertainty=self.is_bayesian)
+                                dense.append(out[0] if self.is_bayesian else out)
+                            if self.is_bayesian:
+                                pred_uncertainty.append(out[-2]); model_uncertainty.append(out[-1])
+                        if on_gpu_topk:
+                            y_pred = self._coo_from_topk(np.concatenate(vals), np.concatenate(idxs), (len(rows), M))
+                        else:
+                            y_pred = torch.from_numpy(np.concatenate(dense)) if dense else torch.empty(0, M)
+                            if sparse_out:
+                                y_pred = self._topk_sparse(y_pred, int(topK))
+                        match = re.search(r"(e\d+)\.pt$", os.path.basename(modelfile))
+                        epoch = (match.group(1) + ".") if match else ""
+                        torch.save({"y_pred": y_pred, "uncertainty": {"pred": pred_uncertainty, "model": model_uncertainty} if self.is_bayesian else None},
+                                   f"{self.output}/f{foldidx}.{pred_set}.{epoch}pred", pickle_protocol=4)
+                        log.info(f"{self.name()} model predictions for fold{foldidx}.{pred_set}.{epoch} has saved at {self.output}/f{foldidx}.{pred_set}.{epoch}pred")
+            engine.close()
+
+        @staticmethod
+        def _topk_sparse(probs, k):
+            """src/pkgmgr.py:125-134"""
+            import torch
+            v, i = torch.topk(probs, k, dim=1)
+            rows = torch.arange(probs.shape[0]).unsqueeze(1).expand(-1, k)
+            return torch.sparse_coo_tensor(torch.stack([rows, i], dim=0).reshape(2, -1), v.reshape(-1), size=probs.shape).coalesce()
+
+        @staticmethod
+        def _coo_from_topk(vals, idx, shape):
+            """The coalesced COO tensor topk_sparse() returns (indices sorted by row, then column), from the GPU top-K."""
+            import torch
+            order = np.argsort(idx, axis=1, kind="stable")
+            idx_s = np.take_along_axis(idx, order, axis=1).astype(np.int64)
+            val_s = np.take_along_axis(vals, order, axis=1)
+            rows = np.repeat(np.arange(shape[0], dtype=np.int64), idx.shape[1])
+            ind = torch.from_numpy(np.stack([rows, idx_s.reshape(-1)]))
+            return torch.sparse_coo_tensor(ind, torch.from_numpy(val_s.reshape(-1)), size=shape, is_coalesced=True)
+
+    Fnn.__qualname__ = "Fnn"
+    return Fnn
+
+
+Fnn = make_fnn(Ntf)
