@@ -28,6 +28,7 @@ static const char* kFamNames[F_COUNT] = {"gather", "gemm_hidden", "flipout_opera
                                          "out_fused_fwd_loss_dh", "out_fused_dw_adam"};
 
 struct TimeRec { int fam; hipEvent_t a, b; };
+constexpr int64_t kGemmSlabFloats = 8 << 20;  // 32 MiB
 
 struct ntf_engine {
     ntf_config cfg{};
@@ -58,6 +59,7 @@ struct ntf_engine {
     float *partial = nullptr, *row_fix = nullptr, *d_loss = nullptr, *ent_mc = nullptr, *ent_mean = nullptr;
     float *dh_slab = nullptr;         // fused path: partial d(hidden) slabs
     char* fws = nullptr;              // fused path: sign-bit images, h*s_in, loss partials
+    float* gemm_slab = nullptr;       // split-K partial sums of the generic GEMM
     double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
     float* tk_vals = nullptr; int32_t* tk_idx = nullptr; int64_t tk_cap = 0;
     // injection staging (device)
@@ -173,13 +175,13 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     A(dmalloc(e, &e->d_rows, B)); A(dmalloc(e, &e->d_neg, (int64_t)B * std::max(1, cfg->ns)));
     e->act.assign(e->L, nullptr);
     for (int l = 0; l < e->L; ++l) A(dmalloc(e, &e->act[l], (int64_t)B * cfg->dims[l]));
-    A(dmalloc(e, &e->Zout, (int64_t)B * M)); A(dmalloc(e, &e->dZout, (int64_t)M * fused_ldb(B)));
+    A(dmalloc(e, &e->Zout, (int64_t)B * M)); A(dmalloc(e, &e->dZout, (int64_t)((M + 127) / 128 * 128) * fused_ldb(B)));
     if (e->maxhid) { A(dmalloc(e, &e->Zh, (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[0], (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[1], (int64_t)B * e->maxhid)); }
     e->Wp.assign(e->L, nullptr); e->bp.assign(e->L, nullptr);
     if (cfg->bayesian) for (int l = 0; l < e->L; ++l) { A(dmalloc(e, &e->Wp[l], e->layers[l].nw())); A(dmalloc(e, &e->bp[l], e->layers[l].out)); }
     A(dmalloc(e, &e->partial, (int64_t)B * std::max(loss_dense_nchunk(M), fused_loss_slots(M)))); A(dmalloc(e, &e->row_fix, B));
     A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 2)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
-    A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B));
+    A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B)); A(dmalloc(e, &e->gemm_slab, kGemmSlabFloats));
     if (rc == NTF_OK && fused_ok(e)) {
         A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
         A(dmalloc(e, &e->fws, (int64_t)fused_workspace_bytes(B, e->layers[e->L - 1].in, M)));
@@ -207,7 +209,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto& p : e->Wp) dfree(p);
     for (auto& p : e->bp) dfree(p);
     dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_acc); dfree(e->d_acc_steps);
-    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws); dfree(e->tk_vals); dfree(e->tk_idx);
+    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws); dfree(e->gemm_slab); dfree(e->tk_vals); dfree(e->tk_idx);
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
@@ -450,8 +452,11 @@ static int forward_layers(ntf_engine* e, const StepCtx& c, bool want_logits, boo
         float* W = e->P + li.off[NTF_P_WEIGHT]; float* b = e->P + li.off[NTF_P_BIAS];
         if (e->cfg.bayesian) {
             Scope t(e, F_FLIPOUT_OPERAND);
-            launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_WEIGHT], li.nw(), normal_spec(e, c, l, T_EPS_W), e->Wp[l]);
-            launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_BIAS], li.out, normal_spec(e, c, l, T_EPS_B), e->bp[l]);
+            const bool kl = !want_logits;  // loss steps: this layer's KL rides on the producer's pass over rho (and mu)
+            launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_WEIGHT], kl ? W : nullptr, li.nw(), normal_spec(e, c, l, T_EPS_W), e->Wp[l],
+                                   1.0 / (double)li.nw(), e->d_kl);
+            launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_BIAS], kl ? b : nullptr, li.out, normal_spec(e, c, l, T_EPS_B), e->bp[l],
+                                   1.0 / (double)li.out, e->d_kl);
         }
         Scope t(e, last ? F_OUT_FWD : F_GEMM_HIDDEN);
         GemmArgs g;
@@ -509,18 +514,6 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
     return upload_alias(e, w.data(), M);
 }
 
-static int kl_value(ntf_engine* e) {
-    if (!e->cfg.bayesian) return NTF_OK;
-    Scope t(e, F_KL);
-    HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 8, e->st));
-    for (int l = 0; l < e->L; ++l) {
-        const LayerInfo& li = e->layers[l];
-        launch_kl_value(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], li.nw(), 1.0 / (double)li.nw(), e->d_kl);
-        launch_kl_value(e->st, e->P + li.off[NTF_P_BIAS], e->P + li.off[NTF_P_RHO_BIAS], li.out, 1.0 / (double)li.out, e->d_kl);
-    }
-    return NTF_OK;
-}
-
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
 static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     int r;
@@ -530,7 +523,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const bool fused = fused_ok(e);
     if ((r = make_input(e, c))) return r;
     if ((r = sample_negatives(e, c))) return r;
-    if ((r = kl_value(e))) return r;
+    if (e->cfg.bayesian) HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 8, e->st));  // the Flipout operand producers add each layer's KL
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
     int nslots;
     if (fused) {
@@ -545,8 +538,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
         if (e->cfg.bayesian) {
             { Scope t(e, F_FLIPOUT_OPERAND);
-              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1]);
-              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1]); }
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
+                                     1.0 / (double)lo.nw(), e->d_kl);
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
+                                     1.0 / (double)lo.out, e->d_kl); }
             f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
             f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         }
@@ -597,6 +592,9 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                 g.A = dZ; g.sam = 1; g.sak = li.out;
                 g.B = in; g.sbk = li.in; g.sbn = 1;
                 g.C = gW; g.ldc = li.in;
+                const int wtiles = ((li.out + 63) / 64) * ((li.in + 63) / 64);
+                if (wtiles < 64 && B >= 256) { g.ksplit = std::max(1, std::min({16, B / 64, (int)(kGemmSlabFloats / ((int64_t)li.out * li.in))})); g.slab = e->gemm_slab; }
+                if (g.ksplit <= 1) { g.ksplit = 1; g.slab = nullptr; }
                 launch_gemm(e->st, g);
                 if (e->cfg.bayesian) { g.sa = sout_; g.sa_t = 1; g.sb = sin_; g.sb_t = 0; g.C = gRW; launch_gemm(e->st, g); }
             }
@@ -611,13 +609,12 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                 g.mask = e->act[l]; g.ldmask = li.in;
                 const int tiles = ((B + 63) / 64) * ((li.in + 63) / 64);
                 int ks = 1;
-                if (li.out >= 4096) ks = std::max(1, std::min(64, 1024 / tiles));
-                g.ksplit = ks;
-                if (ks > 1) HIPCHK(e, hipMemsetAsync(dA, 0, (size_t)B * li.in * 4, e->st));
+                if (li.out >= 4096) ks = std::max(1, std::min({64, 1024 / tiles, (int)(kGemmSlabFloats / ((int64_t)B * li.in))}));
+                g.ksplit = ks; g.slab = e->gemm_slab;
                 launch_gemm(e->st, g);
                 if (e->cfg.bayesian) {
                     g.B = e->Wp[l]; g.sa = sout_; g.sa_t = 0; g.sc = sin_;
-                    if (ks == 1) g.accumulate = 1;
+                    g.accumulate = 1;
                     launch_gemm(e->st, g);
                 }
             }

@@ -38,7 +38,7 @@ static Geom geom(int B, int M) {
 }
 int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)NCG_MAX * BM * H; }
 
-struct WsLayout { size_t sbits, sbitsT, sinbits, hs, lossp, total; };
+struct WsLayout { size_t sbits, sbitsT, sinbits, hs, hz, lossp, total; };
 static WsLayout ws_layout(int Bmax, int H, int M) {
     const int Bpad = rup(Bmax, BM), nCB = rup((M + 31) / 32, 2);
     WsLayout w; size_t o = 0;
@@ -47,6 +47,7 @@ static WsLayout ws_layout(int Bmax, int H, int M) {
     w.sbitsT = take((size_t)nCB * 32 * (Bpad / 32) * 4);
     w.sinbits = take((size_t)Bpad * (H / 32) * 4);
     w.hs = take((size_t)Bpad * H * 4);
+    w.hz = take((size_t)Bpad * H * 4);
     w.lossp = take((size_t)Bpad * NCG_MAX * 4);
     w.total = o;
     return w;
@@ -78,21 +79,24 @@ __global__ __launch_bounds__(64) void k_sign_bits(SignSpec so, int B, int M, int
     sbitsT[(int64_t)(cb * 32 + il) * (Bpad / 32) + ib] = tw;
 }
 
-__global__ void k_sin_bits(SignSpec si, const float* __restrict__ h, int B, int H, int Bpad, uint32_t* __restrict__ sinbits, float* __restrict__ hs) {
+// hz = h zero-padded to Bpad rows (so that DMA / MFMA never touch stale rows); Flipout: sinbits and hs = h * s_in
+__global__ void k_prep_h(SignSpec si, int bayes, const float* __restrict__ h, int B, int H, int Bpad, uint32_t* __restrict__ sinbits,
+                         float* __restrict__ hs, float* __restrict__ hz) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int wpr = H / 32;
     if (t >= Bpad * wpr) return;
     const int i = t / wpr, wj = t % wpr;
     uint32_t w = 0;
-    if (i < B) {
+    if (bayes && i < B) {
         if (si.inj) { for (int b = 0; b < 32; ++b) if (si.inj[(int64_t)i * si.ld + wj * 32 + b] < 0.f) w |= 1u << b; }
         else w = sign_word(si.k0, si.k1, (uint32_t)i, (uint32_t)wj);
     }
-    sinbits[t] = w;
+    if (bayes) sinbits[t] = w;
     for (int b = 0; b < 32; ++b) {
         const int j = wj * 32 + b;
         const float v = (i < B) ? h[(int64_t)i * H + j] : 0.f;
-        hs[(int64_t)i * H + j] = ((w >> b) & 1u) ? -v : v;
+        hz[(int64_t)i * H + j] = v;
+        if (bayes) hs[(int64_t)i * H + j] = ((w >> b) & 1u) ? -v : v;
     }
 }
 
@@ -103,15 +107,33 @@ __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// LDS-DMA issued from inline asm: hipcc then neither counts it nor fences later ds_reads behind it with vmcnt(0)
+// (which it does for the builtin, serialising the prefetch of tile t+1 with the compute on tile t).  The waits are
+// placed by hand: a counted s_waitcnt vmcnt(N) before the barrier that publishes the buffer.
+//   lds_dst = wave-uniform LDS byte address; lane l lands at lds_dst + l*size; gsrc = this lane's global source.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 struct OutFwdArgs {
     int B, M, Bpad, NRB, NCG, T, nCB;
     const float *h, *hs, *mu, *mu_b, *wp, *bp;
     const uint32_t *sbits, *sinbits;
+    uint32_t so_k0, so_k1, si_k0, si_k1;   // native sign generators; *_inj != 0: read the packed images instead (injected signs)
+    int so_inj, si_inj;
     float tnw, inv_B;
     float *dzT, *slab, *lossp;
 };
 
-template <int H, bool BAYES, bool TRAIN, bool DH>
+template <int H, bool BAYES, bool TRAIN, bool DH, bool INJ>
 __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = 4 * H;              // bytes per weight row
@@ -137,13 +159,16 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
 #pragma unroll
     for (int t = 0; t < H / 8; ++t) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row_ok) v = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 8 * t + 4 * half);
+        v = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 8 * t + 4 * half);  // p.h = zero-padded copy
         hf[4 * t] = v.x; hf[4 * t + 1] = v.y; hf[4 * t + 2] = v.z; hf[4 * t + 3] = v.w;
     }
     // s_in sign words of this row, pre-shifted so that bit (8t + e) & 31 of word (8t + e) >> 5 is the sign of k = 8t + 4*half + e
     uint32_t sinw[NJT];
 #pragma unroll
-    for (int w = 0; w < NJT; ++w) sinw[w] = BAYES ? (p.sinbits[(int64_t)i * NJT + w] >> (4 * half)) : 0u;
+    for (int w = 0; w < NJT; ++w)
+        sinw[w] = BAYES ? ((INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) >> (4 * half)) : 0u;
+    const float rmask = row_ok ? 1.f : 0.f;                 // padding rows of the last row block contribute nothing
+    const float rscale = row_ok ? p.tnw * p.inv_B : 0.f;
 
     // LDS byte offsets (relative to the stage base) that depend on the lane; everything else is an immediate.
     //   A fragment of zT: row u*32 + il, logical 16-byte chunk q = 2*tq + half, physical chunk q ^ swz(row)
@@ -155,13 +180,18 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
         if (H >= 64) aoff[k] = il * ROWB + 16 * (((2 * k + half) & 15) ^ (il & 15));
         else aoff[k] = il * ROWB + 16 * ((2 * k + half) ^ ((il >> 1) & 7));
     }
-    int boff[4];
+    // dh B operand: ONE wide read per (row, matrix) feeds all NJT column tiles: lane il owns hidden units j = NJT*il + jt,
+    // i.e. NJT consecutive floats of the weight row (b128 for H=128).  Row = u*32 + (s&3) + 8*(s>>2) + 4*half.
+    //   H >= 64: swz(row) = (s&3) + 4*half + 8*((s>>2)&1)  -> one offset per ((s&3), (s>>2)&1)
+    int boff[4][2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        // swz(row) for row = u*32 + (s&3) + 8*(s>>2) + 4*half
-        if (H >= 64) boff[k] = 4 * half * ROWB + 16 * (((il >> 2) ^ (k + 4 * half)) & 7) + 4 * (il & 3);
-        else boff[k] = 4 * half * ROWB + 16 * (il >> 2) + 4 * (il & 3);  // H == 32: resolved per (s) below
-    }
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b8 = 0; b8 < 2; ++b8) {
+            const int q = (NJT * il) >> 2;
+            if (H >= 64) boff[k][b8] = 4 * half * ROWB + 16 * (q ^ (k + 4 * half + 8 * b8)) + 4 * ((NJT * il) & 3);
+            else boff[k][b8] = 0;  // H == 32: computed per step (few registers at stake there)
+        }
 
     f32x16 Y1[NJT], Y2[NJT];
 #pragma unroll
@@ -170,129 +200,150 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
         for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
     float lsum = 0.f;
 
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto stage_tile = [&](int t, int buf) {
-        char* sb = smem + buf * STAGE;
+        const uint32_t sb = smem_base + buf * STAGE;
         const int c0 = t * BN;
         constexpr int PER_WAVE = TB / 4096;  // 1 KiB wave-instructions per wave per matrix
 #pragma unroll
         for (int n = 0; n < PER_WAVE; ++n) {
-            const int inst = wave * PER_WAVE + n;
+            const int inst = wave_u * PER_WAVE + n;
             const int off = inst * 1024 + lane * 16;
             const int row = off / ROWB, pch = (off % ROWB) >> 4;
             const int q = pch ^ swz<H>(row);
             const int64_t grow = min(c0 + row, p.M - 1);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.mu + grow * H + 4 * q), (lds_ptr_t)(sb + inst * 1024), 16, 0, 0);
-            if (BAYES)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.wp + grow * H + 4 * q), (lds_ptr_t)(sb + TB + inst * 1024), 16, 0, 0);
+            glds16(p.mu + grow * H + 4 * q, sb + inst * 1024);
+            if (BAYES) glds16(p.wp + grow * H + 4 * q, sb + TB + inst * 1024);
         }
-        if (wave == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.mu_b + min(c0 + lane, p.M - 1)), (lds_ptr_t)(sb + NMAT * TB), 4, 0, 0);
-        if (BAYES && wave == 1) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.bp + min(c0 + lane, p.M - 1)), (lds_ptr_t)(sb + NMAT * TB + 256), 4, 0, 0);
+        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TB);
+        if (BAYES && wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TB + 256);
     };
 
+    // s_out sign words of (row i, tile t) = words 2t, 2t+1 of the row: regenerated by the hash (no memory traffic inside the
+    // loop); only with injected signs (tests) are they fetched from the packed image.
+    auto sign_words = [&](int t) -> uint2 {
+        if (!BAYES || !row_ok) return make_uint2(0u, 0u);
+        if (INJ) return *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);  // injected signs (tests): packed image
+        return make_uint2(sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t)), sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t + 1)));
+    };
     if (t_beg < t_end) stage_tile(t_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = t_beg; t < t_end; ++t) {
         const int buf = (t - t_beg) & 1;
+        const uint2 w2 = sign_words(t);
         if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
-        const char* sb = smem + buf * STAGE;
+        char* sb = smem + buf * STAGE;
         const int c0 = t * BN;
+        if (c0 + BN > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
+            if (tid < BN && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TB)[tid] = -1e30f;
+            __syncthreads();
+        }
 
-        // ---- zT tile: rows = experts (two 32-row sub-tiles), cols = this wave's 32 batch rows
+        // ---- zT tile: rows = experts (two 32-row sub-tiles u), cols = this wave's 32 batch rows.
+        // Issue order (one basic block, software-interleaved so that the VALU epilogue runs under the MFMA pipe):
+        //   X(u=0) | X(u=1) with epilogue(u=0) spread over its k-steps | dh(u=0) with epilogue(u=1) spread | dh(u=1)
         f32x16 X1[2], X2[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { X1[u][r] = 0.f; X2[u][r] = 0.f; }
-#pragma unroll
-        for (int tq = 0; tq < H / 8; ++tq) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                // chunk q = 2*tq + half: low bits through aoff[], the bits above the swizzle width as an immediate
-                const int imm = u * 32 * ROWB + ((H >= 64) ? ((2 * tq) & ~15) * 16 : 0);
-                const char* ap = sb + aoff[tq % QM] + imm;
-                const float4 a = *reinterpret_cast<const float4*>(ap);
-                const float av[4] = {a.x, a.y, a.z, a.w};
-                float awv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (BAYES) { const float4 aw = *reinterpret_cast<const float4*>(ap + TB); awv[0] = aw.x; awv[1] = aw.y; awv[2] = aw.z; awv[3] = aw.w; }
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const int e = 4 * tq + e4;
-                    X1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e4], hf[e], X1[u], 0, 0, 0);
-                    if (BAYES) {
-                        const int kb = 8 * tq + e4;  // k without the lane half
-                        const uint32_t m = (sinw[kb >> 5] << (31 - (kb & 31))) & 0x80000000u;
-                        X2[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(awv[e4], __uint_as_float(__float_as_uint(hf[e]) ^ m), X2[u], 0, 0, 0);
-                    }
-                }
-            }
-        }
-
-        // ---- epilogue on the accumulator registers: lane = batch row i, register r <-> expert c0 + u*32 + rowmap(r, half)
         uint32_t sw[2] = {0u, 0u};
-        if (BAYES) {
-            const uint2 w2 = *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);
-            sw[0] = w2.x >> (4 * half); sw[1] = w2.y >> (4 * half);
-        }
+        if (BAYES) { sw[0] = w2.x >> (4 * half); sw[1] = w2.y >> (4 * half); }
         const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TB) + 4 * half;
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TB + 256) + 4 * half;
+
+        auto x_step = [&](int u, int tq) {   // 4 k-pairs of sub-tile u
+            const int imm = u * 32 * ROWB + ((H >= 64) ? ((2 * tq) & ~15) * 16 : 0);
+            const char* ap = sb + aoff[tq % QM] + imm;
+            const float4 a = *reinterpret_cast<const float4*>(ap);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            float awv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (BAYES) { const float4 aw = *reinterpret_cast<const float4*>(ap + TB); awv[0] = aw.x; awv[1] = aw.y; awv[2] = aw.z; awv[3] = aw.w; }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cr = u * 32 + (r & 3) + 8 * (r >> 2);  // + 4*half folded into the bias pointers / shifted sign word
-                const int c = c0 + cr + 4 * half;
-                float z = X1[u][r] + bias_mu[cr];
-                bool neg = false;
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * tq + e4;
+                X1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e4], hf[e], X1[u], 0, 0, 0);
                 if (BAYES) {
-                    neg = (sw[u] >> ((r & 3) + 8 * (r >> 2))) & 1u;
-                    const float x2 = X2[u][r] + bias_p[cr];
-                    z += neg ? -x2 : x2;
-                }
-                const bool valid = row_ok && (c < p.M);
-                const bool pos = z > 0.f;
-                const float l = pos ? z : z * kLeakySlope;
-                const float e = __expf(-fabsf(l));
-                const float tt = 1.f + e;
-                const float sp = fmaxf(l, 0.f) + __logf(tt);
-                lsum += valid ? sp : 0.f;
-                if (TRAIN) {
-                    const float inv = __frcp_rn(tt);
-                    const float sg = (l >= 0.f) ? inv : e * inv;
-                    const float dz = valid ? p.tnw * sg * (pos ? 1.f : kLeakySlope) * p.inv_B : 0.f;
-                    if (c < p.M) p.dzT[(int64_t)c * p.Bpad + i] = dz;
-                    X1[u][r] = dz;
-                    X2[u][r] = neg ? -dz : dz;
+                    const int kb = 8 * tq + e4;  // k without the lane half
+                    const uint32_t m = (sinw[kb >> 5] << (31 - (kb & 31))) & 0x80000000u;
+                    X2[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(awv[e4], __uint_as_float(__float_as_uint(hf[e]) ^ m), X2[u], 0, 0, 0);
                 }
             }
-        }
+        };
+        auto epilogue = [&](int u, int r) {  // lane = batch row i, register r <-> expert c0 + u*32 + rowmap(r, half)
+            const int cr = u * 32 + (r & 3) + 8 * (r >> 2);  // + 4*half folded into the bias pointers / shifted sign word
+            float z = X1[u][r] + bias_mu[cr];                // experts past M carry a -1e30 bias (patched below): sp = dz = 0 there
+            uint32_t sbit = 0u;
+            if (BAYES) {
+                sbit = (sw[u] << (31 - ((r & 3) + 8 * (r >> 2)))) & 0x80000000u;
+                z += __uint_as_float(__float_as_uint(X2[u][r] + bias_p[cr]) ^ sbit);
+            }
+            const bool pos = z > 0.f;
+            const float l = pos ? z : z * kLeakySlope;
+            const float e = __expf(-fabsf(l));
+            const float tt = 1.f + e;
+            lsum = fmaf(fmaxf(l, 0.f) + __logf(tt), rmask, lsum);
+            if (TRAIN) {
+                const float inv = __builtin_amdgcn_rcpf(tt);
+                const float sg = (l >= 0.f) ? inv : e * inv;
+                const float dz = rscale * sg * (pos ? 1.f : kLeakySlope);
+                p.dzT[(int64_t)(c0 + cr + 4 * half) * p.Bpad + i] = dz;  // dzT is padded to whole tiles: exactly 32 stores per lane per tile
+                X1[u][r] = dz;
+                X2[u][r] = __uint_as_float(__float_as_uint(dz) ^ sbit);
+            }
+        };
+        auto dh_step = [&](int u, int s) {   // dh += dz[:, c] * W[c, :] for c = u*32 + rowmap(s, half): A operand = accumulator register s
+            const int rowc = u * 32 + (s & 3) + 8 * (s >> 2);  // row without the lane half
+            const char* bp_;
+            if (H >= 64) bp_ = sb + boff[s & 3][(s >> 2) & 1] + rowc * ROWB;
+            else {
+                const int row = rowc + 4 * half;
+                bp_ = sb + row * ROWB + 16 * (((NJT * il) >> 2) ^ swz<H>(row)) + 4 * ((NJT * il) & 3);
+            }
+            float bv[NJT], bwv[NJT];
+            if (NJT == 4) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bp_); bv[0] = b4.x; bv[1] = b4.y; bv[NJT > 2 ? 2 : 0] = b4.z; bv[NJT > 3 ? 3 : 0] = b4.w;
+                if (BAYES) { const float4 w4 = *reinterpret_cast<const float4*>(bp_ + TB); bwv[0] = w4.x; bwv[1] = w4.y; bwv[NJT > 2 ? 2 : 0] = w4.z; bwv[NJT > 3 ? 3 : 0] = w4.w; }
+            } else if (NJT == 2) {
+                const float2 b2 = *reinterpret_cast<const float2*>(bp_); bv[0] = b2.x; bv[NJT > 1 ? 1 : 0] = b2.y;
+                if (BAYES) { const float2 w2_ = *reinterpret_cast<const float2*>(bp_ + TB); bwv[0] = w2_.x; bwv[NJT > 1 ? 1 : 0] = w2_.y; }
+            } else {
+                bv[0] = *reinterpret_cast<const float*>(bp_);
+                if (BAYES) bwv[0] = *reinterpret_cast<const float*>(bp_ + TB);
+            }
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                Y1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1[u][s], bv[jt], Y1[jt], 0, 0, 0);
+                if (BAYES) Y2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X2[u][s], bwv[jt], Y2[jt], 0, 0, 0);
+            }
+        };
 
-        // ---- dh += dz . mu_tile : A operand = the accumulator registers as they stand, B operand from the same LDS tile
+        constexpr int NTQ = H / 8, RPT = 16 / NTQ;  // epilogue registers handled per k-step of the other sub-tile
+#pragma unroll
+        for (int tq = 0; tq < NTQ; ++tq) x_step(0, tq);
+#pragma unroll
+        for (int tq = 0; tq < NTQ; ++tq) {
+            x_step(1, tq);
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) epilogue(0, tq * RPT + rr);
+        }
         if (TRAIN && DH) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int s2 = 0; s2 < 16; ++s2) { dh_step(0, s2); epilogue(1, s2); }
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int rowc = u * 32 + (s & 3) + 8 * (s >> 2);  // row without the lane half
+            for (int s2 = 0; s2 < 16; ++s2) dh_step(1, s2);
+        } else {
 #pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) {
-                        const char* bp_;
-                        if (H >= 64) {
-                            // chunk (8*jt + il>>2) ^ swz(row), swz(row) = (s&3) + 4*half + 8*((s>>2)&1): low 3 bits in boff[s&3]
-                            bp_ = sb + boff[s & 3] + rowc * ROWB + 16 * ((8 * jt) ^ (8 * ((s >> 2) & 1)));
-                        } else {
-                            // H == 32: 8 chunks per row, swz(row) = (row >> 1) & 7 with row = rowc + 4*half
-                            const int szc = ((rowc >> 1) & 7);  // the half adds 2 to (row >> 1): xor handled through the lane term below
-                            bp_ = sb + rowc * ROWB + 4 * half * ROWB + 16 * (((il >> 2) ^ ((szc + 2 * half) & 7))) + 4 * (il & 3);
-                        }
-                        Y1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1[u][s], *reinterpret_cast<const float*>(bp_), Y1[jt], 0, 0, 0);
-                        if (BAYES)
-                            Y2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X2[u][s], *reinterpret_cast<const float*>(bp_ + TB), Y2[jt], 0, 0, 0);
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r) epilogue(1, r);
         }
-        __syncthreads();  // next tile landed (vmcnt(0)) and nobody still reads this one
+        // The next tile's DMA was issued before this tile's 32 dzT stores: wait until at most those stores are outstanding
+        // (vmcnt counts loads, DMA and stores in issue order), not for the stores themselves, then a bare barrier.
+        if (TRAIN) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // per-row loss partial of this column group
@@ -303,16 +354,21 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int irow = i0 + rowmap(r, half);
+            float v[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
-                float v = Y1[jt][r];
+                const int j = NJT * il + jt;  // this lane's hidden units are consecutive: one 4*NJT-byte store per register
+                v[jt] = Y1[jt][r];
                 if (BAYES) {
-                    const uint32_t w = p.sinbits[(int64_t)irow * NJT + jt];
+                    const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + (j >> 5)] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)(j >> 5));
                     const float y2 = Y2[jt][r];
-                    v += ((w >> il) & 1u) ? -y2 : y2;
+                    v[jt] += ((w >> (j & 31)) & 1u) ? -y2 : y2;
                 }
-                p.slab[((int64_t)cg * p.Bpad + irow) * H + jt * 32 + il] = v;
             }
+            float* dst = p.slab + ((int64_t)cg * p.Bpad + irow) * H + NJT * il;
+            if (NJT == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[NJT > 2 ? 2 : 0], v[NJT > 3 ? 3 : 0]);
+            else if (NJT == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[NJT > 1 ? 1 : 0]);
+            else dst[0] = v[0];
         }
     }
 }
@@ -421,18 +477,18 @@ struct DwArgs {
 };
 
 template <int H, bool BAYES>
-__global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
+__global__ __launch_bounds__(256, 1) void k_out_dw(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NJT = H / 32;
     constexpr int KB = 32;                  // batch rows per K block
     constexpr int HROW = 4 * H;
-    __shared__ __attribute__((aligned(16))) char sA[128 * KB * 4];
-    __shared__ __attribute__((aligned(16))) char sH[KB * HROW];
-    __shared__ __attribute__((aligned(16))) char sHs[BAYES ? KB * HROW : 16];
+    constexpr int TA = 128 * KB * 4;        // dzT tile [128 experts][32 batch rows], 16-byte chunks XOR-swizzled
+    constexpr int TH = KB * HROW;           // h tile [32][H]
+    constexpr int STAGE = TA + (BAYES ? 2 : 1) * TH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
     const int c0 = blockIdx.x * 128;
     const int crow = wave * 32 + il;        // this lane's expert row inside the tile
     const int c = c0 + crow;
-    const int cclamp = min(c, p.M - 1);
     const int nib = p.Bpad / KB;
 
     f32x16 acc1[NJT], acc2[NJT];
@@ -442,34 +498,39 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
         for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
     float sum1 = 0.f, sum2 = 0.f;
 
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage = [&](int ib, int buf) {
+        const uint32_t sb = smem_base + buf * STAGE;
+#pragma unroll
+        for (int n = 0; n < TA / 4096; ++n) {      // 1 KiB wave-instructions: 8 expert rows x 128 B
+            const int inst = wave_u * (TA / 4096) + n;
+            const int row = inst * 8 + (lane >> 3), pch = lane & 7;
+            const int q = pch ^ ((row >> 1) & 7);
+            glds16(p.dzT + (int64_t)(c0 + row) * p.Bpad + ib * KB + 4 * q, sb + inst * 1024);
+        }
+#pragma unroll
+        for (int n = 0; n < TH / 4096; ++n) {
+            const int inst = wave_u * (TH / 4096) + n;
+            const int64_t goff = (int64_t)ib * KB * H + inst * 256 + lane * 4;  // h tile rows are contiguous in memory
+            glds16(p.h + goff, sb + TA + inst * 1024);
+            if (BAYES) glds16(p.hs + goff, sb + TA + TH + inst * 1024);
+        }
+    };
+
+    uint32_t word_next = 0;
+    const int cw = min(c, p.M - 1);  // sbitsT has rup(M, 64) rows, the tile may reach rup(M, 128)
+    if (BAYES) word_next = p.sbitsT[(int64_t)cw * (p.Bpad / 32)];
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int ib = 0; ib < nib; ++ib) {
-        // stage dzT tile [128 experts][32 batch rows] (16-byte chunks XOR-swizzled) and the h / h*s_in tiles [32][H]
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int ch = tid + 256 * n;
-            const int row = ch >> 3, q = ch & 7;
-            const int grow = min(c0 + row, p.M - 1);
-            const float4 v = *reinterpret_cast<const float4*>(p.dzT + (int64_t)grow * p.Bpad + ib * KB + 4 * q);
-            *reinterpret_cast<float4*>(sA + row * 128 + 16 * (q ^ ((row >> 1) & 7))) = v;
-        }
-#pragma unroll
-        for (int n = 0; n < (KB * H / 4 + 255) / 256; ++n) {
-            const int ch = tid + 256 * n;
-            if (ch < KB * H / 4) {
-                const int row = ch / (H / 4), q = ch % (H / 4);
-                const int gi = ib * KB + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f), vs = v;
-                if (gi < p.B) {
-                    v = *reinterpret_cast<const float4*>(p.h + (int64_t)gi * H + 4 * q);
-                    if (BAYES) vs = *reinterpret_cast<const float4*>(p.hs + (int64_t)gi * H + 4 * q);
-                }
-                *reinterpret_cast<float4*>(sH + row * HROW + 16 * q) = v;
-                if (BAYES) *reinterpret_cast<float4*>(sHs + row * HROW + 16 * q) = vs;
-            }
-        }
-        uint32_t word = 0;
-        if (BAYES) word = p.sbitsT[(int64_t)cclamp * (p.Bpad / 32) + ib] >> (4 * half);
-        __syncthreads();
+        const int buf = ib & 1;
+        const uint32_t word = word_next >> (4 * half);
+        if (BAYES && ib + 1 < nib) word_next = p.sbitsT[(int64_t)cw * (p.Bpad / 32) + ib + 1];
+        if (ib + 1 < nib) stage(ib + 1, buf ^ 1);
+        const char* sA = smem + buf * STAGE;
+        const char* sH = sA + TA;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int q = 2 * t + half;
@@ -482,16 +543,28 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
                 sum1 += a1;
                 float a2 = a1;
                 if (BAYES) { a2 = ((word >> kk) & 1u) ? -a1 : a1; sum2 += a2; }
-                const char* hb = sH + (kk + 4 * half) * HROW + 4 * il;
-                const char* hsb = sHs + (kk + 4 * half) * HROW + 4 * il;
+                // ONE wide read feeds all NJT column tiles: lane il owns hidden units j = NJT*il + jt
+                const char* hb = sH + (kk + 4 * half) * HROW + 4 * NJT * il;
+                float bv[NJT], bsv[NJT];
+                if (NJT == 4) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(hb); bv[0] = b4.x; bv[1] = b4.y; bv[NJT > 2 ? 2 : 0] = b4.z; bv[NJT > 3 ? 3 : 0] = b4.w;
+                    if (BAYES) { const float4 s4 = *reinterpret_cast<const float4*>(hb + TH); bsv[0] = s4.x; bsv[1] = s4.y; bsv[NJT > 2 ? 2 : 0] = s4.z; bsv[NJT > 3 ? 3 : 0] = s4.w; }
+                } else if (NJT == 2) {
+                    const float2 b2 = *reinterpret_cast<const float2*>(hb); bv[0] = b2.x; bv[NJT > 1 ? 1 : 0] = b2.y;
+                    if (BAYES) { const float2 s2 = *reinterpret_cast<const float2*>(hb + TH); bsv[0] = s2.x; bsv[NJT > 1 ? 1 : 0] = s2.y; }
+                } else {
+                    bv[0] = *reinterpret_cast<const float*>(hb);
+                    if (BAYES) bsv[0] = *reinterpret_cast<const float*>(hb + TH);
+                }
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt) {
-                    acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, *reinterpret_cast<const float*>(hb + 128 * jt), acc1[jt], 0, 0, 0);
-                    if (BAYES) acc2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, *reinterpret_cast<const float*>(hsb + 128 * jt), acc2[jt], 0, 0, 0);
+                    acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[jt], acc1[jt], 0, 0, 0);
+                    if (BAYES) acc2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bsv[jt], acc2[jt], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next K block landed (the DMA is invisible to hipcc's own counting)
+        __syncthreads();                                     // ... and this one is fully consumed
     }
 
     sum1 += __shfl_xor(sum1, 32, 64);
@@ -502,18 +575,21 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
     for (int r = 0; r < 16; ++r) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
         if (cr >= p.M) continue;
+        const int64_t idx0 = (int64_t)cr * H + NJT * il;  // NJT consecutive hidden units per lane: one wide access per array
+        float gm[NJT], gr[NJT];
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const int64_t idx = (int64_t)cr * H + jt * 32 + il;
-            if (!BAYES) { p.g_mu[idx] = acc1[jt][r]; }
+            if (!BAYES) { gm[jt] = acc1[jt][r]; gr[jt] = 0.f; }
             else {
-                const float m = p.mu[idx], rh = p.rho[idx], w = p.wp[idx];
+                const float m = p.mu[idx0 + jt], rh = p.rho[idx0 + jt], w = p.wp[idx0 + jt];
                 const float sigma = softplus_rho(rh);
                 const float sg = 1.f / (1.f + expf(-rh));
-                p.g_mu[idx] = acc1[jt][r] + p.klw * m;
-                p.g_rho[idx] = acc2[jt][r] * (w / sigma) * sg + p.klw * (sigma - 1.f / sigma) * sg;
+                gm[jt] = acc1[jt][r] + p.klw * m;
+                gr[jt] = acc2[jt][r] * (w / sigma) * sg + p.klw * (sigma - 1.f / sigma) * sg;
             }
         }
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) { p.g_mu[idx0 + jt] = gm[jt]; if (BAYES) p.g_rho[idx0 + jt] = gr[jt]; }
     }
 }
 
@@ -523,9 +599,10 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
     const size_t lds = 2 * STAGE;
     const bool dh = f.dh != nullptr;
+    const bool inj = BAYES && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
 #define NTF_LAUNCH_FWD(TR, DHF)                                                                                           \
     do {                                                                                                                  \
-        auto kf = k_out_fwd<H, BAYES, TR, DHF>;                                                                           \
+        auto kf = inj ? k_out_fwd<H, BAYES, TR, DHF, BAYES> : k_out_fwd<H, BAYES, TR, DHF, false>;                        \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);                                                        \
         hipLaunchKernelGGL((k_out_special<H, BAYES, TR, DHF>), dim3(f.B), dim3(64), 0, st, s);                            \
@@ -544,16 +621,20 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f) {
     uint32_t* sbitsT = reinterpret_cast<uint32_t*>(ws + w.sbitsT);
     uint32_t* sinbits = reinterpret_cast<uint32_t*>(ws + w.sinbits);
     float* hs = reinterpret_cast<float*>(ws + w.hs);
+    float* hz = reinterpret_cast<float*>(ws + w.hz);
     float* lossp = reinterpret_cast<float*>(ws + w.lossp);
     if (f.bayes) {
         hipLaunchKernelGGL(k_sign_bits, dim3(g.nCB / 2, g.Bpad / 32), dim3(64), 0, st, f.s_out, f.B, f.M, g.Bpad, g.nCB, sbits, sbitsT);
+    }
+    {
         const int n = g.Bpad * (f.H / 32);
-        hipLaunchKernelGGL(k_sin_bits, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.h, f.B, f.H, g.Bpad, sinbits, hs);
+        hipLaunchKernelGGL(k_prep_h, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.bayes, f.h, f.B, f.H, g.Bpad, sinbits, hs, hz);
     }
     OutFwdArgs a;
     a.B = f.B; a.M = f.M; a.Bpad = g.Bpad; a.NRB = g.NRB; a.NCG = g.NCG; a.T = g.T; a.nCB = g.nCB;
-    a.h = f.h; a.hs = hs; a.mu = f.mu; a.mu_b = f.mu_b; a.wp = f.wp; a.bp = f.bp; a.sbits = sbits; a.sinbits = sinbits;
+    a.h = hz; a.hs = hs; a.mu = f.mu; a.mu_b = f.mu_b; a.wp = f.wp; a.bp = f.bp; a.sbits = sbits; a.sinbits = sinbits;
     a.tnw = f.tnw; a.inv_B = f.inv_B; a.dzT = f.dzT; a.slab = f.dh_slab; a.lossp = lossp;
+    a.so_k0 = f.s_out.k0; a.so_k1 = f.s_out.k1; a.si_k0 = f.s_in.k0; a.si_k1 = f.s_in.k1; a.so_inj = f.s_out.inj != nullptr; a.si_inj = f.s_in.inj != nullptr;
     SpecialArgs s;
     s.B = f.B; s.M = f.M; s.Bpad = g.Bpad; s.NCG = g.NCG; s.nCB = g.nCB; s.ns = f.ns;
     s.h = f.h; s.hs = hs; s.mu = f.mu; s.mu_b = f.mu_b; s.wp = f.wp; s.bp = f.bp; s.slab = f.dh_slab; s.lossp = lossp; s.h_mask = f.h_mask;
@@ -570,12 +651,14 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     const WsLayout w = ws_layout(f.B, f.H, f.M);
     char* ws = static_cast<char*>(f.ws);
     DwArgs a;
-    a.B = f.B; a.M = f.M; a.Bpad = g.Bpad; a.dzT = f.dzT; a.h = f.h; a.hs = reinterpret_cast<const float*>(ws + w.hs);
+    a.B = f.B; a.M = f.M; a.Bpad = g.Bpad; a.dzT = f.dzT; a.h = reinterpret_cast<const float*>(ws + w.hz); a.hs = reinterpret_cast<const float*>(ws + w.hs);
     a.mu = f.mu; a.rho = f.rho; a.wp = f.wp; a.sbitsT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
     a.g_mu = f.g_mu; a.g_rho = f.g_rho; a.g_b = f.g_b; a.g_bp = f.g_bp; a.klw = f.klw;
     const int grid = (f.M + 127) / 128;
-#define NTF_DW(HH) do { if (f.bayes) hipLaunchKernelGGL((k_out_dw<HH, true>), dim3(grid), dim3(256), 0, st, a); \
-                        else hipLaunchKernelGGL((k_out_dw<HH, false>), dim3(grid), dim3(256), 0, st, a); } while (0)
+#define NTF_DW1(HH, BY) do { auto kf = k_out_dw<HH, BY>; const size_t lds = 2 * (128 * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a); } while (0)
+#define NTF_DW(HH) do { if (f.bayes) NTF_DW1(HH, true); else NTF_DW1(HH, false); } while (0)
     if (f.H == 128) NTF_DW(128); else if (f.H == 64) NTF_DW(64); else NTF_DW(32);
 #undef NTF_DW
 }

@@ -34,7 +34,8 @@ struct GemmArgs {
     SignSpec sc;                                // sign on the output at (m,n)
     const float* mask = nullptr; int64_t ldmask = 0; // value *= (mask[m,n] > 0 ? 1 : slope)
     int accumulate = 0;                         // value += C[m,n]
-    int ksplit = 1;                             // >1: atomicAdd partial sums into (pre-zeroed) C
+    int ksplit = 1;                             // >1: K split over blockIdx.z into `slab` [ksplit, M, N], summed in slice order
+    float* slab = nullptr;
     float alpha = 1.0f;
 };
 
@@ -47,7 +48,8 @@ void launch_densify_rows(hipStream_t st, const int64_t* indptr, const int32_t* i
                          int64_t n, int width, float* out);
 
 // Wp = softplus(rho) * eps  (eps generated or injected)
-void launch_flipout_perturb(hipStream_t st, const float* rho, int64_t n, NormalSpec eps, float* out);
+// also accumulates w * KL(N(mu, softplus(rho)^2) || N(0,1)) summed over the tensor into kl_out when mu != nullptr
+void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out);
 // g_rho = gWp * eps * sigmoid(rho) + kl' ; g_mu += kl'   (KL of N(mu, sigma^2) against N(0,1), mean over n, times klw)
 void launch_flipout_grad_finalize(hipStream_t st, const float* mu, const float* rho, float* g_mu, float* g_rho /*in: gWp*/,
                                   int64_t n, NormalSpec eps, float klw);

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
         if (a.sc.enabled) v *= sign_at(a.sc, row, col);
         if (a.mask) v *= (a.mask[(int64_t)row * a.ldmask + col] > 0.f) ? 1.f : kLeakySlope;
         if (a.ksplit > 1) {
-            atomicAdd(&a.C[(int64_t)row * a.ldc + col], v);
+            a.slab[((int64_t)blockIdx.z * a.M + row) * a.N + col] = v;  // partial sums; k_gemm_reduce adds them in slice order
         } else {
             if (a.accumulate) v += a.C[(int64_t)row * a.ldc + col];
             if (a.C) a.C[(int64_t)row * a.ldc + col] = v;
@@ -93,10 +93,23 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     }
 }
 
+__global__ void k_gemm_reduce(const float* __restrict__ slab, int ks, int64_t mn, int N, float* __restrict__ C, int64_t ldc, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= mn) return;
+    float s = 0.f;
+    for (int z = 0; z < ks; ++z) s += slab[(int64_t)z * mn + e];
+    const int64_t o = (e / N) * ldc + (e % N);
+    C[o] = accumulate ? C[o] + s : s;
+}
+
 void launch_gemm(hipStream_t st, const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0) return;
     dim3 grid((a.N + GBN - 1) / GBN, (a.M + GBM - 1) / GBM, a.ksplit > 1 ? a.ksplit : 1);
     hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, a);
+    if (a.ksplit > 1) {
+        const int64_t mn = (int64_t)a.M * a.N;
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, a.slab, a.ksplit, mn, a.N, a.C, a.ldc, a.accumulate);
+    }
 }
 
 // =====================================================================================
@@ -193,20 +206,46 @@ void launch_densify_rows(hipStream_t st, const int64_t* indptr, const int32_t* i
 // =====================================================================================
 // Flipout operand producer / gradient finaliser / KL  (bayesian-torch LinearFlipout + kl_div, restated)
 // =====================================================================================
-__global__ void k_flipout_perturb(const float* __restrict__ rho, int64_t n, NormalSpec eps, float* __restrict__ out) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // quad index
-    const int64_t e0 = q * 4;
-    if (e0 >= n) return;
-    float z[4];
-    normal4(eps, q, e0, n, z);
+// out = softplus(rho) * eps; when mu is given, also adds this tensor's KL(N(mu, sigma^2) || N(0,1)) * w to kl_out.
+// Grid-stride over quads with a bounded grid, so that the KL costs one double atomic per workgroup (<= 2048 in all).
+__global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict__ rho, const float* __restrict__ mu, int64_t n, NormalSpec eps,
+                                                         float* __restrict__ out, double w, double* kl_out) {
+    const int64_t quads = (n + 3) / 4;
+    float kl = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e0 = q * 4;
+        float z[4];
+        normal4(eps, q, e0, n, z);
+        if (e0 + 3 < n) {
+            const float4 r4 = *reinterpret_cast<const float4*>(rho + e0);
+            const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
+            float ov[4], mv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + e0); mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (e0 + j < n) out[e0 + j] = softplus_rho(rho[e0 + j]) * z[j];
+            for (int j = 0; j < 4; ++j) {
+                const float sigma = softplus_rho(rv[j]);
+                ov[j] = sigma * z[j];
+                if (mu) kl += -logf(sigma) + 0.5f * (sigma * sigma + mv[j] * mv[j]) - 0.5f;
+            }
+            *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        } else {
+            for (int j = 0; j < 4 && e0 + j < n; ++j) {
+                const float sigma = softplus_rho(rho[e0 + j]);
+                out[e0 + j] = sigma * z[j];
+                if (mu) { const float m = mu[e0 + j]; kl += -logf(sigma) + 0.5f * (sigma * sigma + m * m) - 0.5f; }
+            }
+        }
+    }
+    if (mu) {
+        const double s = block_reduce_sum_d((double)kl);
+        if (threadIdx.x == 0) atomicAdd(kl_out, s * w);
+    }
 }
-void launch_flipout_perturb(hipStream_t st, const float* rho, int64_t n, NormalSpec eps, float* out) {
+void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out) {
     if (n <= 0) return;
     const int64_t quads = (n + 3) / 4;
-    hipLaunchKernelGGL(k_flipout_perturb, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rho, n, eps, out);
+    const int blocks = (int)std::min<int64_t>((quads + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out);
 }
 
 __global__ void k_flipout_grad_finalize(const float* __restrict__ mu, const float* __restrict__ rho, float* __restrict__ g_mu,
@@ -348,8 +387,23 @@ __global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dZ,
     g_b[n] = s1;
     if (g_pert) g_pert[n] = s2;
 }
+// narrow layers (hidden): one wave per column, lanes stride over the batch rows, fixed-order shuffle reduction
+__global__ __launch_bounds__(256) void k_bias_grad_wave(const float* __restrict__ dZ, int64_t ld, int B, int N, SignSpec sout,
+                                                        float* __restrict__ g_b, float* __restrict__ g_pert) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = lane; b < B; b += 64) {
+        const float v = dZ[(int64_t)b * ld + n];
+        s1 += v;
+        if (g_pert) s2 += v * sign_at(sout, b, n);
+    }
+    s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2);
+    if (lane == 0) { g_b[n] = s1; if (g_pert) g_pert[n] = s2; }
+}
 void launch_bias_grad(hipStream_t st, const float* dZ, int64_t ld, int B, int N, SignSpec sout, float* g_b, float* g_pert) {
-    hipLaunchKernelGGL(k_bias_grad, dim3((N + 255) / 256), dim3(256), 0, st, dZ, ld, B, N, sout, g_b, g_pert);
+    if (N <= 4096) hipLaunchKernelGGL(k_bias_grad_wave, dim3((N + 3) / 4), dim3(256), 0, st, dZ, ld, B, N, sout, g_b, g_pert);
+    else hipLaunchKernelGGL(k_bias_grad, dim3((N + 255) / 256), dim3(256), 0, st, dZ, ld, B, N, sout, g_b, g_pert);
 }
 
 // =====================================================================================
