@@ -477,7 +477,7 @@ struct DwArgs {
 };
 
 template <int H, bool BAYES>
-__global__ __launch_bounds__(256, 1) void k_out_dw(DwArgs p) {
+__global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NJT = H / 32;
     constexpr int KB = 32;                  // batch rows per K block
@@ -521,14 +521,14 @@ __global__ __launch_bounds__(256, 1) void k_out_dw(DwArgs p) {
     uint32_t word_next = 0;
     const int cw = min(c, p.M - 1);  // sbitsT has rup(M, 64) rows, the tile may reach rup(M, 128)
     if (BAYES) word_next = p.sbitsT[(int64_t)cw * (p.Bpad / 32)];
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // single LDS stage, two workgroups per CU: while one waits for its DMA the other one owns the MFMA pipe
     for (int ib = 0; ib < nib; ++ib) {
-        const int buf = ib & 1;
+        const int buf = 0;
+        stage(ib, 0);
         const uint32_t word = word_next >> (4 * half);
         if (BAYES && ib + 1 < nib) word_next = p.sbitsT[(int64_t)cw * (p.Bpad / 32) + ib + 1];
-        if (ib + 1 < nib) stage(ib + 1, buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         const char* sA = smem + buf * STAGE;
         const char* sH = sA + TA;
 #pragma unroll
@@ -563,8 +563,7 @@ __global__ __launch_bounds__(256, 1) void k_out_dw(DwArgs p) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next K block landed (the DMA is invisible to hipcc's own counting)
-        __syncthreads();                                     // ... and this one is fully consumed
+        __syncthreads();  // everyone is done with the tile before the next DMA overwrites it
     }
 
     sum1 += __shfl_xor(sum1, 32, 64);
@@ -655,7 +654,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.mu = f.mu; a.rho = f.rho; a.wp = f.wp; a.sbitsT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
     a.g_mu = f.g_mu; a.g_rho = f.g_rho; a.g_b = f.g_b; a.g_bp = f.g_bp; a.klw = f.klw;
     const int grid = (f.M + 127) / 128;
-#define NTF_DW1(HH, BY) do { auto kf = k_out_dw<HH, BY>; const size_t lds = 2 * (128 * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
+#define NTF_DW1(HH, BY) do { auto kf = k_out_dw<HH, BY>; const size_t lds = 1 * (128 * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a); } while (0)
 #define NTF_DW(HH) do { if (f.bayes) NTF_DW1(HH, true); else NTF_DW1(HH, false); } while (0)
