@@ -72,6 +72,7 @@ struct ntf_engine {
     std::vector<hipEvent_t> pool;
     double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
     int last_global_B = 0; int last_B = 0;
+    bool adam_in_dw = false;          // this step's output-layer Adam already ran inside the dW kernel
 };
 
 #define HIPCHK(e, call)                                                                                   \
@@ -363,6 +364,7 @@ struct StepCtx {
     const ntf_inject* inj = nullptr;
     uint64_t step = 0;
     bool train = false;
+    bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
 };
 
 static int stage_rows(ntf_engine* e, const int64_t* rows, int B, bool rows_on_device, const int64_t** dev) {
@@ -580,7 +582,17 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.B = B; f.H = li.in; f.M = M; f.bayes = e->cfg.bayesian;
             f.dzT = e->dZout; f.h = in; f.g_mu = gW; f.g_rho = gRW; f.g_b = gb; f.g_bp = gRb; f.ws = e->fws;
             f.mu = e->P + li.off[NTF_P_WEIGHT];
+            f.s_out = sout_; f.s_out_inj = e->cfg.bayesian && (sout_.inj != nullptr || sin_.inj != nullptr);
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
+            if (c.fuse_adam) {
+                const double b1 = 0.9, b2 = 0.999;
+                const double tt = (double)(e->adam_t + 1);
+                const double bc1 = 1.0 - std::pow(b1, tt), bc2 = 1.0 - std::pow(b2, tt);
+                f.adam = 1; f.lr_over_bc1 = e->lr / (float)bc1; f.b1 = (float)b1; f.b2 = (float)b2; f.eps = 1e-8f; f.bc2_sqrt = (float)std::sqrt(bc2);
+                f.w_mu = e->P + li.off[NTF_P_WEIGHT]; f.m_mu = e->M1 + li.off[NTF_P_WEIGHT]; f.v_mu = e->V2 + li.off[NTF_P_WEIGHT];
+                if (e->cfg.bayesian) { f.w_rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.m_rho = e->M1 + li.off[NTF_P_RHO_WEIGHT]; f.v_rho = e->V2 + li.off[NTF_P_RHO_WEIGHT]; }
+                e->adam_in_dw = true;
+            }
             Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f);
         } else {
             const float* dZ = last ? e->dZout : e->dAct[(l + 1) & 1];
@@ -636,7 +648,17 @@ static int apply_adam(ntf_engine* e) {
     e->adam_t += 1;
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - std::pow(b1, (double)e->adam_t), bc2 = 1.0 - std::pow(b2, (double)e->adam_t);
-    launch_adam(e->st, e->P, e->G, e->M1, e->V2, e->n_params, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
+    auto run = [&](int64_t lo, int64_t hi) {
+        if (hi > lo) launch_adam(e->st, e->P + lo, e->G + lo, e->M1 + lo, e->V2 + lo, hi - lo, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
+    };
+    if (!e->adam_in_dw) { run(0, e->n_params); return NTF_OK; }
+    // the output layer's weight (and rho_weight) segments were updated inside the dW kernel: run over the rest
+    e->adam_in_dw = false;
+    const LayerInfo& lo = e->layers[e->L - 1];
+    const int64_t w0 = lo.off[NTF_P_WEIGHT], w1 = lo.off[NTF_P_BIAS];  // segments are laid out weight, bias, rho_weight, rho_bias
+    run(0, w0);
+    if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS]; run(w1, r0); run(r1, e->n_params); }
+    else run(w1, e->n_params);
     return NTF_OK;
 }
 
@@ -655,6 +677,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     if ((r = check_ready(e, true))) return r;
     if (global_B < B) FAIL(e, NTF_EINVAL, "global_B < B");
     StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
+    c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
     if ((r = stage_rows(e, rows, B, rows_on_device, &c.rows_dev))) return r;
     if ((r = stage_all_inj(e, c))) return r;
     if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && !(inj && inj->neg_idx)) {

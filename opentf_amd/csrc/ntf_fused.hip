@@ -58,25 +58,16 @@ size_t fused_workspace_bytes(int B, int H, int M) { return ws_layout(B, H, M).to
 // sign bit images: sbits[i][cb] (bit c&31 of word cb = c>>5), its 32x32-block transpose sbitsT[c][i>>5],
 // sinbits[i][j>>5] and hs = h * s_in
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sign_bits(SignSpec so, int B, int M, int Bpad, int nCB, uint32_t* __restrict__ sbits,
-                                                  uint32_t* __restrict__ sbitsT) {
-    const int lane = threadIdx.x, il = lane & 31, half = lane >> 5;
-    const int cb = 2 * blockIdx.x + half, ib = blockIdx.y;
-    const int i = ib * 32 + il;
+__global__ __launch_bounds__(64) void k_sign_bits(SignSpec so, int B, int M, int nCB, uint32_t* __restrict__ sbits) {
+    // packed row image sbits[i][cb] of an INJECTED sign tensor (tests); native runs regenerate the words by hash in the kernels
+    const int cb = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y;
+    if (cb >= nCB) return;
     uint32_t w = 0;
     if (i < B) {
-        if (so.inj) {
-            for (int b = 0; b < 32; ++b) { const int c = cb * 32 + b; if (c < M && so.inj[(int64_t)i * so.ld + c] < 0.f) w |= 1u << b; }
-        } else w = sign_word(so.k0, so.k1, (uint32_t)i, (uint32_t)cb);
+        if (so.inj) { for (int b = 0; b < 32; ++b) { const int c = cb * 32 + b; if (c < M && so.inj[(int64_t)i * so.ld + c] < 0.f) w |= 1u << b; } }
+        else w = sign_word(so.k0, so.k1, (uint32_t)i, (uint32_t)cb);
     }
     sbits[(int64_t)i * nCB + cb] = w;
-    uint32_t tw = 0;
-    for (int b = 0; b < 32; ++b) {
-        const unsigned long long bal = __ballot((w >> b) & 1u);
-        const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-        if (il == b) tw = mine;
-    }
-    sbitsT[(int64_t)(cb * 32 + il) * (Bpad / 32) + ib] = tw;
 }
 
 // hz = h zero-padded to Bpad rows (so that DMA / MFMA never touch stale rows); Flipout: sinbits and hs = h * s_in
@@ -381,6 +372,7 @@ struct SpecialArgs {
     const int64_t *rows, *m_indptr, *neg; const int32_t* m_indices;
     float tpw, tnw, inv_B;
     float *dzT, *dh, *row_fix;
+    uint32_t so_k0, so_k1; int so_inj;
 };
 
 template <int H, bool BAYES, bool TRAIN, bool DH>
@@ -427,7 +419,8 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
         float so = 1.f;
         if (BAYES) {
             d2 = wave_reduce_sum(d2);
-            so = ((p.sbits[(int64_t)i * p.nCB + (c >> 5)] >> (c & 31)) & 1u) ? -1.f : 1.f;
+            const uint32_t sw_ = p.so_inj ? p.sbits[(int64_t)i * p.nCB + (c >> 5)] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(c >> 5));
+            so = ((sw_ >> (c & 31)) & 1u) ? -1.f : 1.f;
             z += (d2 + p.bp[c]) * so;
         }
         float sp, sg, dact;
@@ -470,14 +463,40 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct DwArgs {
     int B, M, Bpad;
-    const float *dzT, *h, *hs, *mu, *rho, *wp;
-    const uint32_t* sbitsT;
-    float *g_mu, *g_rho, *g_b, *g_bp;
+    const float *__restrict__ dzT, *__restrict__ h, *__restrict__ hs, *__restrict__ mu, *__restrict__ rho, *__restrict__ wp;
+    const uint32_t* sbits; int nCB; uint32_t so_k0, so_k1; int so_inj;   // s_out signs: packed row image (injected) or hash keys
+    float *__restrict__ g_mu, *__restrict__ g_rho, *__restrict__ g_b, *__restrict__ g_bp;
     float klw;
+    // fused Adam (single GPU): update mu / rho and their moments in the epilogue instead of writing the gradients
+    float *__restrict__ w_mu, *__restrict__ w_rho, *__restrict__ m_mu, *__restrict__ v_mu, *__restrict__ m_rho, *__restrict__ v_rho;
+    float lr_over_bc1, b1, b2, eps, bc2_sqrt;
 };
 
-template <int H, bool BAYES>
-__global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+    m = m + (1.f - b1) * (g - m);
+    v = v * b2 + (1.f - b2) * g * g;
+    return p - lr_over_bc1 * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+
+// 32x32 bit-matrix transpose across the 32 lanes of a half-wave (lane l holds row l): five butterfly stages of masked
+// swaps with the lane l ^ j.  Afterwards lane l holds column l (bit k = old row k).
+__device__ __forceinline__ uint32_t transpose32(uint32_t a, int il) {
+    uint32_t m = 0x0000FFFFu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1) {
+        const uint32_t pv = (uint32_t)__shfl_xor((int)a, j, 64);
+        const bool lower = (il & j) == 0;
+        // bit index = column (LSB first): swap the lower lane's bits with (bit & j) set against the upper lane's bits without
+        const uint32_t lo = lower ? a : pv, hi = lower ? pv : a;
+        const uint32_t t = ((lo >> j) ^ hi) & m;
+        a ^= lower ? (t << j) : t;
+        m ^= m << (j >> 1);
+    }
+    return a;
+}
+
+template <int H, bool BAYES, bool ADAM>
+__global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NJT = H / 32;
     constexpr int KB = 32;                  // batch rows per K block
@@ -518,15 +537,25 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
         }
     };
 
+    // s_out sign bits of (32 batch rows of the K block) x (this wave's 32 experts): lane il produces the row word of batch row
+    // ib*32 + il for the wave's column block (one hash, or one load from the injected image), then a 32x32 bit transpose
+    // across lanes leaves lane il with the word of ITS expert (bit k = batch row ib*32 + k).
+    const uint32_t cb = (uint32_t)((c0 + wave * 32) >> 5);
+    auto sign_col_word = [&](int ib) -> uint32_t {
+        const int i = ib * KB + il;
+        uint32_t w = 0u;
+        if (p.so_inj) { if ((int)cb < p.nCB) w = p.sbits[(int64_t)i * p.nCB + cb]; }
+        else w = sign_word(p.so_k0, p.so_k1, (uint32_t)i, cb);
+        return transpose32(w, il);
+    };
     uint32_t word_next = 0;
-    const int cw = min(c, p.M - 1);  // sbitsT has rup(M, 64) rows, the tile may reach rup(M, 128)
-    if (BAYES) word_next = p.sbitsT[(int64_t)cw * (p.Bpad / 32)];
+    if (BAYES) word_next = sign_col_word(0);
     // single LDS stage, two workgroups per CU: while one waits for its DMA the other one owns the MFMA pipe
     for (int ib = 0; ib < nib; ++ib) {
         const int buf = 0;
         stage(ib, 0);
         const uint32_t word = word_next >> (4 * half);
-        if (BAYES && ib + 1 < nib) word_next = p.sbitsT[(int64_t)cw * (p.Bpad / 32) + ib + 1];
+        if (BAYES && ib + 1 < nib) word_next = sign_col_word(ib + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const char* sA = smem + buf * STAGE;
@@ -575,20 +604,36 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
         if (cr >= p.M) continue;
         const int64_t idx0 = (int64_t)cr * H + NJT * il;  // NJT consecutive hidden units per lane: one wide access per array
-        float gm[NJT], gr[NJT];
+        float gm[NJT], gr[NJT], pm[NJT], pr[NJT];
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            if (!BAYES) { gm[jt] = acc1[jt][r]; gr[jt] = 0.f; }
+            pm[jt] = ADAM ? p.w_mu[idx0 + jt] : (BAYES ? p.mu[idx0 + jt] : 0.f);
+            if (!BAYES) { gm[jt] = acc1[jt][r]; gr[jt] = 0.f; pr[jt] = 0.f; }
             else {
-                const float m = p.mu[idx0 + jt], rh = p.rho[idx0 + jt], w = p.wp[idx0 + jt];
+                const float rh = ADAM ? p.w_rho[idx0 + jt] : p.rho[idx0 + jt], w = p.wp[idx0 + jt];
+                pr[jt] = rh;
                 const float sigma = softplus_rho(rh);
                 const float sg = 1.f / (1.f + expf(-rh));
-                gm[jt] = acc1[jt][r] + p.klw * m;
+                gm[jt] = acc1[jt][r] + p.klw * pm[jt];
                 gr[jt] = acc2[jt][r] * (w / sigma) * sg + p.klw * (sigma - 1.f / sigma) * sg;
             }
         }
+        if (!ADAM) {
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) { p.g_mu[idx0 + jt] = gm[jt]; if (BAYES) p.g_rho[idx0 + jt] = gr[jt]; }
+            for (int jt = 0; jt < NJT; ++jt) { p.g_mu[idx0 + jt] = gm[jt]; if (BAYES) p.g_rho[idx0 + jt] = gr[jt]; }
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                float m = p.m_mu[idx0 + jt], v = p.v_mu[idx0 + jt];
+                p.w_mu[idx0 + jt] = adam_update(pm[jt], gm[jt], m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                p.m_mu[idx0 + jt] = m; p.v_mu[idx0 + jt] = v;
+                if (BAYES) {
+                    float m2 = p.m_rho[idx0 + jt], v2 = p.v_rho[idx0 + jt];
+                    p.w_rho[idx0 + jt] = adam_update(pr[jt], gr[jt], m2, v2, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                    p.m_rho[idx0 + jt] = m2; p.v_rho[idx0 + jt] = v2;
+                }
+            }
+        }
     }
 }
 
@@ -598,7 +643,7 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
     const size_t lds = 2 * STAGE;
     const bool dh = f.dh != nullptr;
-    const bool inj = BAYES && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
+    const bool inj = BAYES && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);  // packed images instead of the hash
 #define NTF_LAUNCH_FWD(TR, DHF)                                                                                           \
     do {                                                                                                                  \
         auto kf = inj ? k_out_fwd<H, BAYES, TR, DHF, BAYES> : k_out_fwd<H, BAYES, TR, DHF, false>;                        \
@@ -617,14 +662,12 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f) {
     const WsLayout w = ws_layout(f.B, f.H, f.M);
     char* ws = static_cast<char*>(f.ws);
     uint32_t* sbits = reinterpret_cast<uint32_t*>(ws + w.sbits);
-    uint32_t* sbitsT = reinterpret_cast<uint32_t*>(ws + w.sbitsT);
     uint32_t* sinbits = reinterpret_cast<uint32_t*>(ws + w.sinbits);
     float* hs = reinterpret_cast<float*>(ws + w.hs);
     float* hz = reinterpret_cast<float*>(ws + w.hz);
     float* lossp = reinterpret_cast<float*>(ws + w.lossp);
-    if (f.bayes) {
-        hipLaunchKernelGGL(k_sign_bits, dim3(g.nCB / 2, g.Bpad / 32), dim3(64), 0, st, f.s_out, f.B, f.M, g.Bpad, g.nCB, sbits, sbitsT);
-    }
+    const bool inj = f.bayes && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
+    if (inj) hipLaunchKernelGGL(k_sign_bits, dim3((g.nCB + 63) / 64, g.Bpad), dim3(64), 0, st, f.s_out, f.B, f.M, g.nCB, sbits);
     {
         const int n = g.Bpad * (f.H / 32);
         hipLaunchKernelGGL(k_prep_h, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.bayes, f.h, f.B, f.H, g.Bpad, sinbits, hs, hz);
@@ -639,6 +682,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f) {
     s.h = f.h; s.hs = hs; s.mu = f.mu; s.mu_b = f.mu_b; s.wp = f.wp; s.bp = f.bp; s.slab = f.dh_slab; s.lossp = lossp; s.h_mask = f.h_mask;
     s.sbits = sbits; s.sinbits = sinbits; s.rows = f.rows; s.m_indptr = f.m_indptr; s.neg = f.neg; s.m_indices = f.m_indices;
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
+    s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     const int grid = g.NRB * g.NCG;
 #define NTF_H(HH) do { if (f.bayes) fwd_dispatch<HH, true>(st, f, a, s, grid); else fwd_dispatch<HH, false>(st, f, a, s, grid); } while (0)
     if (f.H == 128) NTF_H(128); else if (f.H == 64) NTF_H(64); else NTF_H(32);
@@ -651,10 +695,13 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     char* ws = static_cast<char*>(f.ws);
     DwArgs a;
     a.B = f.B; a.M = f.M; a.Bpad = g.Bpad; a.dzT = f.dzT; a.h = reinterpret_cast<const float*>(ws + w.hz); a.hs = reinterpret_cast<const float*>(ws + w.hs);
-    a.mu = f.mu; a.rho = f.rho; a.wp = f.wp; a.sbitsT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
+    a.mu = f.mu; a.rho = f.rho; a.wp = f.wp; a.sbits = reinterpret_cast<const uint32_t*>(ws + w.sbits); a.nCB = g.nCB;
+    a.so_k0 = f.s_out.k0; a.so_k1 = f.s_out.k1; a.so_inj = f.s_out_inj;
     a.g_mu = f.g_mu; a.g_rho = f.g_rho; a.g_b = f.g_b; a.g_bp = f.g_bp; a.klw = f.klw;
+    a.w_mu = f.w_mu; a.w_rho = f.w_rho; a.m_mu = f.m_mu; a.v_mu = f.v_mu; a.m_rho = f.m_rho; a.v_rho = f.v_rho;
+    a.lr_over_bc1 = f.lr_over_bc1; a.b1 = f.b1; a.b2 = f.b2; a.eps = f.eps; a.bc2_sqrt = f.bc2_sqrt;
     const int grid = (f.M + 127) / 128;
-#define NTF_DW1(HH, BY) do { auto kf = k_out_dw<HH, BY>; const size_t lds = 1 * (128 * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
+#define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 1 * (128 * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a); } while (0)
 #define NTF_DW(HH) do { if (f.bayes) NTF_DW1(HH, true); else NTF_DW1(HH, false); } while (0)

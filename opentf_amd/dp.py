@@ -11,6 +11,8 @@ what lets the world_size-2 gloo tests drive this logic on CPU with a stand-in en
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -30,6 +32,8 @@ class DataParallel:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._grad = engine.grad_tensor()  # flat view of the engine's gradient buffer (HBM; aliases, no copy)
+        # NTF_DP_FORCE_ALLREDUCE=1: run the collective even at world_size 1 (exercises RCCL on the aliased buffer on a 1-GPU box)
+        self.force_allreduce = dist.is_initialized() and os.environ.get("NTF_DP_FORCE_ALLREDUCE", "0") == "1"
 
     def _phase(self, order, global_B, train):
         """One `for batch in loader` phase (src/mdl/fnn.py:118) over `order`; returns the mean batch loss."""
@@ -41,12 +45,17 @@ class DataParallel:
         for goff in range(0, n, global_B):
             gB = min(global_B, n - goff)
             lo, hi = shard_bounds(gB, self.world, self.rank)
+            if self.world == 1 and not self.force_allreduce:
+                # one GPU: backward and Adam in one call (lets the engine fuse the output layer's Adam into its dW kernel)
+                self.engine.step_staged(goff, gB, global_offset=goff, global_B=gB, train=train, apply=train)
+                steps += 1
+                continue
             if hi > lo:
                 self.engine.step_staged(goff + lo, hi - lo, global_offset=goff, global_B=gB, train=train, apply=False)
             elif train:
                 self._grad.zero_()
             if train:
-                if self.world > 1:
+                if self.world > 1 or self.force_allreduce:
                     dist.all_reduce(self._grad, op=dist.ReduceOp.SUM, group=self.group)
                 self.engine.apply()
             steps += 1

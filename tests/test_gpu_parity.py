@@ -139,6 +139,23 @@ def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
             _close(state[k], sd[k].numpy(), 1e-3, 2e-5)
 
 
+@pytest.mark.parametrize("bayesian", [False, True])
+def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian):
+    """cfg.fuse_adam moves the output layer's Adam into the dW kernel's epilogue: same parameters, step for step."""
+    sd, X, y = _bnn_case(64, [128], 900, 150, 3)
+    if not bayesian:
+        torch.manual_seed(3); sd = O.fnn_init(64, [128], 900)
+    def run(fuse):
+        e = _engine([64, 128, 900], bayesian=bayesian, max_batch=150, ns=4, nsd="uniform", seed=21, lr=1e-2, fuse_adam=fuse)
+        e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
+        losses = [e.train_step(np.arange(150)) for _ in range(4)]
+        return losses, e.state_dict()
+    (la, pa), (lb, pb) = run(False), run(True)
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    for k in pa:
+        np.testing.assert_allclose(pa[k], pb[k], rtol=1e-5, atol=1e-7)
+
+
 def test_split_backward_equals_train_step():
     """ntf_backward over two row shards with global_B, gradients summed == one full-batch gradient."""
     sd, X, y = _bnn_case(32, [32], 200, 24, 9)
