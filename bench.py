@@ -42,8 +42,10 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override the number of teams (debug)")
     ap.add_argument("--experts", type=int, default=0, help="override the number of experts (debug)")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--fuse-adam", type=int, default=2, help="0 flat Adam, 1 in the dW epilogue, 2 chunked beside dW on a side stream (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-bench", action="store_true", help="also time the whole-dataset gather (get_dense_vecs)")
+    ap.add_argument("--force-dist", action="store_true", help="init RCCL and all-reduce the gradient buffer even at world_size 1 (validation)")
     return ap.parse_args()
 
 
@@ -54,15 +56,24 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=2):
     from oracle import ntf_oracle as O
     from opentf_amd.synth import init_params
     from collections import OrderedDict
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     sd = OrderedDict((k, torch.from_numpy(v.copy())) for k, v in init_params(dims, bayesian, 0).items())
     opt = O.Adam(sd, cfg["lr"])
     m_ip, m_ix = ds["member"]
     member = scipy.sparse.csr_matrix((np.ones(len(m_ix), np.uint8), m_ix, m_ip), shape=(ds["N"], ds["M"]))
     s_ip, s_ix = ds["skill"]
     rng = np.random.default_rng(1)
-    O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], 32), member, cfg)  # warm
+    # torch's intra-op pool does not scale to every hardware thread on these elementwise-heavy [B, M] ops: pick the
+    # fastest of a few thread counts on a short probe, then time the sample with it (the count used is reported as `cores`)
+    best, cores = None, 1
+    for n in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
+        torch.set_num_threads(n)
+        O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], 32), member, cfg)  # warm
+        t0 = time.perf_counter()
+        O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], 64), member, cfg)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best: best, cores = dt, n
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     for _ in range(steps):
         O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], sample_rows), member, cfg)
@@ -79,8 +90,11 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or a.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if a.force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ["NTF_DP_FORCE_ALLREDUCE"] = "1"
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
     from opentf_amd import libntf
@@ -95,7 +109,7 @@ def main():
     with torch.cuda.stream(stream):
         e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
                           lr=1e-3, seed=1234 + rank, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
-                          fuse_adam=(world == 1))
+                          fuse_adam=a.fuse_adam if world == 1 else 0)
         e.set_skill_table(ds["table"]); e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
         e.load_state_dict(init_params(dims, bayesian, 0))
         dp = DataParallel(e)
@@ -134,6 +148,7 @@ def main():
     if rank != 0:
         if world > 1: dist.destroy_process_group()
         return
+    if a.force_dist and world == 1: dist.destroy_process_group()
     B, H, M = a.batch, a.hidden, ds["M"]
     gemm = 2.0 * B * H * M  # one [B,H]x[H,M]-sized product
     k = 2 if bayesian else 1

@@ -57,8 +57,9 @@ typedef struct ntf_config {
     float   lr;                 /* cfg.lr; Adam defaults beta 0.9/0.999 eps 1e-8 (src/mdl/fnn.py:104) */
     uint64_t seed;              /* seed of the device-side generators (negatives, Flipout eps and signs) */
     int32_t fused;              /* 1 = use the fused output-layer kernels when the shape allows, 0 = generic path */
-    int32_t fuse_adam;          /* 1 = on one GPU run the output layer's Adam inside the dW kernel's epilogue (its gradients are then
-                                   not materialised: ntf_get_grad returns stale values for that layer after ntf_train_step) */
+    int32_t fuse_adam;          /* single-GPU train steps only.  0: one flat Adam kernel after backward.  1: the output layer's Adam runs inside
+                                   the dW kernel's epilogue (its gradients are not materialised).  2: the dW kernel is launched in expert chunks
+                                   and Adam of a finished chunk runs on a side stream beside the next chunk's dW */
     int32_t reserved[6];
 } ntf_config;
 

@@ -52,11 +52,12 @@ __device__ __forceinline__ void normal4(const NormalSpec& s, int64_t q, int64_t 
         return;
     }
     const uint4 r = philox4x32(make_uint4((uint32_t)q, (uint32_t)(q >> 32), s.tag, s.step), make_uint2(s.k0, s.k1));
-    const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
-    float s0, c0, s1, c1;
-    sincospif(2.f * u01(r.y), &s0, &c0);
-    sincospif(2.f * u01(r.w), &s1, &c1);
-    z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+    // Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take their argument in revolutions
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.x)));   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.z)));
+    const float a0 = u01(r.y), a1 = u01(r.w);
+    z[0] = r0 * __builtin_amdgcn_cosf(a0); z[1] = r0 * __builtin_amdgcn_sinf(a0);
+    z[2] = r1 * __builtin_amdgcn_cosf(a1); z[3] = r1 * __builtin_amdgcn_sinf(a1);
 }
 
 __device__ __forceinline__ float softplus_rho(float rho) { return log1pf(expf(rho)); }  // sigma = log1p(exp(rho))

@@ -72,7 +72,9 @@ struct ntf_engine {
     std::vector<hipEvent_t> pool;
     double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
     int last_global_B = 0; int last_B = 0;
-    bool adam_in_dw = false;          // this step's output-layer Adam already ran inside the dW kernel
+    bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
+    hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
+    hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
 };
 
 #define HIPCHK(e, call)                                                                                   \
@@ -214,6 +216,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
+    if (e->st2) { hipStreamSynchronize(e->st2); hipStreamDestroy(e->st2); hipEventDestroy(e->ev_chunk); hipEventDestroy(e->ev_side); }
     if (e->own_stream && e->st) hipStreamDestroy(e->st);
     delete e;
 }
@@ -584,6 +587,30 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.mu = e->P + li.off[NTF_P_WEIGHT];
             f.s_out = sout_; f.s_out_inj = e->cfg.bayesian && (sout_.inj != nullptr || sin_.inj != nullptr);
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
+            if (c.fuse_adam && e->cfg.fuse_adam == 2) {
+                // chunked: dW of expert chunk k on the main stream, Adam of chunk k on the side stream while dW of chunk k+1 runs
+                if (!e->st2) { HIPCHK(e, hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_chunk, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming)); }
+                const double b1 = 0.9, b2 = 0.999, tt = (double)(e->adam_t + 1);
+                const float bc1 = (float)(1.0 - std::pow(b1, tt)), bc2s = (float)std::sqrt(1.0 - std::pow(b2, tt));
+                const int total = (M + 127) / 128, chunk = 512;
+                Scope t(e, F_OUT_FUSED_DW);
+                for (int w0 = 0; w0 < total; w0 += chunk) {
+                    f.wg_begin = w0; f.wg_count = chunk;
+                    launch_fused_out_dw(e->st, f);
+                    HIPCHK(e, hipEventRecord(e->ev_chunk, e->st));
+                    HIPCHK(e, hipStreamWaitEvent(e->st2, e->ev_chunk, 0));
+                    const int64_t lo = (int64_t)w0 * 128 * li.in, hi = std::min<int64_t>((int64_t)(w0 + chunk) * 128, M) * li.in;
+                    for (int kind : {NTF_P_WEIGHT, NTF_P_RHO_WEIGHT}) {
+                        if (kind == NTF_P_RHO_WEIGHT && !e->cfg.bayesian) continue;
+                        const int64_t o = li.off[kind] + lo;
+                        launch_adam(e->st2, e->P + o, e->G + o, e->M1 + o, e->V2 + o, hi - lo, e->lr, (float)b1, (float)b2, 1e-8f, bc1, bc2s);
+                    }
+                }
+                HIPCHK(e, hipEventRecord(e->ev_side, e->st2));
+                HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_side, 0));  // later kernels on the main stream read the updated parameters
+                e->adam_in_dw = true;
+                goto dw_done;
+            }
             if (c.fuse_adam) {
                 const double b1 = 0.9, b2 = 0.999;
                 const double tt = (double)(e->adam_t + 1);
@@ -593,7 +620,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                 if (e->cfg.bayesian) { f.w_rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.m_rho = e->M1 + li.off[NTF_P_RHO_WEIGHT]; f.v_rho = e->V2 + li.off[NTF_P_RHO_WEIGHT]; }
                 e->adam_in_dw = true;
             }
-            Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f);
+            { Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f); }
+        dw_done:;
         } else {
             const float* dZ = last ? e->dZout : e->dAct[(l + 1) & 1];
             { Scope t(e, F_BIAS_GRAD); launch_bias_grad(e->st, dZ, li.out, B, li.out, sout_, gb, gRb); }

@@ -35,6 +35,7 @@ struct FusedDw {
     SignSpec s_out; int s_out_inj = 0;              // s_out keys; s_out_inj: signs were injected this step (packed image in ws)
     // adam != 0 (single GPU): Adam on mu / rho runs in the epilogue (in place), g_mu / g_rho are not written
     int adam = 0;
+    int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the 128-expert tiles [wg_begin, wg_begin + wg_count)
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
 };

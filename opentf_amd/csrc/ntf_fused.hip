@@ -470,6 +470,7 @@ struct DwArgs {
     // fused Adam (single GPU): update mu / rho and their moments in the epilogue instead of writing the gradients
     float *__restrict__ w_mu, *__restrict__ w_rho, *__restrict__ m_mu, *__restrict__ v_mu, *__restrict__ m_rho, *__restrict__ v_rho;
     float lr_over_bc1, b1, b2, eps, bc2_sqrt;
+    int wg_begin;   // first 128-expert tile of this launch (the expert range can be launched in chunks)
 };
 
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwA
     constexpr int TH = KB * HROW;           // h tile [32][H]
     constexpr int STAGE = TA + (BAYES ? 2 : 1) * TH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    const int c0 = blockIdx.x * 128;
+    const int c0 = (p.wg_begin + blockIdx.x) * 128;
     const int crow = wave * 32 + il;        // this lane's expert row inside the tile
     const int c = c0 + crow;
     const int nib = p.Bpad / KB;
@@ -700,7 +701,10 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.g_mu = f.g_mu; a.g_rho = f.g_rho; a.g_b = f.g_b; a.g_bp = f.g_bp; a.klw = f.klw;
     a.w_mu = f.w_mu; a.w_rho = f.w_rho; a.m_mu = f.m_mu; a.v_mu = f.v_mu; a.m_rho = f.m_rho; a.v_rho = f.v_rho;
     a.lr_over_bc1 = f.lr_over_bc1; a.b1 = f.b1; a.b2 = f.b2; a.eps = f.eps; a.bc2_sqrt = f.bc2_sqrt;
-    const int grid = (f.M + 127) / 128;
+    const int total = (f.M + 127) / 128;
+    const int grid = f.wg_count > 0 ? std::min(f.wg_count, total - f.wg_begin) : total;
+    a.wg_begin = f.wg_count > 0 ? f.wg_begin : 0;
+    if (grid <= 0) return;
 #define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 1 * (128 * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a); } while (0)

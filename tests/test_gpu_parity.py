@@ -111,7 +111,8 @@ def _bnn_case(D, H, M, B, seed):
     return sd, X, y
 
 
-@pytest.mark.parametrize("D,H,M,B", [(18, [32], 112, 19), (128, [128], 1500, 70), (40, [64, 32], 300, 33), (128, [128], 5000, 130)])
+@pytest.mark.parametrize("D,H,M,B", [(18, [32], 112, 19), (128, [128], 1500, 70), (40, [64, 32], 300, 33), (128, [128], 5000, 130),
+                                     (24, [64], 777, 129), (16, [128], 13, 1), (16, [32], 63, 257), (50, [], 90, 21), (32, [], 100, 40)])
 @pytest.mark.parametrize("fused", [False, True])
 def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
     sd, X, y = _bnn_case(D, H, M, B, 5)
@@ -150,10 +151,11 @@ def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian):
         e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
         losses = [e.train_step(np.arange(150)) for _ in range(4)]
         return losses, e.state_dict()
-    (la, pa), (lb, pb) = run(False), run(True)
-    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    (la, pa), (lb, pb), (lc, pc) = run(0), run(1), run(2)
+    np.testing.assert_allclose(la, lb, rtol=1e-6); np.testing.assert_allclose(la, lc, rtol=1e-6)
     for k in pa:
         np.testing.assert_allclose(pa[k], pb[k], rtol=1e-5, atol=1e-7)
+        assert np.array_equal(pa[k], pc[k]), k  # mode 2 runs the same Adam kernel on the same gradients, only elsewhere in time
 
 
 def test_split_backward_equals_train_step():
