@@ -243,6 +243,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
             for (int r = 0; r < 16; ++r) { X1[u][r] = 0.f; X2[u][r] = 0.f; }
         uint32_t sw[2] = {0u, 0u};
         if (BAYES) { sw[0] = w2.x >> (4 * half); sw[1] = w2.y >> (4 * half); }
+        // buffer descriptor over this tile's 64 rows of dzT (the tile base is wave-uniform; rows are Bpad floats)
+        const int dz_row_bytes = p.Bpad * 4;
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BN * dz_row_bytes, 0x00020000);
+        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
         const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TB) + 4 * half;
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TB + 256) + 4 * half;
 
@@ -272,16 +276,19 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
                 sbit = (sw[u] << (31 - ((r & 3) + 8 * (r >> 2)))) & 0x80000000u;
                 z += __uint_as_float(__float_as_uint(X2[u][r] + bias_p[cr]) ^ sbit);
             }
+            // softplus(l) = l + ln(1 + e^-l), sigmoid(l) = 1 / (1 + e^-l) on the raw hardware transcendentals (v_exp_f32 / v_log_f32 are
+            // base 2; 1 + e^-l is in [1, 1 + e^80]: no denormal fix-ups needed).  l is clamped at -80 for the exponent only
+            // (leaky_relu keeps real logits far above it; the -1e30 mask of padded experts lands there and yields sp = dz = 0).
+            // The f32 matrix pipe shares the FMA hardware with the VALU, so every instruction here is paid in MFMA time: keep it short.
             const bool pos = z > 0.f;
             const float l = pos ? z : z * kLeakySlope;
-            const float e = __expf(-fabsf(l));
-            const float tt = 1.f + e;
-            lsum = fmaf(fmaxf(l, 0.f) + __logf(tt), rmask, lsum);
+            const float lc = fmaxf(l, -80.f);
+            const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
+            lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
             if (TRAIN) {
-                const float inv = __builtin_amdgcn_rcpf(tt);
-                const float sg = (l >= 0.f) ? inv : e * inv;
-                const float dz = rscale * sg * (pos ? 1.f : kLeakySlope);
-                p.dzT[(int64_t)(c0 + cr + 4 * half) * p.Bpad + i] = dz;  // dzT is padded to whole tiles: exactly 32 stores per lane per tile
+                const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
+                // dzT tile base in the buffer descriptor, lane part in voffset, register part as a scalar offset: no per-element address math
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
                 X1[u][r] = dz;
                 X2[u][r] = __uint_as_float(__float_as_uint(dz) ^ sbit);
             }
