@@ -178,7 +178,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     A(dmalloc(e, &e->d_rows, B)); A(dmalloc(e, &e->d_neg, (int64_t)B * std::max(1, cfg->ns)));
     e->act.assign(e->L, nullptr);
     for (int l = 0; l < e->L; ++l) A(dmalloc(e, &e->act[l], (int64_t)B * cfg->dims[l]));
-    A(dmalloc(e, &e->Zout, (int64_t)B * M)); A(dmalloc(e, &e->dZout, (int64_t)((M + 127) / 128 * 128) * fused_ldb(B)));
+    A(dmalloc(e, &e->Zout, (int64_t)B * M)); A(dmalloc(e, &e->dZout, (int64_t)((M + 255) / 256 * 256) * fused_ldb(B)));
     if (e->maxhid) { A(dmalloc(e, &e->Zh, (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[0], (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[1], (int64_t)B * e->maxhid)); }
     e->Wp.assign(e->L, nullptr); e->bp.assign(e->L, nullptr);
     if (cfg->bayesian) for (int l = 0; l < e->L; ++l) { A(dmalloc(e, &e->Wp[l], e->layers[l].nw())); A(dmalloc(e, &e->bp[l], e->layers[l].out)); }
@@ -592,14 +592,14 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                 if (!e->st2) { HIPCHK(e, hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_chunk, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming)); }
                 const double b1 = 0.9, b2 = 0.999, tt = (double)(e->adam_t + 1);
                 const float bc1 = (float)(1.0 - std::pow(b1, tt)), bc2s = (float)std::sqrt(1.0 - std::pow(b2, tt));
-                const int total = (M + 127) / 128, chunk = 512;
+                const int tile = fused_dw_tile(), total = (M + tile - 1) / tile, chunk = 256;   // one workgroup per CU per round
                 Scope t(e, F_OUT_FUSED_DW);
                 for (int w0 = 0; w0 < total; w0 += chunk) {
                     f.wg_begin = w0; f.wg_count = chunk;
                     launch_fused_out_dw(e->st, f);
                     HIPCHK(e, hipEventRecord(e->ev_chunk, e->st));
                     HIPCHK(e, hipStreamWaitEvent(e->st2, e->ev_chunk, 0));
-                    const int64_t lo = (int64_t)w0 * 128 * li.in, hi = std::min<int64_t>((int64_t)(w0 + chunk) * 128, M) * li.in;
+                    const int64_t lo = (int64_t)w0 * tile * li.in, hi = std::min<int64_t>((int64_t)(w0 + chunk) * tile, M) * li.in;
                     for (int kind : {NTF_P_WEIGHT, NTF_P_RHO_WEIGHT}) {
                         if (kind == NTF_P_RHO_WEIGHT && !e->cfg.bayesian) continue;
                         const int64_t o = li.off[kind] + lo;

@@ -22,9 +22,12 @@ namespace ntf {
 constexpr int BM = 128;       // batch rows per workgroup: 4 waves x 32
 constexpr int BN = 64;        // experts per tile
 constexpr int NCG_MAX = 256;  // column groups (one workgroup per CU when the batch has a single row block)
+constexpr int DW_WAVES = 8;               // waves per workgroup of the dW kernel: two per SIMD
+constexpr int DW_TC = 32 * DW_WAVES;      // experts per workgroup of the dW kernel
 
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 int fused_ldb(int B) { return rup(B, BM); }
+int fused_dw_tile() { return DW_TC; }
 bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
 int fused_loss_slots(int) { return 0; }
 
@@ -504,16 +507,16 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t a, int il) {
 }
 
 template <int H, bool BAYES, bool ADAM>
-__global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwArgs
+__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NJT = H / 32;
     constexpr int KB = 32;                  // batch rows per K block
     constexpr int HROW = 4 * H;
-    constexpr int TA = 128 * KB * 4;        // dzT tile [128 experts][32 batch rows], 16-byte chunks XOR-swizzled
-    constexpr int TH = KB * HROW;           // h tile [32][H]
-    constexpr int STAGE = TA + (BAYES ? 2 : 1) * TH;
+    constexpr int TA = DW_TC * KB * 4;      // dzT tile [256 experts][32 batch rows], 16-byte chunks XOR-swizzled
+    constexpr int TH = KB * HROW;           // h tile [32][H] (and h*s_in behind it)
+    constexpr int STAGE = TA + (BAYES ? 2 : 1) * TH;   // two stages: the DMA of K block b+1 runs under the MFMAs of K block b
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    const int c0 = (p.wg_begin + blockIdx.x) * 128;
+    const int c0 = (p.wg_begin + blockIdx.x) * DW_TC;
     const int crow = wave * 32 + il;        // this lane's expert row inside the tile
     const int c = c0 + crow;
     const int nib = p.Bpad / KB;
@@ -530,18 +533,21 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwA
     auto stage = [&](int ib, int buf) {
         const uint32_t sb = smem_base + buf * STAGE;
 #pragma unroll
-        for (int n = 0; n < TA / 4096; ++n) {      // 1 KiB wave-instructions: 8 expert rows x 128 B
-            const int inst = wave_u * (TA / 4096) + n;
+        for (int n = 0; n < TA / 1024 / DW_WAVES; ++n) {      // 1 KiB wave-instructions: 8 expert rows x 128 B
+            const int inst = wave_u * (TA / 1024 / DW_WAVES) + n;
             const int row = inst * 8 + (lane >> 3), pch = lane & 7;
             const int q = pch ^ ((row >> 1) & 7);
             glds16(p.dzT + (int64_t)(c0 + row) * p.Bpad + ib * KB + 4 * q, sb + inst * 1024);
         }
+        constexpr int HI = TH / 1024;                           // wave-instructions per h tile (may be fewer than the waves)
 #pragma unroll
-        for (int n = 0; n < TH / 4096; ++n) {
-            const int inst = wave_u * (TH / 4096) + n;
-            const int64_t goff = (int64_t)ib * KB * H + inst * 256 + lane * 4;  // h tile rows are contiguous in memory
-            glds16(p.h + goff, sb + TA + inst * 1024);
-            if (BAYES) glds16(p.hs + goff, sb + TA + TH + inst * 1024);
+        for (int n = 0; n < (HI + DW_WAVES - 1) / DW_WAVES; ++n) {
+            const int inst = wave_u * ((HI + DW_WAVES - 1) / DW_WAVES) + n;
+            if (inst < HI) {
+                const int64_t goff = (int64_t)ib * KB * H + inst * 256 + lane * 4;  // h tile rows are contiguous in memory
+                glds16(p.h + goff, sb + TA + inst * 1024);
+                if (BAYES) glds16(p.hs + goff, sb + TA + TH + inst * 1024);
+            }
         }
     };
 
@@ -558,14 +564,14 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwA
     };
     uint32_t word_next = 0;
     if (BAYES) word_next = sign_col_word(0);
-    // single LDS stage, two workgroups per CU: while one waits for its DMA the other one owns the MFMA pipe
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int ib = 0; ib < nib; ++ib) {
-        const int buf = 0;
-        stage(ib, 0);
+        const int buf = ib & 1;
         const uint32_t word = word_next >> (4 * half);
         if (BAYES && ib + 1 < nib) word_next = sign_col_word(ib + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (ib + 1 < nib) stage(ib + 1, buf ^ 1);
         const char* sA = smem + buf * STAGE;
         const char* sH = sA + TA;
 #pragma unroll
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwA
                 const float a1 = av[e4];
                 sum1 += a1;
                 float a2 = a1;
-                if (BAYES) { a2 = ((word >> kk) & 1u) ? -a1 : a1; sum2 += a2; }
+                if (BAYES) { a2 = __uint_as_float(__float_as_uint(a1) ^ ((word << (31 - kk)) & 0x80000000u)); sum2 += a2; }
                 // ONE wide read feeds all NJT column tiles: lane il owns hidden units j = NJT*il + jt
                 const char* hb = sH + (kk + 4 * half) * HROW + 4 * NJT * il;
                 float bv[NJT], bsv[NJT];
@@ -600,7 +606,8 @@ __global__ __launch_bounds__(256, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwA
                 }
             }
         }
-        __syncthreads();  // everyone is done with the tile before the next DMA overwrites it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next K block landed (the DMA is invisible to hipcc's own counting)
+        __syncthreads();                                     // ... and this one is fully consumed
     }
 
     sum1 += __shfl_xor(sum1, 32, 64);
@@ -708,13 +715,13 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.g_mu = f.g_mu; a.g_rho = f.g_rho; a.g_b = f.g_b; a.g_bp = f.g_bp; a.klw = f.klw;
     a.w_mu = f.w_mu; a.w_rho = f.w_rho; a.m_mu = f.m_mu; a.v_mu = f.v_mu; a.m_rho = f.m_rho; a.v_rho = f.v_rho;
     a.lr_over_bc1 = f.lr_over_bc1; a.b1 = f.b1; a.b2 = f.b2; a.eps = f.eps; a.bc2_sqrt = f.bc2_sqrt;
-    const int total = (f.M + 127) / 128;
+    const int total = (f.M + DW_TC - 1) / DW_TC;
     const int grid = f.wg_count > 0 ? std::min(f.wg_count, total - f.wg_begin) : total;
     a.wg_begin = f.wg_count > 0 ? f.wg_begin : 0;
     if (grid <= 0) return;
-#define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 1 * (128 * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
+#define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a); } while (0)
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
 #define NTF_DW(HH) do { if (f.bayes) NTF_DW1(HH, true); else NTF_DW1(HH, false); } while (0)
     if (f.H == 128) NTF_DW(128); else if (f.H == 64) NTF_DW(64); else NTF_DW(32);
 #undef NTF_DW
