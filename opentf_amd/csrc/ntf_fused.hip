@@ -253,13 +253,17 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
         const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TB) + 4 * half;
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TB + 256) + 4 * half;
 
-        auto x_step = [&](int u, int tq) {   // 4 k-pairs of sub-tile u
+        // operand fetch and MFMA issue are separate so that the fetch for group g+1 can be issued before the MFMAs of group g
+        // (one wave per SIMD: nobody else hides the LDS latency)
+        auto x_load = [&](int u, int tq, float4& a, float4& aw) {
             const int imm = u * 32 * ROWB + ((H >= 64) ? ((2 * tq) & ~15) * 16 : 0);
             const char* ap = sb + aoff[tq % QM] + imm;
-            const float4 a = *reinterpret_cast<const float4*>(ap);
+            a = *reinterpret_cast<const float4*>(ap);
+            if (BAYES) aw = *reinterpret_cast<const float4*>(ap + TB);
+        };
+        auto x_mma = [&](int u, int tq, const float4& a, const float4& aw) {   // 4 k-pairs of sub-tile u
             const float av[4] = {a.x, a.y, a.z, a.w};
-            float awv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (BAYES) { const float4 aw = *reinterpret_cast<const float4*>(ap + TB); awv[0] = aw.x; awv[1] = aw.y; awv[2] = aw.z; awv[3] = aw.w; }
+            const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
                 const int e = 4 * tq + e4;
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
                 X2[u][r] = __uint_as_float(__float_as_uint(dz) ^ sbit);
             }
         };
-        auto dh_step = [&](int u, int s) {   // dh += dz[:, c] * W[c, :] for c = u*32 + rowmap(s, half): A operand = accumulator register s
+        struct BOp { float v[NJT], w[NJT]; };
+        auto dh_load = [&](int u, int s, BOp& o) {   // weight rows c = u*32 + rowmap(s, half): NJT consecutive hidden units per lane
             const int rowc = u * 32 + (s & 3) + 8 * (s >> 2);  // row without the lane half
             const char* bp_;
             if (H >= 64) bp_ = sb + boff[s & 3][(s >> 2) & 1] + rowc * ROWB;
@@ -304,38 +309,52 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
                 const int row = rowc + 4 * half;
                 bp_ = sb + row * ROWB + 16 * (((NJT * il) >> 2) ^ swz<H>(row)) + 4 * ((NJT * il) & 3);
             }
-            float bv[NJT], bwv[NJT];
             if (NJT == 4) {
-                const float4 b4 = *reinterpret_cast<const float4*>(bp_); bv[0] = b4.x; bv[1] = b4.y; bv[NJT > 2 ? 2 : 0] = b4.z; bv[NJT > 3 ? 3 : 0] = b4.w;
-                if (BAYES) { const float4 w4 = *reinterpret_cast<const float4*>(bp_ + TB); bwv[0] = w4.x; bwv[1] = w4.y; bwv[NJT > 2 ? 2 : 0] = w4.z; bwv[NJT > 3 ? 3 : 0] = w4.w; }
+                const float4 b4 = *reinterpret_cast<const float4*>(bp_); o.v[0] = b4.x; o.v[1] = b4.y; o.v[NJT > 2 ? 2 : 0] = b4.z; o.v[NJT > 3 ? 3 : 0] = b4.w;
+                if (BAYES) { const float4 w4 = *reinterpret_cast<const float4*>(bp_ + TB); o.w[0] = w4.x; o.w[1] = w4.y; o.w[NJT > 2 ? 2 : 0] = w4.z; o.w[NJT > 3 ? 3 : 0] = w4.w; }
             } else if (NJT == 2) {
-                const float2 b2 = *reinterpret_cast<const float2*>(bp_); bv[0] = b2.x; bv[NJT > 1 ? 1 : 0] = b2.y;
-                if (BAYES) { const float2 w2_ = *reinterpret_cast<const float2*>(bp_ + TB); bwv[0] = w2_.x; bwv[NJT > 1 ? 1 : 0] = w2_.y; }
+                const float2 b2 = *reinterpret_cast<const float2*>(bp_); o.v[0] = b2.x; o.v[NJT > 1 ? 1 : 0] = b2.y;
+                if (BAYES) { const float2 w2_ = *reinterpret_cast<const float2*>(bp_ + TB); o.w[0] = w2_.x; o.w[NJT > 1 ? 1 : 0] = w2_.y; }
             } else {
-                bv[0] = *reinterpret_cast<const float*>(bp_);
-                if (BAYES) bwv[0] = *reinterpret_cast<const float*>(bp_ + TB);
+                o.v[0] = *reinterpret_cast<const float*>(bp_);
+                if (BAYES) o.w[0] = *reinterpret_cast<const float*>(bp_ + TB);
             }
+        };
+        auto dh_mma = [&](int u, int s, const BOp& o) {   // dh += dz[:, c] * W[c, :]: A operand = accumulator register s as it stands
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
-                Y1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1[u][s], bv[jt], Y1[jt], 0, 0, 0);
-                if (BAYES) Y2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X2[u][s], bwv[jt], Y2[jt], 0, 0, 0);
+                Y1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1[u][s], o.v[jt], Y1[jt], 0, 0, 0);
+                if (BAYES) Y2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X2[u][s], o.w[jt], Y2[jt], 0, 0, 0);
             }
         };
 
         constexpr int NTQ = H / 8, RPT = 16 / NTQ;  // epilogue registers handled per k-step of the other sub-tile
+        {
+            float4 xa[2], xw[2];
+            xw[0] = xw[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            x_load(0, 0, xa[0], xw[0]);
 #pragma unroll
-        for (int tq = 0; tq < NTQ; ++tq) x_step(0, tq);
+            for (int g = 0; g < 2 * NTQ; ++g) {
+                const int u = g / NTQ, tq = g % NTQ;
+                if (g + 1 < 2 * NTQ) x_load((g + 1) / NTQ, (g + 1) % NTQ, xa[(g + 1) & 1], xw[(g + 1) & 1]);
+                x_mma(u, tq, xa[g & 1], xw[g & 1]);
+                if (u == 1) {
 #pragma unroll
-        for (int tq = 0; tq < NTQ; ++tq) {
-            x_step(1, tq);
-#pragma unroll
-            for (int rr = 0; rr < RPT; ++rr) epilogue(0, tq * RPT + rr);
+                    for (int rr = 0; rr < RPT; ++rr) epilogue(0, tq * RPT + rr);
+                }
+            }
         }
         if (TRAIN && DH) {
+            BOp bo[2];
+            dh_load(0, 0, bo[0]);
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) { dh_step(0, s2); epilogue(1, s2); }
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) dh_step(1, s2);
+            for (int g = 0; g < 32; ++g) {
+                const int u = g >> 4, s2 = g & 15;
+                if (g + 1 < 32) dh_load((g + 1) >> 4, (g + 1) & 15, bo[(g + 1) & 1]);
+                if (u == 1 && s2 == 0) { /* epilogue(1, .) has produced every dz of sub-tile 1 by now */ }
+                dh_mma(u, s2, bo[g & 1]);
+                if (u == 0) epilogue(1, s2);
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) epilogue(1, r);
