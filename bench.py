@@ -49,7 +49,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=2):
+def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=5):
     """The oracle's reference-shaped step (dense [B, M] labels, rand_like+topk negatives, autograd, Adam) on the host."""
     import scipy.sparse
     import torch
@@ -80,6 +80,22 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=2):
     dt = time.perf_counter() - t0
     return {"value": steps * sample_rows / dt, "unit": "teams/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps of B={sample_rows} at full M={ds['M']} (oracle/ntf_oracle.py reference_shaped_step, torch {torch.__version__} CPU)"}
+
+
+def pmc_traffic(family, a, ds):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
+    as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
+    path = os.path.join(ROOT, "profiles", "r1_c_pmc_traffic_and_sq.json")
+    if not (os.path.exists(path) and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
+            and not a.rows and not a.experts):
+        return None
+    key = {"out_fused_fwd_loss_dh": "k_out_fwd", "out_fused_dw_adam": "k_out_dw"}.get(family)
+    if not key:
+        return None
+    for name, v in json.load(open(path))["kernels"].items():
+        if key in name:
+            return v["hbm_bytes"]
+    return None
 
 
 def main():
@@ -162,7 +178,8 @@ def main():
         ms, calls = cand[dom]
         ach = flops_per_launch[dom] / (ms / calls * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
-                "traffic": None, "avg_ms": ms / calls, "launches": calls}
+                "traffic": pmc_traffic(dom, a, ds), "avg_ms": ms / calls, "launches": calls,
+                "flops_per_launch": flops_per_launch[dom]}
     out = {
         "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",

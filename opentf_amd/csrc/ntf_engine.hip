@@ -22,10 +22,10 @@ struct LayerInfo {
 };
 
 enum Fam { F_GATHER = 0, F_GEMM_HIDDEN, F_FLIPOUT_OPERAND, F_OUT_FWD, F_LOSS, F_OUT_BWD_DW, F_OUT_BWD_DA, F_BIAS_GRAD,
-           F_FLIPOUT_FINAL, F_KL, F_ADAM, F_SAMPLER, F_INFER, F_OUT_FUSED_FWD, F_OUT_FUSED_DW, F_COUNT };
+           F_FLIPOUT_FINAL, F_KL, F_ADAM, F_SAMPLER, F_INFER, F_OUT_FUSED_FWD, F_OUT_FUSED_DW, F_OUT_FUSED_AUX, F_COUNT };
 static const char* kFamNames[F_COUNT] = {"gather", "gemm_hidden", "flipout_operand", "out_fwd_gemm", "loss", "out_bwd_dw_gemm",
                                          "out_bwd_da_gemm", "bias_grad", "flipout_grad_finalize", "kl", "adam", "sampler", "infer",
-                                         "out_fused_fwd_loss_dh", "out_fused_dw_adam"};
+                                         "out_fused_fwd_loss_dh", "out_fused_dw_adam", "out_fused_prep_special"};
 
 struct TimeRec { int fam; hipEvent_t a, b; };
 constexpr int64_t kGemmSlabFloats = 8 << 20;  // 32 MiB
@@ -551,7 +551,9 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         }
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
-        { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f); }
+        { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
+        { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
+        { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
         nslots = fused_loss_slots(M);
     } else {
         if ((r = forward_layers(e, c, false, false))) return r;

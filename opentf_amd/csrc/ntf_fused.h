@@ -46,7 +46,8 @@ int64_t fused_dh_slab_floats(int B, int H, int M);
 size_t fused_workspace_bytes(int B, int H, int M);
 int fused_ldb(int B);
 int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are padded to a multiple of it)
-void launch_fused_out_fwd(hipStream_t st, const FusedOut& f);
+// phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction
+void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
 
 }  // namespace ntf

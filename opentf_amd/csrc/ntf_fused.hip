@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
 
 // ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
-static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid) {
+static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
     const size_t lds = 2 * STAGE;
     const bool dh = f.dh != nullptr;
@@ -681,9 +681,11 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
 #define NTF_LAUNCH_FWD(TR, DHF)                                                                                           \
     do {                                                                                                                  \
         auto kf = inj ? k_out_fwd<H, BAYES, TR, DHF, BAYES> : k_out_fwd<H, BAYES, TR, DHF, false>;                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);                                                        \
-        hipLaunchKernelGGL((k_out_special<H, BAYES, TR, DHF>), dim3(f.B), dim3(64), 0, st, s);                            \
+        if (phases & 2) {                                                                                                 \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);                                                    \
+        }                                                                                                                 \
+        if (phases & 4) hipLaunchKernelGGL((k_out_special<H, BAYES, TR, DHF>), dim3(f.B), dim3(64), 0, st, s);            \
     } while (0)
     if (!f.train) NTF_LAUNCH_FWD(false, false);
     else if (dh) NTF_LAUNCH_FWD(true, true);
@@ -691,7 +693,7 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
 #undef NTF_LAUNCH_FWD
 }
 
-void launch_fused_out_fwd(hipStream_t st, const FusedOut& f) {
+void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     const Geom g = geom(f.B, f.M);
     const WsLayout w = ws_layout(f.B, f.H, f.M);
     char* ws = static_cast<char*>(f.ws);
@@ -701,8 +703,8 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f) {
     float* hz = reinterpret_cast<float*>(ws + w.hz);
     float* lossp = reinterpret_cast<float*>(ws + w.lossp);
     const bool inj = f.bayes && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
-    if (inj) hipLaunchKernelGGL(k_sign_bits, dim3((g.nCB + 63) / 64, g.Bpad), dim3(64), 0, st, f.s_out, f.B, f.M, g.nCB, sbits);
-    {
+    if (inj && (phases & 1)) hipLaunchKernelGGL(k_sign_bits, dim3((g.nCB + 63) / 64, g.Bpad), dim3(64), 0, st, f.s_out, f.B, f.M, g.nCB, sbits);
+    if (phases & 1) {
         const int n = g.Bpad * (f.H / 32);
         hipLaunchKernelGGL(k_prep_h, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.bayes, f.h, f.B, f.H, g.Bpad, sinbits, hs, hz);
     }
@@ -718,7 +720,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f) {
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     const int grid = g.NRB * g.NCG;
-#define NTF_H(HH) do { if (f.bayes) fwd_dispatch<HH, true>(st, f, a, s, grid); else fwd_dispatch<HH, false>(st, f, a, s, grid); } while (0)
+#define NTF_H(HH) do { if (f.bayes) fwd_dispatch<HH, true>(st, f, a, s, grid, phases); else fwd_dispatch<HH, false>(st, f, a, s, grid, phases); } while (0)
     if (f.H == 128) NTF_H(128); else if (f.H == 64) NTF_H(64); else NTF_H(32);
 #undef NTF_H
 }
