@@ -119,6 +119,18 @@ int ntf_epoch_loss(ntf_engine* e, double* sum, int64_t* steps); /* reads and cle
 int ntf_stage_order(ntf_engine* e, const int64_t* order, int64_t n);
 int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, int32_t train, int32_t apply, float* loss_out);
 
+/* data-parallel pipelining.  ntf_step_staged_deferred = ntf_step_staged(train=1, apply=0) except that the output layer's
+ * weight-gradient kernel is left pending; ntf_dw_chunk(k), k = 0..n-1 in order, then launches it for the k-th range of experts, so that
+ * the host can all-reduce the gradients of chunk k while chunk k+1 is being computed.  ntf_dw_chunks: n for this model (0 when the
+ * fused output-layer path does not apply: nothing is deferred then).  ntf_dw_chunk_range: where chunk k's gradients sit in the flat
+ * gradient buffer (offsets in floats; off_rho = -1 for Fnn) - a pure function of the model shape, identical on every rank.
+ * After the last chunk the whole gradient buffer is complete.  ntf_param_segment: where a parameter sits in the flat buffers. */
+int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, float* loss_out);
+int ntf_dw_chunks(ntf_engine* e, int32_t* n_chunks);
+int ntf_dw_chunk_range(ntf_engine* e, int32_t k, int64_t* off_weight, int64_t* off_rho, int64_t* count);
+int ntf_dw_chunk(ntf_engine* e, int32_t k);
+int ntf_param_segment(ntf_engine* e, int layer, int kind, int64_t* off, int64_t* count);
+
 /* ---- inference:  Fnn.test batch body                              src/mdl/fnn.py:200-211
  * probs_host [B, M] = sigmoid(forward) (Bnn: mean over nmc stochastic forwards);
  * pred_unc/model_unc [B] = predictive entropy / mutual information (may be NULL). */

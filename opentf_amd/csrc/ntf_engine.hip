@@ -73,6 +73,8 @@ struct ntf_engine {
     double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
     int last_global_B = 0; int last_B = 0;
     bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
+    // data-parallel pipelining: the output layer's dW kernel deferred by ntf_step_staged_deferred, launched by ntf_dw_chunk
+    bool pend_valid = false; FusedDw pend; NormalSpec pend_eps_b; float pend_klw_b = 0.f; int pend_chunks = 0;
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
 };
@@ -367,6 +369,7 @@ struct StepCtx {
     const ntf_inject* inj = nullptr;
     uint64_t step = 0;
     bool train = false;
+    bool defer_dw = false;   // leave the output layer's dW kernel to ntf_dw_chunk (data-parallel overlap with the all-reduce)
     bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
 };
 
@@ -589,6 +592,12 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.mu = e->P + li.off[NTF_P_WEIGHT];
             f.s_out = sout_; f.s_out_inj = e->cfg.bayesian && (sout_.inj != nullptr || sin_.inj != nullptr);
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
+            if (c.defer_dw) {
+                const int tile = fused_dw_tile(), total = (M + tile - 1) / tile;
+                e->pend = f; e->pend_valid = true; e->pend_chunks = (total + 255) / 256;
+                if (e->cfg.bayesian) { e->pend_eps_b = normal_spec(e, c, l, T_EPS_B); e->pend_klw_b = kl_share / ((float)li.out * (float)c.global_B); }
+                continue;  // its bias-gradient finalisation follows the last chunk
+            }
             if (c.fuse_adam && e->cfg.fuse_adam == 2) {
                 // chunked: dW of expert chunk k on the main stream, Adam of chunk k on the side stream while dW of chunk k+1 runs
                 if (!e->st2) { HIPCHK(e, hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_chunk, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming)); }
@@ -700,7 +709,7 @@ static int read_loss(ntf_engine* e, float* loss_out) {
 }
 
 static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t global_B, const ntf_inject* inj, float* loss_out, bool train,
-                       bool apply, bool rows_on_device, const int64_t* global_rows_host, int n_global) {
+                       bool apply, bool rows_on_device, const int64_t* global_rows_host, int n_global, bool defer_dw = false) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     int r;
@@ -708,6 +717,8 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     if (global_B < B) FAIL(e, NTF_EINVAL, "global_B < B");
     StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
     c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
+    c.defer_dw = defer_dw && train && !apply && fused_ok(e);
+    e->pend_valid = false;
     if ((r = stage_rows(e, rows, B, rows_on_device, &c.rows_dev))) return r;
     if ((r = stage_all_inj(e, c))) return r;
     if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && !(inj && inj->neg_idx)) {
@@ -760,6 +771,63 @@ extern "C" int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t
         offset + B > global_offset + global_B)
         FAIL(e, NTF_EINVAL, "step_staged: shard / batch outside the staged order");
     return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, train != 0, apply != 0, true, e->h_order.data() + global_offset, global_B);
+}
+
+extern "C" int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, float* loss_out) {
+    if (!e) return NTF_EINVAL;
+    const int64_t n = (int64_t)e->h_order.size();
+    if (offset < 0 || B < 1 || offset + B > n || global_offset < 0 || global_offset + global_B > n || offset < global_offset ||
+        offset + B > global_offset + global_B)
+        FAIL(e, NTF_EINVAL, "step_staged_deferred: shard / batch outside the staged order");
+    return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, true, false, true, e->h_order.data() + global_offset, global_B, true);
+}
+static int dw_chunk_span(ntf_engine* e, int k, int64_t& off_w, int64_t& off_r, int64_t& cnt, int& wg_begin) {
+    const LayerInfo& li = e->layers[e->L - 1];
+    const int tile = fused_dw_tile(), M = li.out, total = (M + tile - 1) / tile, n = (total + 255) / 256;
+    if (!fused_ok(e) || k < 0 || k >= n) FAIL(e, NTF_EINVAL, "dw_chunk: bad chunk index (or the fused output-layer path does not apply to this shape)");
+    wg_begin = k * 256;
+    const int64_t lo = (int64_t)wg_begin * tile * li.in, hi = std::min<int64_t>((int64_t)(wg_begin + 256) * tile, M) * li.in;
+    off_w = li.off[NTF_P_WEIGHT] + lo; cnt = hi - lo;
+    off_r = e->cfg.bayesian ? li.off[NTF_P_RHO_WEIGHT] + lo : -1;
+    return NTF_OK;
+}
+extern "C" int ntf_dw_chunks(ntf_engine* e, int32_t* n_chunks) {
+    if (!e || !n_chunks) return NTF_EINVAL;
+    const int tile = fused_dw_tile(), total = (e->layers[e->L - 1].out + tile - 1) / tile;
+    *n_chunks = fused_ok(e) ? (total + 255) / 256 : 0;
+    return NTF_OK;
+}
+extern "C" int ntf_dw_chunk_range(ntf_engine* e, int32_t k, int64_t* off_weight, int64_t* off_rho, int64_t* count) {
+    if (!e || !off_weight || !off_rho || !count) return NTF_EINVAL;
+    int wg;
+    return dw_chunk_span(e, k, *off_weight, *off_rho, *count, wg);
+}
+extern "C" int ntf_dw_chunk(ntf_engine* e, int32_t k) {
+    if (!e) return NTF_EINVAL;
+    if (!e->pend_valid) FAIL(e, NTF_ESTATE, "dw_chunk: no deferred dW kernel pending (call ntf_step_staged_deferred first)");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int64_t ow, orr, cnt; int wg;
+    int r = dw_chunk_span(e, k, ow, orr, cnt, wg);
+    if (r) return r;
+    const LayerInfo& li = e->layers[e->L - 1];
+    FusedDw f = e->pend;
+    f.wg_begin = wg; f.wg_count = 256;
+    { Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f); }
+    if (k == e->pend_chunks - 1) {
+        if (e->cfg.bayesian) {
+            Scope t(e, F_FLIPOUT_FINAL);
+            launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_BIAS], e->P + li.off[NTF_P_RHO_BIAS], e->G + li.off[NTF_P_BIAS],
+                                         e->G + li.off[NTF_P_RHO_BIAS], li.out, e->pend_eps_b, e->pend_klw_b);
+        }
+        e->pend_valid = false;
+    }
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
+    return NTF_OK;
+}
+extern "C" int ntf_param_segment(ntf_engine* e, int layer, int kind, int64_t* off, int64_t* count) {
+    if (!e || !off || !count) return NTF_EINVAL;
+    return param_span(e, layer, kind, *off, *count);
 }
 
 static int run_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss, bool train) {

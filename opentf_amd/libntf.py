@@ -64,6 +64,11 @@ SYMBOLS = {
     "ntf_epoch_loss": (C.c_int, [_P, _P, _P]),
     "ntf_stage_order": (C.c_int, [_P, _P, _I64]),
     "ntf_step_staged": (C.c_int, [_P, _I64, _I32, _I64, _I32, _I32, _I32, _P]),
+    "ntf_step_staged_deferred": (C.c_int, [_P, _I64, _I32, _I64, _I32, _P]),
+    "ntf_dw_chunks": (C.c_int, [_P, C.POINTER(_I32)]),
+    "ntf_dw_chunk_range": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
+    "ntf_dw_chunk": (C.c_int, [_P, _I32]),
+    "ntf_param_segment": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_I64), C.POINTER(_I64)]),
     "ntf_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P]),
     "ntf_logits": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_forward_topk": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
@@ -292,6 +297,38 @@ class Engine:
         self._ck(lib().ntf_step_staged(self._h, int(offset), int(B), int(offset if global_offset is None else global_offset),
                                        int(B if global_B is None else global_B), int(train), int(apply), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
+
+    # ---- data-parallel pipelining (see include/opentf_amd.h)
+    def step_staged_deferred(self, offset, B, global_offset, global_B):
+        self._ck(lib().ntf_step_staged_deferred(self._h, int(offset), int(B), int(global_offset), int(global_B), None))
+
+    def dw_chunks(self):
+        n = C.c_int32()
+        self._ck(lib().ntf_dw_chunks(self._h, C.byref(n)))
+        return n.value
+
+    def dw_chunk_range(self, k):
+        ow, orr, cnt = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(lib().ntf_dw_chunk_range(self._h, int(k), C.byref(ow), C.byref(orr), C.byref(cnt)))
+        return ow.value, orr.value, cnt.value
+
+    def dw_chunk(self, k):
+        self._ck(lib().ntf_dw_chunk(self._h, int(k)))
+
+    def rest_ranges(self):
+        """[lo, hi) float ranges of the flat gradient buffer outside the output layer's weight / rho_weight segments."""
+        n = self.grad_view().__cuda_array_interface__["shape"][0]
+        cuts = []
+        for kind in ([P_WEIGHT, P_RHO_WEIGHT] if self.bayesian else [P_WEIGHT]):
+            o, c = C.c_int64(), C.c_int64()
+            self._ck(lib().ntf_param_segment(self._h, self.L - 1, kind, C.byref(o), C.byref(c)))
+            cuts.append((o.value, o.value + c.value))
+        out, pos = [], 0
+        for lo, hi in sorted(cuts):
+            if lo > pos: out.append((pos, lo))
+            pos = hi
+        if pos < n: out.append((pos, n))
+        return out
 
     def epoch_loss(self):
         s, k = C.c_double(), C.c_int64()

@@ -55,6 +55,51 @@ class OracleEngine:
             if apply: self.apply()
         self.acc += float(loss.item()); self.steps += 1
 
+    # ---- the pipelined (chunked output-layer dW) surface of the engine
+    N_CHUNKS = 3
+
+    def _last_weight_keys(self):
+        last = O.n_layers(self.sd) - 1
+        return [k for k in self.keys if k.startswith(f"layers.{last}.") and k.endswith("weight")]  # weight | mu_weight, rho_weight
+
+    def _offset(self, key):
+        o = 0
+        for k in self.keys:
+            if k == key: return o
+            o += self.sd[k].numel()
+
+    def dw_chunks(self): return self.N_CHUNKS
+
+    def dw_chunk_range(self, k):
+        keys = self._last_weight_keys()
+        rows, cols = self.sd[keys[0]].shape
+        r0, r1 = rows * k // self.N_CHUNKS, rows * (k + 1) // self.N_CHUNKS
+        ow = self._offset(keys[0]) + r0 * cols
+        orr = self._offset(keys[1]) + r0 * cols if len(keys) > 1 else -1
+        return ow, orr, (r1 - r0) * cols
+
+    def rest_ranges(self):
+        cuts = sorted((self._offset(k), self._offset(k) + self.sd[k].numel()) for k in self._last_weight_keys())
+        out, pos = [], 0
+        for lo, hi in cuts:
+            if lo > pos: out.append((pos, lo))
+            pos = hi
+        if pos < self.flat.numel(): out.append((pos, self.flat.numel()))
+        return out
+
+    def step_staged_deferred(self, offset, B, global_offset, global_B):
+        self.step_staged(offset, B, global_offset, global_B, train=True, apply=False)
+        self._full = self.flat.clone()
+        for k in range(self.N_CHUNKS):   # the deferred kernel has not produced these yet: poison them
+            ow, orr, cnt = self.dw_chunk_range(k)
+            self.flat[ow:ow + cnt] = float("nan")
+            if orr >= 0: self.flat[orr:orr + cnt] = float("nan")
+
+    def dw_chunk(self, k):
+        ow, orr, cnt = self.dw_chunk_range(k)
+        self.flat[ow:ow + cnt] = self._full[ow:ow + cnt]
+        if orr >= 0: self.flat[orr:orr + cnt] = self._full[orr:orr + cnt]
+
     def apply(self):
         grads, o = OrderedDict(), 0
         for k in self.keys:
@@ -88,13 +133,14 @@ def _single_process(bayesian):
     return sd, float(np.mean(losses))
 
 
-def _worker(rank, world, port, bayesian, out):
+def _worker(rank, world, port, bayesian, overlap, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from opentf_amd.dp import DataParallel
     sd, X, y, order, gB, noise = _case(bayesian)
     eng = OracleEngine(sd, X, y, 10.0, 1.0, 1e-2, noise)
-    dp = DataParallel(eng)
+    dp = DataParallel(eng, overlap=overlap)
+    assert dp.n_chunks == (OracleEngine.N_CHUNKS if overlap else 0)
     mean_loss = dp.train_epoch(order, gB)
     eval_loss = dp.eval_epoch(order, gB)
     if rank == 0:
@@ -109,13 +155,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("bayesian", [False, True])
-def test_two_rank_data_parallel_equals_single_process(bayesian):
+@pytest.mark.parametrize("bayesian,overlap", [(False, False), (True, False), (False, True), (True, True)])
+def test_two_rank_data_parallel_equals_single_process(bayesian, overlap):
     ref_sd, ref_loss = _single_process(bayesian)
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bayesian, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bayesian, overlap, out)) for r in range(2)]
     for p in procs: p.start()
     mean_loss, eval_loss, sd = out.get(timeout=120)
     for p in procs:

@@ -202,3 +202,46 @@ def test_full_size_gather_properties():
     assert np.abs(C - (A + Bm)).max() < 1e-4
     sample = rng.integers(0, N, 2000)
     assert np.array_equal(A[sample], O.gather_meanpool_fast(ip, ix, T1, sample))  # bit-exact vs the oracle on a sample
+
+
+def test_pipelined_data_parallel_step_on_rccl_world1():
+    """The data-parallel step as the N-GPU bench runs it — deferred dW in expert chunks, asynchronous RCCL all-reduce of each chunk
+    on the engine-owned gradient buffer, then Adam — exercised on one GPU (world_size 1, the collective forced): it must leave
+    exactly the parameters of the plain single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    from opentf_amd import libntf
+    from opentf_amd.dp import DataParallel
+    from opentf_amd.synth import init_params, zipf_csr
+    M, S, N, B = 140_000, 5_000, 20_000, 600     # 3 expert chunks of 65 536
+    s_ip, s_ix = zipf_csr(N, S, 8.57, 1); m_ip, m_ix = zipf_csr(N, M, 3.06, 2)
+    table = np.random.default_rng(0).standard_normal((S, 128), dtype=np.float32)
+    sd = init_params([128, 128, M], True, 0)
+    order = np.random.default_rng(1).integers(0, N, 3 * B)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    os.environ["NTF_DP_FORCE_ALLREDUCE"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        stream = torch.cuda.Stream()
+        results = []
+        with torch.cuda.stream(stream):
+            for mode in ("plain", "pipelined"):
+                e = libntf.Engine([128, 128, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", seed=5,
+                                  stream=stream.cuda_stream)
+                e.set_skill_table(table); e.set_skill_csr((s_ip, s_ix)); e.set_member((m_ip, m_ix)); e.load_state_dict(sd)
+                if mode == "plain":
+                    loss = e.train_epoch(order, B)
+                else:
+                    dp = DataParallel(e)
+                    assert dp.force_allreduce and dp.n_chunks == 3 and len(dp._rest) == 3
+                    loss = dp.train_epoch(order, B)
+                results.append((loss, e.state_dict()))
+                e.close()
+        (la, pa), (lb, pb) = results
+        assert abs(la - lb) <= 1e-6 * abs(la)
+        for k in pa:
+            assert np.array_equal(pa[k], pb[k]), k
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("NTF_DP_FORCE_ALLREDUCE", None)
