@@ -124,7 +124,7 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
-                          lr=1e-3, seed=1234 + rank, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
+                          lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
                           fuse_adam=a.fuse_adam if world == 1 else 0)
         e.set_skill_table(ds["table"]); e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
         e.load_state_dict(init_params(dims, bayesian, 0))

@@ -369,6 +369,8 @@ struct StepCtx {
     const ntf_inject* inj = nullptr;
     uint64_t step = 0;
     bool train = false;
+    uint32_t row0 = 0;       // position of this shard's first row inside its global minibatch: device generators are keyed by the
+                             // GLOBAL row position, so a sharded step draws exactly what the single-process step would draw
     bool defer_dw = false;   // leave the output layer's dW kernel to ntf_dw_chunk (data-parallel overlap with the all-reduce)
     bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
 };
@@ -397,6 +399,7 @@ static SignSpec sign_spec(ntf_engine* e, const StepCtx& c, int layer, int tensor
     const float* h = c.inj ? (tensor == T_S_IN ? c.inj->s_in[layer] : c.inj->s_out[layer]) : nullptr;
     s.inj = h ? inj : nullptr;
     make_key(e, c.step, layer, tensor, s.k0, s.k1);
+    s.k0 += c.row0 * 0x9E3779B1u;  // sign_word(k0 + row0*phi, k1, r, .) == sign_word(k0, k1, r + row0, .): shifts the row index, kernels unchanged
     return s;
 }
 static NormalSpec normal_spec(ntf_engine* e, const StepCtx& c, int layer, int tensor) {
@@ -500,11 +503,11 @@ static int sample_negatives(ntf_engine* e, const StepCtx& c) {
     uint32_t k0, k1; make_key(e, c.step, 0, T_NEG, k0, k1);
     const int M = e->cfg.dims[e->L];
     if (e->cfg.nsd == NTF_NSD_UNIFORM) {
-        launch_ns_uniform(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, k0, k1, (uint32_t)c.step, e->d_neg);
+        launch_ns_uniform(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
     } else if (e->cfg.nsd == NTF_NSD_UNIGRAM) {
         if (!e->al_prob) FAIL(e, NTF_ESTATE, "unigram table not set (ntf_set_unigram)");
         launch_ns_alias(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, e->al_prob, e->al_alias, e->al_weight, e->al_total,
-                        k0, k1, (uint32_t)c.step, e->d_neg);
+                        k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
     } else FAIL(e, NTF_EINVAL, "bad nsd");
     return NTF_OK;
 }
@@ -709,7 +712,7 @@ static int read_loss(ntf_engine* e, float* loss_out) {
 }
 
 static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t global_B, const ntf_inject* inj, float* loss_out, bool train,
-                       bool apply, bool rows_on_device, const int64_t* global_rows_host, int n_global, bool defer_dw = false) {
+                       bool apply, bool rows_on_device, const int64_t* global_rows_host, int n_global, bool defer_dw = false, uint32_t row0 = 0) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     int r;
@@ -718,6 +721,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
     c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
     c.defer_dw = defer_dw && train && !apply && fused_ok(e);
+    c.row0 = row0;
     e->pend_valid = false;
     if ((r = stage_rows(e, rows, B, rows_on_device, &c.rows_dev))) return r;
     if ((r = stage_all_inj(e, c))) return r;
@@ -770,7 +774,8 @@ extern "C" int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t
     if (offset < 0 || B < 1 || offset + B > n || global_offset < 0 || global_offset + global_B > n || offset < global_offset ||
         offset + B > global_offset + global_B)
         FAIL(e, NTF_EINVAL, "step_staged: shard / batch outside the staged order");
-    return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, train != 0, apply != 0, true, e->h_order.data() + global_offset, global_B);
+    return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, train != 0, apply != 0, true, e->h_order.data() + global_offset, global_B,
+                       false, (uint32_t)(offset - global_offset));
 }
 
 extern "C" int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, float* loss_out) {
@@ -779,7 +784,8 @@ extern "C" int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B
     if (offset < 0 || B < 1 || offset + B > n || global_offset < 0 || global_offset + global_B > n || offset < global_offset ||
         offset + B > global_offset + global_B)
         FAIL(e, NTF_EINVAL, "step_staged_deferred: shard / batch outside the staged order");
-    return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, true, false, true, e->h_order.data() + global_offset, global_B, true);
+    return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, true, false, true, e->h_order.data() + global_offset, global_B, true,
+                       (uint32_t)(offset - global_offset));
 }
 static int dw_chunk_span(ntf_engine* e, int k, int64_t& off_w, int64_t& off_r, int64_t& cnt, int& wg_begin) {
     const LayerInfo& li = e->layers[e->L - 1];

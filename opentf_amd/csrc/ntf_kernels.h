@@ -75,12 +75,12 @@ void launch_bias_grad(hipStream_t st, const float* dZ, int64_t ld, int B, int N,
 
 // uniform negatives: ns distinct columns per row among the row's non-members (src/mdl/fnn.py:48-56)
 void launch_ns_uniform(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr,
-                       const int32_t* m_indices, uint32_t k0, uint32_t k1, uint32_t step, int64_t* out);
+                       const int32_t* m_indices, uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* out);
 // weighted negatives by alias table (src/mdl/fnn.py:58-72), fallback to uniform over all columns when the
 // row's negatives have zero total weight
 void launch_ns_alias(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr,
                      const int32_t* m_indices, const float* prob, const int32_t* alias, const double* weight,
-                     double total_weight, uint32_t k0, uint32_t k1, uint32_t step, int64_t* out);
+                     double total_weight, uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* out);
 
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2_sqrt);

@@ -417,7 +417,7 @@ __device__ __forceinline__ bool is_member(const int32_t* mi, int npos, int c) {
 }
 
 __global__ void k_ns_uniform(const int64_t* __restrict__ rows, int B, int M, int ns, const int64_t* __restrict__ m_indptr,
-                             const int32_t* __restrict__ m_indices, uint32_t k0, uint32_t k1, uint32_t step, int64_t* __restrict__ out) {
+                             const int32_t* __restrict__ m_indices, uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     const int64_t team = rows[i];
@@ -428,7 +428,7 @@ __global__ void k_ns_uniform(const int64_t* __restrict__ rows, int B, int M, int
     for (int q = 0; q < ns; ++q) {
         int pick = -1;
         for (int tries = 0; tries < 4096 && pick < 0; ++tries) {
-            const uint4 r = philox4x32(make_uint4((uint32_t)i, ctr++, step, 0x4e533031u), make_uint2(k0, k1));
+            const uint4 r = philox4x32(make_uint4((uint32_t)i + row0, ctr++, step, 0x4e533031u), make_uint2(k0, k1));
             const uint32_t cand[4] = {r.x, r.y, r.z, r.w};
             for (int u = 0; u < 4 && pick < 0; ++u) {
                 const int c = (int)__umulhi(cand[u], (uint32_t)M);
@@ -453,13 +453,13 @@ __global__ void k_ns_uniform(const int64_t* __restrict__ rows, int B, int M, int
     }
 }
 void launch_ns_uniform(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
-                       uint32_t k0, uint32_t k1, uint32_t step, int64_t* out) {
-    hipLaunchKernelGGL(k_ns_uniform, dim3((B + 63) / 64), dim3(64), 0, st, rows, B, M, ns, m_indptr, m_indices, k0, k1, step, out);
+                       uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* out) {
+    hipLaunchKernelGGL(k_ns_uniform, dim3((B + 63) / 64), dim3(64), 0, st, rows, B, M, ns, m_indptr, m_indices, k0, k1, step, row0, out);
 }
 
 __global__ void k_ns_alias(const int64_t* __restrict__ rows, int B, int M, int ns, const int64_t* __restrict__ m_indptr,
                            const int32_t* __restrict__ m_indices, const float* __restrict__ prob, const int32_t* __restrict__ alias,
-                           const double* __restrict__ weight, double total_weight, uint32_t k0, uint32_t k1, uint32_t step,
+                           const double* __restrict__ weight, double total_weight, uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0,
                            int64_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
@@ -474,7 +474,7 @@ __global__ void k_ns_alias(const int64_t* __restrict__ rows, int B, int M, int n
     for (int q = 0; q < ns; ++q) {
         int pick = -1;
         for (int tries = 0; tries < 8192 && pick < 0; ++tries) {
-            const uint4 r = philox4x32(make_uint4((uint32_t)i, ctr++, step, 0x4e533032u), make_uint2(k0, k1));
+            const uint4 r = philox4x32(make_uint4((uint32_t)i + row0, ctr++, step, 0x4e533032u), make_uint2(k0, k1));
             for (int u = 0; u < 2 && pick < 0; ++u) {
                 const uint32_t a = u ? r.z : r.x, b = u ? r.w : r.y;
                 int c = (int)__umulhi(a, (uint32_t)M);
@@ -500,9 +500,9 @@ __global__ void k_ns_alias(const int64_t* __restrict__ rows, int B, int M, int n
 }
 void launch_ns_alias(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
                      const float* prob, const int32_t* alias, const double* weight, double total_weight, uint32_t k0, uint32_t k1,
-                     uint32_t step, int64_t* out) {
+                     uint32_t step, uint32_t row0, int64_t* out) {
     hipLaunchKernelGGL(k_ns_alias, dim3((B + 63) / 64), dim3(64), 0, st, rows, B, M, ns, m_indptr, m_indices, prob, alias, weight,
-                       total_weight, k0, k1, step, out);
+                       total_weight, k0, k1, step, row0, out);
 }
 
 // =====================================================================================

@@ -158,6 +158,28 @@ def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian):
         assert np.array_equal(pa[k], pc[k]), k  # mode 2 runs the same Adam kernel on the same gradients, only elsewhere in time
 
 
+@pytest.mark.parametrize("nsd", ["uniform", "unigram", "unigram_b"])
+def test_sharded_staged_steps_draw_what_the_single_process_step_draws(nsd):
+    """Data-parallel contract with the NATIVE generators: eps is keyed by (seed, step, element), signs and sampled negatives by the
+    row's position inside the GLOBAL minibatch, so two ranks' shards (same seed, same step) sum to the single-process gradient."""
+    sd, X, y = _bnn_case(64, [128], 700, 96, 11)
+    order = np.random.default_rng(2).permutation(96)
+    freq = y.numpy().sum(0) / 96.0
+    def mk():
+        e = _engine([64, 128, 700], bayesian=True, max_batch=96, ns=4, nsd=nsd, seed=77)
+        e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
+        if nsd == "unigram": e.set_unigram(freq)
+        e.stage_order(order); return e
+    full, a, b = mk(), mk(), mk()
+    lf = full.step_staged(0, 96, 0, 96, train=True, apply=False, want_loss=True); gf = full.grads()
+    la = a.step_staged(0, 40, 0, 96, train=True, apply=False, want_loss=True)
+    lb = b.step_staged(40, 56, 0, 96, train=True, apply=False, want_loss=True)
+    assert abs((la + lb) - lf) <= 1e-5 * abs(lf)
+    ga, gb = a.grads(), b.grads()
+    for k in gf:
+        assert _rel(ga[k] + gb[k], gf[k]) < 2e-4, (k, _rel(ga[k] + gb[k], gf[k]))
+
+
 def test_split_backward_equals_train_step():
     """ntf_backward over two row shards with global_B, gradients summed == one full-batch gradient."""
     sd, X, y = _bnn_case(32, [32], 200, 24, 9)
