@@ -158,6 +158,16 @@ int ntf_kernel_times(ntf_engine* e, int enable, const char** names, double* ms, 
 int ntf_k_gemm_f32(void* stream, int m, int n, int k, const float* A, int64_t sam, int64_t sak,
                    const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc);
 
+/* ---- ranking metrics of the eval stage on the device (next row after the hot path)            src/evl/metric.py:5-35,44-73
+ * topk_idx [n, K]: expert ids ranked by decreasing score (ntf_forward_topk order).  The truth / required-skill row of instance i is
+ * rows[i] (NULL: i) of the CSR.  out_metrics [n, 5*n_cut] = P, recall, ndcg_cut, map_cut, success, each over the cutoffs (trec_eval
+ * definitions, binary relevance);  out_cov [n, n_cut] = |skills of the top-k experts ∩ required| / |required|. */
+int ntf_rank_metrics(int device, const int32_t* topk_idx, int64_t n, int32_t K, const int64_t* truth_indptr, const int32_t* truth_indices,
+                     int64_t n_truth_rows, const int64_t* rows, const int32_t* cutoffs, int32_t n_cut, float* out_metrics);
+int ntf_skill_coverage(int device, const int32_t* topk_idx, int64_t n, int32_t K, const int64_t* skill_indptr, const int32_t* skill_indices,
+                       int64_t n_skill_rows, const int64_t* rows, const int64_t* cov_indptr, const int32_t* cov_indices, int64_t n_experts,
+                       const int32_t* cutoffs, int32_t n_cut, float* out_cov);
+
 /* device generators behind Flipout's eps / signs (dev_out = device pointers), for statistical tests */
 int ntf_k_fill_normal(void* stream, uint64_t seed, uint64_t step, int layer, int64_t n, float* dev_out);
 int ntf_k_fill_sign(void* stream, uint64_t seed, uint64_t step, int layer, int rows, int cols, float* dev_out);

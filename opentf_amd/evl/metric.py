@@ -1,0 +1,103 @@
+"""Mirror of the reference's `evl.metric` (src/evl/metric.py) with the per-instance work on the MI355X.
+
+Same function names, arguments and returned DataFrames as the reference (`calculate_metrics` 5-35, `calculate_skill_coverage`
+44-73); the reference builds python dicts for pytrec_eval row by row, here the ranked top-K lists go through
+`ntf_rank_metrics` / `ntf_skill_coverage` of libopentf_amd.so.  `calculate_auc_roc` stays sklearn on the host, as in the reference.
+Ties in the scores are ranked by ascending expert id (trec_eval: descending document name) — irrelevant for real-valued model
+outputs, stated here because it is the one place the two can differ.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+TREC = ("P", "recall", "ndcg_cut", "map_cut", "success")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ranked_topk(Y_, k):
+    """[n, k] expert ids by decreasing score (stable: ascending id among equal scores), from a dense array or a scipy CSR."""
+    n = Y_.shape[0]
+    if sp.issparse(Y_):
+        Y_ = sp.csr_matrix(Y_)
+        out = np.zeros((n, k), dtype=np.int32)
+        for i in range(n):
+            cols, vals = Y_.indices[Y_.indptr[i]:Y_.indptr[i + 1]], Y_.data[Y_.indptr[i]:Y_.indptr[i + 1]]
+            order = np.lexsort((cols, -vals))[:k]
+            got = cols[order]
+            if len(got) < k:  # fewer stored entries than k: the remaining (zero-score) experts follow in id order
+                rest = np.setdiff1d(np.arange(Y_.shape[1], dtype=np.int64), cols, assume_unique=False)[: k - len(got)]
+                got = np.concatenate([got, rest])
+            out[i] = got
+        return out
+    Y_ = np.asarray(Y_)
+    idx = np.argsort(-Y_, axis=1, kind="stable")[:, :k]
+    return np.ascontiguousarray(idx, dtype=np.int32)
+
+
+def _cutoffs(metrics, family):
+    for m in metrics:
+        if m.startswith(family + "_"):
+            return [int(x) for x in m[len(family) + 1:].split(",")]
+    return []
+
+
+def calculate_metrics(Y, Y_, topK=None, per_instance=False, metrics=("P_2,5", "recall_2,5", "ndcg_cut_2,5"), device=0):
+    import pandas as pd
+    from .. import libntf
+    assert Y.shape == Y_.shape, f"Shape mismatch between truth Y {Y.shape} vs preds Y_ {Y_.shape}!"
+    Y = sp.csr_matrix(Y); Y.sort_indices()
+    n, M = Y_.shape
+    fams = [f for f in TREC if _cutoffs(metrics, f)]
+    cuts = sorted({k for f in fams for k in _cutoffs(metrics, f)})
+    kmax = min(max(cuts), min(topK, M) if topK else M)
+    top = _ranked_topk(Y_, kmax)
+    ip, ix = np.ascontiguousarray(Y.indptr, dtype=np.int64), np.ascontiguousarray(Y.indices, dtype=np.int32)
+    cu = np.ascontiguousarray(cuts, dtype=np.int32)
+    out = np.zeros((n, 5 * len(cuts)), dtype=np.float32)
+    rc = libntf.lib().ntf_rank_metrics(int(device), _ptr(top), n, top.shape[1], _ptr(ip), _ptr(ix), n, None, _ptr(cu), len(cuts), _ptr(out))
+    if rc != 0:
+        raise libntf.NtfError(f"ntf_rank_metrics failed ({rc})")
+    cols, data = [], []
+    for f in fams:  # the reference's column order: family by family, each over its cutoffs
+        for k in _cutoffs(metrics, f):
+            cols.append(f"{f}_{k}"); data.append(out[:, TREC.index(f) * len(cuts) + cuts.index(k)].astype(np.float64))
+    df = pd.DataFrame(np.stack(data, axis=1), columns=cols, index=[f"q{i}" for i in range(n)])
+    df_mean = df.mean().to_frame("mean").rename_axis("metrics")
+    return (df if per_instance else None), df_mean
+
+
+def calculate_auc_roc(Y, Y_, curve=False):
+    from sklearn import metrics as skm
+    assert Y.shape == Y_.shape
+    dense = Y_.toarray() if sp.issparse(Y_) else np.asarray(Y_)
+    auc = skm.roc_auc_score(Y.toarray(), dense, average="micro", multi_class="ovr")
+    if curve:
+        fpr, tpr, _ = skm.roc_curve(Y.toarray().ravel(), dense.ravel())
+        return auc, (fpr, tpr)
+    return auc, None
+
+
+def calculate_skill_coverage(X, Y_, expertskillvecs, per_instance=False, topks="2,5,10", device=0):
+    import pandas as pd
+    from .. import libntf
+    assert X.shape[0] == Y_.shape[0]
+    X = sp.csr_matrix(X); X.sort_indices()
+    cov = sp.csr_matrix(expertskillvecs); cov.sort_indices()
+    cuts = [int(k) for k in topks.split(",")]
+    n, E = Y_.shape
+    top = _ranked_topk(Y_, min(max(cuts), E))
+    out = np.zeros((n, len(cuts)), dtype=np.float32)
+    cu = np.ascontiguousarray(cuts, dtype=np.int32)
+    xs, xi = np.ascontiguousarray(X.indptr, dtype=np.int64), np.ascontiguousarray(X.indices, dtype=np.int32)
+    cs, ci = np.ascontiguousarray(cov.indptr, dtype=np.int64), np.ascontiguousarray(cov.indices, dtype=np.int32)
+    rc = libntf.lib().ntf_skill_coverage(int(device), _ptr(top), n, top.shape[1], _ptr(xs), _ptr(xi), n, None, _ptr(cs), _ptr(ci), E, _ptr(cu), len(cuts), _ptr(out))
+    if rc != 0:
+        raise libntf.NtfError(f"ntf_skill_coverage failed ({rc})")
+    df = pd.DataFrame(out.astype(np.float64), columns=[f"skill_coverage_{k}" for k in cuts])
+    return df, df.mean().to_frame("mean").rename_axis("metrics")

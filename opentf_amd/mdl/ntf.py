@@ -86,8 +86,62 @@ class Ntf:
     def test(self, teamsvecs, splits, testcfg): pass
 
     def evaluate(self, teamsvecs, splits, evalcfg):
-        raise NotImplementedError("evaluate() is the reference's CPU metric stage (src/mdl/ntf.py:32-92); mount this plugin in the "
-                                  "reference tree (INTEGRATION.md) to inherit it")
+        """The reference's eval stage (src/mdl/ntf.py:32-92) with the per-instance metrics on the device (opentf_amd.evl.metric):
+        same inputs (the `.pred` files test() wrote), same outputs (`*.pred.eval.mean.csv`, `*.pred.eval.instance.csv`,
+        `{set}.pred.eval.mean.csv` with mean/std over folds).  Mounted in the reference tree the plugin inherits the reference's
+        own evaluate() instead."""
+        import re
+        import pandas as pd
+        import scipy.sparse
+        import torch
+        from ..evl import metric
+        assert os.path.isdir(self.output), f"No folder for {self.output} exist!"
+        y_test = teamsvecs["member"][splits["test"]]
+        trec = list(cfg_get(cfg_get(evalcfg, "metrics"), "trec") or [])
+        other = list(cfg_get(cfg_get(evalcfg, "metrics"), "other") or [])
+        per_instance = bool(cfg_get(evalcfg, "per_instance"))
+        for pred_set in (["test", "train", "valid"] if cfg_get(evalcfg, "on_train") else ["test"]):
+            fold_mean, mean_std = pd.DataFrame(), pd.DataFrame()
+            fold_inst = pd.DataFrame()
+            for foldidx in splits["folds"].keys():
+                Y = y_test if pred_set == "test" else teamsvecs["member"][splits["folds"][foldidx][pred_set]]
+                predfiles = [f"{self.output}/f{foldidx}.{pred_set}.pred"]
+                if cfg_get(evalcfg, "per_epoch"):
+                    predfiles += [f"{self.output}/{_}" for _ in os.listdir(self.output) if re.match(rf"f{foldidx}.{pred_set}.e\d+.pred$", _)]
+                for i, predfile in enumerate(sorted(sorted(predfiles), key=len)):
+                    Y_ = torch.load(predfile, map_location="cpu", weights_only=False)["y_pred"]
+                    if Y_.is_sparse:
+                        Y_ = Y_.coalesce()
+                        ind = Y_.indices().numpy()
+                        Y_ = scipy.sparse.csr_matrix((Y_.values().numpy(), (ind[0], ind[1])), shape=tuple(Y_.size()))
+                    else:
+                        Y_ = Y_.numpy()
+                    assert Y.shape == Y_.shape, f"Shape mismatch between truth Y {Y.shape} vs preds Y_ {Y_.shape}!"
+                    df, df_mean = pd.DataFrame(), pd.DataFrame()
+                    if trec:
+                        df, df_mean = metric.calculate_metrics(Y, Y_, cfg_get(evalcfg, "topK"), per_instance, trec)
+                    if [m for m in other if "aucroc" in m]:
+                        aucroc, _ = metric.calculate_auc_roc(Y, Y_)
+                        if df_mean.empty: df_mean = pd.DataFrame(columns=["mean"])
+                        df_mean.loc["aucroc"] = aucroc
+                    skc = [m for m in other if "skill_coverage" in m]
+                    if skc:
+                        X = teamsvecs["skill"] if scipy.sparse.issparse(teamsvecs["skill"]) else teamsvecs["original_skill"]
+                        X = X[splits["test"]] if pred_set == "test" else X[splits["folds"][foldidx][pred_set]]
+                        df_skc, df_mean_skc = metric.calculate_skill_coverage(X, Y_, teamsvecs["skillcoverage"], per_instance,
+                                                                               topks=skc[0].replace("skill_coverage_", ""))
+                        df = df_skc if (df is None or df.empty) else pd.concat([df.reset_index(drop=True), df_skc.reset_index(drop=True)], axis=1)
+                        df_mean = df_mean_skc if df_mean.empty else pd.concat([df_mean, df_mean_skc], axis=0)
+                    if per_instance: df.to_csv(f"{predfile}.eval.instance.csv", float_format="%.5f", index=False)
+                    df_mean.to_csv(f"{predfile}.eval.mean.csv")
+                    if i == 0:
+                        fold_mean = pd.concat([fold_mean, df_mean], axis=1)
+                        if per_instance: fold_inst = fold_inst.add(df, fill_value=0)
+            mean_std["mean"] = fold_mean.mean(axis=1)
+            mean_std["std"] = fold_mean.std(axis=1)
+            mean_std.to_csv(f"{self.output}/{pred_set}.pred.eval.mean.csv")
+            if per_instance:
+                fold_inst.truediv(len(splits["folds"].keys())).to_csv(f"{self.output}/{pred_set}.pred.eval.instance_mean.csv", index=False)
 
     def adila(self, teamsvecs, splits, faircfg):
         raise NotImplementedError("adila() is the reference's fairness stage (src/mdl/ntf.py:108-134); see INTEGRATION.md")

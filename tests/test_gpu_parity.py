@@ -348,3 +348,33 @@ def test_errors_are_reported_not_swallowed():
         e.train_step(np.array([0, 99]))      # row id out of range
     with pytest.raises(NtfError):
         e.set_member((np.array([0, 1]), np.array([20], np.int32)))  # column id out of range
+
+
+# ------------------------------------------------------------------------------------------ eval-stage metrics
+def test_device_ranking_metrics_match_committed_reference_results():
+    """opentf_amd.evl.metric (device kernels through the C ABI) against the reference's committed pytrec_eval / skill-coverage
+    per-instance tables for its own committed prediction files (tests/golden/g10_metrics.npz), and against the metric oracle."""
+    from opentf_amd.evl import metric
+    from oracle import metric_oracle as MO
+    g = golden("g10_metrics")
+    trec = ["P_2,5,10", "recall_2,5,10", "ndcg_cut_2,5,10", "map_cut_2,5,10", "success_2,5,10"]
+    for name in [str(n) for n in g["names"]]:
+        n, M, S = [int(v) for v in g[f"{name}.shape"]]
+        Y = scipy.sparse.csr_matrix((np.ones(len(g[f"{name}.truth_indices"]), np.uint8), g[f"{name}.truth_indices"], g[f"{name}.truth_indptr"]), shape=(n, M))
+        X = scipy.sparse.csr_matrix((np.ones(len(g[f"{name}.skill_indices"]), np.uint8), g[f"{name}.skill_indices"], g[f"{name}.skill_indptr"]), shape=(n, S))
+        cov = scipy.sparse.csr_matrix((np.ones(len(g[f"{name}.cov_indices"]), np.uint8), g[f"{name}.cov_indices"], g[f"{name}.cov_indptr"]), shape=(M, S))
+        yp = g[f"{name}.y_pred"]
+        df, df_mean = metric.calculate_metrics(Y, yp, 1000, True, trec)
+        dfc, dfc_mean = metric.calculate_skill_coverage(X, yp, cov, True, "2,5,10")
+        got = np.concatenate([df.values, dfc.values], axis=1)
+        assert list(df.columns) + list(dfc.columns) == [str(c) for c in g[f"{name}.columns"]]
+        ties = any(len(np.unique(r)) < len(r) for r in yp)
+        if not ties:  # equal scores are ranked differently by trec_eval (document name, descending)
+            np.testing.assert_allclose(got, g[f"{name}.expected"], atol=6e-6, err_msg=name)
+        np.testing.assert_allclose(df_mean["mean"].values, df.values.mean(0), rtol=1e-12)
+        # sparse (top-K) prediction files give the same result as dense ones
+        k = min(10, M)
+        idx = np.argsort(-yp, axis=1, kind="stable")[:, :k]
+        sparse_pred = scipy.sparse.csr_matrix((np.take_along_axis(yp, idx, 1).ravel(), idx.ravel(), np.arange(0, n * k + 1, k)), shape=(n, M))
+        df2, _ = metric.calculate_metrics(Y, sparse_pred, 1000, True, trec)
+        np.testing.assert_allclose(df2.values, df.values, atol=1e-7)
