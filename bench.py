@@ -128,6 +128,8 @@ def main():
                           fuse_adam=a.fuse_adam if world == 1 else 0)
         e.set_skill_table(ds["table"]); e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
         e.load_state_dict(init_params(dims, bayesian, 0))
+        if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
+            e.set_unigram(np.bincount(ds["member"][1], minlength=ds["M"]) / ds["N"])
         dp = DataParallel(e)
         gB = a.batch * world                                   # weak scaling: B teams per GPU
         rng = np.random.default_rng(7)

@@ -75,6 +75,9 @@ struct ntf_engine {
     bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
     // data-parallel pipelining: the output layer's dW kernel deferred by ntf_step_staged_deferred, launched by ntf_dw_chunk
     bool pend_valid = false; FusedDw pend; NormalSpec pend_eps_b; float pend_klw_b = 0.f; int pend_chunks = 0;
+    // unigram_b staging (sparse per-batch alias table)
+    std::vector<int32_t> ub_entries; void* ub_host[2] = {nullptr, nullptr}; void* ub_dev[2] = {nullptr, nullptr}; hipEvent_t ub_ev[2] = {nullptr, nullptr};
+    bool ub_used[2] = {false, false}; size_t ub_cap = 0; int ub_slot = 0, ub_nsup = 0; double ub_total = 0;
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
 };
@@ -218,6 +221,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
+    for (int k = 0; k < 2; ++k) { if (e->ub_host[k]) hipHostFree(e->ub_host[k]); if (e->ub_dev[k]) hipFree(e->ub_dev[k]); if (e->ub_ev[k]) hipEventDestroy(e->ub_ev[k]); }
     if (e->st2) { hipStreamSynchronize(e->st2); hipStreamDestroy(e->st2); hipEventDestroy(e->ev_chunk); hipEventDestroy(e->ev_side); }
     if (e->own_stream && e->st) hipStreamDestroy(e->st);
     delete e;
@@ -508,21 +512,59 @@ static int sample_negatives(ntf_engine* e, const StepCtx& c) {
         if (!e->al_prob) FAIL(e, NTF_ESTATE, "unigram table not set (ntf_set_unigram)");
         launch_ns_alias(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, e->al_prob, e->al_alias, e->al_weight, e->al_total,
                         k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
+    } else if (e->cfg.nsd == NTF_NSD_UNIGRAM_B) {
+        const char* d = static_cast<const char*>(e->ub_dev[e->ub_slot]);
+        const size_t n = (size_t)e->ub_nsup;
+        launch_ns_alias_sparse(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, reinterpret_cast<const int32_t*>(d),
+                               reinterpret_cast<const float*>(d + n * 8), reinterpret_cast<const int32_t*>(d + n * 4),
+                               reinterpret_cast<const float*>(d + n * 12), e->ub_nsup, e->ub_total, k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
     } else FAIL(e, NTF_EINVAL, "bad nsd");
     return NTF_OK;
 }
 
-// unigram_b (src/mdl/fnn.py:74-76): per-batch expert frequency y.sum(0)/B over the GLOBAL batch rows (host ids)
+// unigram_b (src/mdl/fnn.py:74-76): per-batch expert frequency y.sum(0)/B over the GLOBAL batch rows (host ids).  The table has
+// support only on the batch's experts: sort + count them on the host (a few thousand entries), alias over the support, staged through
+// two pinned buffers so that the host may prepare step t+1 while step t runs.
 static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int n) {
-    const int M = e->cfg.dims[e->L];
-    std::vector<double> w(M, 0.0);
+    std::vector<int32_t>& ent = e->ub_entries;
+    ent.clear();
     for (int i = 0; i < n; ++i) {
         const int64_t t = global_rows_host[i];
-        for (int64_t p = e->h_m_indptr[t]; p < e->h_m_indptr[t + 1]; ++p) w[e->h_m_indices[p]] += 1.0;
+        for (int64_t p = e->h_m_indptr[t]; p < e->h_m_indptr[t + 1]; ++p) ent.push_back(e->h_m_indices[p]);
     }
+    std::sort(ent.begin(), ent.end());
+    std::vector<int32_t> cols; std::vector<double> w;
     const float invn = 1.0f / (float)n;  // the reference keeps this table in f32
-    for (int c = 0; c < M; ++c) w[c] = (double)((float)w[c] * invn);
-    return upload_alias(e, w.data(), M);
+    for (size_t i = 0; i < ent.size();) {
+        size_t j = i; while (j < ent.size() && ent[j] == ent[i]) ++j;
+        cols.push_back(ent[i]); w.push_back((double)((float)(j - i) * invn));
+        i = j;
+    }
+    const int nsup = (int)cols.size();
+    std::vector<float> prob; std::vector<int32_t> alias; double total = 0;
+    build_alias(w.data(), nsup, prob, alias, total);
+    // staging: [cols | alias | prob | weight] per slot
+    const int slot = e->ub_slot ^= 1;
+    const size_t need = (size_t)std::max(nsup, 1) * 16;
+    if (e->ub_cap < need) {
+        HIPCHK(e, hipStreamSynchronize(e->st));
+        for (int k = 0; k < 2; ++k) { if (e->ub_host[k]) hipHostFree(e->ub_host[k]); if (e->ub_dev[k]) hipFree(e->ub_dev[k]); e->ub_host[k] = nullptr; e->ub_dev[k] = nullptr; }
+        e->ub_cap = need * 2;
+        for (int k = 0; k < 2; ++k) { HIPCHK(e, hipHostMalloc(&e->ub_host[k], e->ub_cap, hipHostMallocDefault)); HIPCHK(e, hipMalloc(&e->ub_dev[k], e->ub_cap)); }
+        if (!e->ub_ev[0]) { HIPCHK(e, hipEventCreateWithFlags(&e->ub_ev[0], hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ub_ev[1], hipEventDisableTiming)); }
+        e->ub_used[0] = e->ub_used[1] = false;
+    }
+    if (e->ub_used[slot]) HIPCHK(e, hipEventSynchronize(e->ub_ev[slot]));  // the copy that last read this pinned buffer has completed
+    char* h = static_cast<char*>(e->ub_host[slot]);
+    std::memcpy(h, cols.data(), (size_t)nsup * 4);
+    std::memcpy(h + (size_t)nsup * 4, alias.data(), (size_t)nsup * 4);
+    std::memcpy(h + (size_t)nsup * 8, prob.data(), (size_t)nsup * 4);
+    float* hw = reinterpret_cast<float*>(h + (size_t)nsup * 12);
+    for (int k = 0; k < nsup; ++k) hw[k] = (float)w[k];
+    HIPCHK(e, hipMemcpyAsync(e->ub_dev[slot], h, (size_t)nsup * 16, hipMemcpyHostToDevice, e->st));
+    HIPCHK(e, hipEventRecord(e->ub_ev[slot], e->st));
+    e->ub_used[slot] = true; e->ub_nsup = nsup; e->ub_total = total;
+    return NTF_OK;
 }
 
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
@@ -729,11 +771,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
         if (!global_rows_host) FAIL(e, NTF_EINVAL, "unigram_b needs the batch rows on the host");
         if ((r = set_batch_unigram(e, global_rows_host, n_global))) return r;
     }
-    const int saved = e->cfg.nsd;
-    if (saved == NTF_NSD_UNIGRAM_B) e->cfg.nsd = NTF_NSD_UNIGRAM;
-    r = run_step(e, c, true);
-    e->cfg.nsd = saved;
-    if (r) return r;
+    if ((r = run_step(e, c, true))) return r;
     e->last_B = B; e->last_global_B = global_B;
     if (train && apply && (r = apply_adam(e))) return r;
     if ((r = read_loss(e, loss_out))) return r;

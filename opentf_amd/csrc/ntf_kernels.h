@@ -82,6 +82,11 @@ void launch_ns_alias(hipStream_t st, const int64_t* rows, int B, int M, int ns, 
                      const int32_t* m_indices, const float* prob, const int32_t* alias, const double* weight,
                      double total_weight, uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* out);
 
+// the same over a sparse support (unigram_b: the experts of the current batch): cols sorted ascending, tables indexed by support slot
+void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
+                            const int32_t* cols, const float* prob, const int32_t* alias, const float* weight, int nsup, double total_weight,
+                            uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* out);
+
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2_sqrt);
 void launch_fill(hipStream_t st, float* p, int64_t n, float v);

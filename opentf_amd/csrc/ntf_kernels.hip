@@ -505,6 +505,61 @@ void launch_ns_alias(hipStream_t st, const int64_t* rows, int B, int M, int ns, 
                        total_weight, k0, k1, step, row0, out);
 }
 
+// unigram_b: the per-batch frequency table has support only on the experts of the batch (<= a few thousand of M): the alias
+// table is built over that support; cols[] maps a support slot to its expert (sorted, so a row's positives are found by bisection).
+__global__ void k_ns_alias_sparse(const int64_t* __restrict__ rows, int B, int M, int ns, const int64_t* __restrict__ m_indptr,
+                                  const int32_t* __restrict__ m_indices, const int32_t* __restrict__ cols, const float* __restrict__ prob,
+                                  const int32_t* __restrict__ alias, const float* __restrict__ weight, int nsup, double total_weight,
+                                  uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t team = rows[i];
+    const int32_t* mi = m_indices + m_indptr[team];
+    const int npos = (int)(m_indptr[team + 1] - m_indptr[team]);
+    int64_t* o = out + (int64_t)i * ns;
+    double negw = total_weight;
+    for (int p = 0; p < npos; ++p) {
+        int lo = 0, hi = nsup;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cols[mid] < mi[p]) lo = mid + 1; else hi = mid; }
+        if (lo < nsup && cols[lo] == mi[p]) negw -= (double)weight[lo];
+    }
+    const bool fallback = !(negw > 1e-9 * total_weight) || nsup == 0;  // every sampling weight sits on the row's members (fnn.py:67-69)
+    uint32_t ctr = 0;
+    for (int q = 0; q < ns; ++q) {
+        int pick = -1;
+        for (int tries = 0; tries < 8192 && pick < 0; ++tries) {
+            const uint4 r = philox4x32(make_uint4((uint32_t)i + row0, ctr++, step, 0x4e533033u), make_uint2(k0, k1));
+            for (int u = 0; u < 2 && pick < 0; ++u) {
+                const uint32_t a = u ? r.z : r.x, b = u ? r.w : r.y;
+                int c; bool bad;
+                if (fallback) { c = (int)__umulhi(a, (uint32_t)M); bad = false; }  // uniform over ALL columns, members included
+                else {
+                    int sl = (int)__umulhi(a, (uint32_t)nsup);
+                    if (u01(b) >= prob[sl]) sl = alias[sl];
+                    c = cols[sl];
+                    bad = is_member(mi, npos, c) || !(weight[sl] > 0.f);
+                }
+                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) pick = c;
+            }
+        }
+        if (pick < 0) {  // fewer than ns admissible experts: take any unused column (multinomial would raise)
+            for (int c = 0; c < M && pick < 0; ++c) {
+                bool bad = false;
+                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) pick = c;
+            }
+        }
+        o[q] = pick;
+    }
+}
+void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
+                            const int32_t* cols, const float* prob, const int32_t* alias, const float* weight, int nsup, double total_weight,
+                            uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* out) {
+    hipLaunchKernelGGL(k_ns_alias_sparse, dim3((B + 63) / 64), dim3(64), 0, st, rows, B, M, ns, m_indptr, m_indices, cols, prob, alias, weight,
+                       nsup, total_weight, k0, k1, step, row0, out);
+}
+
 // =====================================================================================
 // Adam (torch.optim.Adam defaults, src/mdl/fnn.py:104,139) over the flat parameter buffer
 // =====================================================================================

@@ -254,6 +254,44 @@ def test_native_uniform_sampler_invariants_and_distribution():
     assert (np.abs(hits[1:] - expected) < 6 * np.sqrt(expected) + 5).all()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_native_unigram_b_sampler_draws_from_the_batch_support(fused):
+    """unigram_b (src/mdl/fnn.py:59-76): negatives of a row come from the experts of the CURRENT batch, minus the row's own, with
+    probability proportional to their batch frequency.  Identity first layer + one-hot inputs make column i of dW[out] row i's dz."""
+    B, M, ns = 64, 300, 4
+    rng = np.random.default_rng(3)
+    y = np.zeros((B, M), np.float32)
+    hot = np.arange(10)                       # ten frequent experts ...
+    for i in range(B):
+        y[i, rng.choice(hot, 2, replace=False)] = 1
+        y[i, 10 + (i % 40)] = 1               # ... and forty rare ones; columns >= 50 never occur in the batch
+    sd = {"layers.0.weight": torch.eye(B), "layers.0.bias": torch.zeros(B), "layers.1.weight": torch.zeros(M, B), "layers.1.bias": torch.zeros(M)}
+    e = _engine([B, B, M], max_batch=B, ns=ns, nsd="unigram_b", tpw=1.0, tnw=0.0, seed=5, fused=fused)
+    e.load_state_dict(sd); e.set_dense_input(np.eye(B, dtype=np.float32)); e.set_member(_csr_from_dense(y))
+    hits = np.zeros(M)
+    for it in range(60):
+        e.backward(np.arange(B))
+        dw = e.grads()["layers.1.weight"]      # [M, B]
+        for i in range(B):
+            picked = np.nonzero(dw[:, i] > 0)[0]
+            assert len(picked) == ns, (i, picked)
+            assert (y[i, picked] == 0).all() and (picked < 50).all()
+            hits[picked] += 1
+    freq = y.sum(0)
+    assert hits[50:].sum() == 0
+    assert hits[:10].min() > 2 * hits[10:50].max()          # frequent experts dominate
+    ratio = (hits[:10] / freq[:10]).mean() / (hits[10:50] / freq[10:50]).mean()
+    assert 0.5 < ratio < 1.3                                 # ~proportional (without-replacement draws flatten it a little)
+    # single-row batch: every weighted expert is a member -> the reference falls back to uniform over all columns
+    e1 = _engine([B, B, M], max_batch=B, ns=ns, nsd="unigram_b", tpw=1.0, tnw=0.0, seed=5, fused=fused)
+    e1.load_state_dict(sd); e1.set_dense_input(np.eye(B, dtype=np.float32)); e1.set_member(_csr_from_dense(y))
+    seen = set()
+    for it in range(50):
+        e1.backward(np.array([it % B]))
+        seen.update(np.nonzero(e1.grads()["layers.1.weight"][:, it % B] > 0)[0].tolist())
+    assert max(seen) >= 50 and len(seen) > 100
+
+
 def test_native_normal_and_sign_statistics():
     from opentf_amd import libntf
     n = 1 << 22
