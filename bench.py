@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--model", default="bnn", choices=["bnn", "fnn"])
     ap.add_argument("--nsd", default="uniform")
+    ap.add_argument("--input", default="meanpool", choices=["meanpool", "multihot"],
+                    help="meanpool: team2vec table rows averaged over the team's skills (config 2); multihot: the 0/1 skill row itself, D=S (config 3)")
     ap.add_argument("--rows", type=int, default=0, help="override the number of teams (debug)")
     ap.add_argument("--experts", type=int, default=0, help="override the number of experts (debug)")
     ap.add_argument("--no-fused", action="store_true")
@@ -87,7 +89,7 @@ def pmc_traffic(family, a, ds):
     as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
     path = os.path.join(ROOT, "profiles", "r1_c_pmc_traffic_and_sq.json")
     if not (os.path.exists(path) and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
-            and not a.rows and not a.experts):
+            and a.input == "meanpool" and not a.rows and not a.experts):
         return None
     key = {"out_fused_fwd_loss_dh": "k_out_fwd", "out_fused_dw_adam": "k_out_dw"}.get(family)
     if not key:
@@ -119,14 +121,16 @@ def main():
 
     bayesian = a.model == "bnn"
     ds = make_dataset(a.dataset, d=a.d, seed=0, n_rows=a.rows or None, n_experts=a.experts or None)
-    dims = [a.d, a.hidden, ds["M"]]
+    multihot = a.input == "multihot"
+    dims = [ds["S"] if multihot else a.d, a.hidden, ds["M"]]
     cfg = {"ns": 5, "nsd": a.nsd, "tpw": 10.0, "tnw": 1.0, "lr": 1e-3}
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
+        e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
                           lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
                           fuse_adam=a.fuse_adam if world == 1 else 0)
-        e.set_skill_table(ds["table"]); e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
+        if not multihot: e.set_skill_table(ds["table"])
+        e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
         e.load_state_dict(init_params(dims, bayesian, 0))
         if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
             e.set_unigram(np.bincount(ds["member"][1], minlength=ds["M"]) / ds["N"])
@@ -186,13 +190,14 @@ def main():
         "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{a.dataset} mt10.ts2 shapes N={ds['N']} S={ds['S']} M={M}; {a.model} (Flipout) on mean-pooled skill table d={a.d}, "
+        "config": {"workload": f"{a.dataset} mt10.ts2 shapes N={ds['N']} S={ds['S']} M={M}; {a.model}{' (Flipout)' if bayesian else ''} on " +
+                               (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
                                f"h=[{H}], b={B}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3", "global_batch": gB, "parallelism": f"dp{world}"},
         "roofline": roof, "cpu_baseline": None, "mean_loss": mean_loss,
         "kernel_ms_per_step": {f: round(v[0] / a.steps, 4) for f, v in times.items() if v[1] > 0},
     }
     if gather: out["roofline_gather"] = gather
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and not multihot:   # the CPU leg times the headline (mean-pool) configuration only
         out["cpu_baseline"] = cpu_baseline(ds, dims, bayesian, cfg)
     print(json.dumps(out))
     if world > 1: dist.destroy_process_group()

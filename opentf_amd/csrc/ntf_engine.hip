@@ -22,10 +22,10 @@ struct LayerInfo {
 };
 
 enum Fam { F_GATHER = 0, F_GEMM_HIDDEN, F_FLIPOUT_OPERAND, F_OUT_FWD, F_LOSS, F_OUT_BWD_DW, F_OUT_BWD_DA, F_BIAS_GRAD,
-           F_FLIPOUT_FINAL, F_KL, F_ADAM, F_SAMPLER, F_INFER, F_OUT_FUSED_FWD, F_OUT_FUSED_DW, F_OUT_FUSED_AUX, F_COUNT };
+           F_FLIPOUT_FINAL, F_KL, F_ADAM, F_SAMPLER, F_INFER, F_OUT_FUSED_FWD, F_OUT_FUSED_DW, F_OUT_FUSED_AUX, F_MULTIHOT, F_COUNT };
 static const char* kFamNames[F_COUNT] = {"gather", "gemm_hidden", "flipout_operand", "out_fwd_gemm", "loss", "out_bwd_dw_gemm",
                                          "out_bwd_da_gemm", "bias_grad", "flipout_grad_finalize", "kl", "adam", "sampler", "infer",
-                                         "out_fused_fwd_loss_dh", "out_fused_dw_adam", "out_fused_prep_special"};
+                                         "out_fused_fwd_loss_dh", "out_fused_dw_adam", "out_fused_prep_special", "multihot_layer0"};
 
 struct TimeRec { int fam; hipEvent_t a, b; };
 constexpr int64_t kGemmSlabFloats = 8 << 20;  // 32 MiB
@@ -153,6 +153,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (!cfg || cfg->abi_version != NTF_ABI_VERSION) { g_create_error = "bad config / abi_version"; return NTF_EINVAL; }
     if (cfg->n_layers < 1 || cfg->n_layers > NTF_MAX_LAYERS || cfg->max_batch < 1 || cfg->ns < 0) { g_create_error = "bad n_layers/max_batch/ns"; return NTF_EINVAL; }
     for (int i = 0; i <= cfg->n_layers; ++i) if (cfg->dims[i] < 1) { g_create_error = "bad dims"; return NTF_EINVAL; }
+    if (cfg->input_mode == NTF_INPUT_MULTIHOT && cfg->n_layers < 2) { g_create_error = "multi-hot input needs a hidden layer (src/mdl/fnn.py:17-19)"; return NTF_EINVAL; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device: the engine has no CPU fallback"; return NTF_EHIP; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return NTF_EINVAL; }
@@ -182,7 +183,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     A(dmalloc(e, &e->P, off)); A(dmalloc(e, &e->G, off)); A(dmalloc(e, &e->M1, off)); A(dmalloc(e, &e->V2, off));
     A(dmalloc(e, &e->d_rows, B)); A(dmalloc(e, &e->d_neg, (int64_t)B * std::max(1, cfg->ns)));
     e->act.assign(e->L, nullptr);
-    for (int l = 0; l < e->L; ++l) A(dmalloc(e, &e->act[l], (int64_t)B * cfg->dims[l]));
+    for (int l = (cfg->input_mode == NTF_INPUT_MULTIHOT ? 1 : 0); l < e->L; ++l) A(dmalloc(e, &e->act[l], (int64_t)B * cfg->dims[l]));  // multi-hot X is never dense
     A(dmalloc(e, &e->Zout, (int64_t)B * M)); A(dmalloc(e, &e->dZout, (int64_t)((M + 255) / 256 * 256) * fused_ldb(B)));
     if (e->maxhid) { A(dmalloc(e, &e->Zh, (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[0], (int64_t)B * e->maxhid)); A(dmalloc(e, &e->dAct[1], (int64_t)B * e->maxhid)); }
     e->Wp.assign(e->L, nullptr); e->bp.assign(e->L, nullptr);
@@ -447,11 +448,11 @@ static int stage_all_inj(ntf_engine* e, const StepCtx& c) {
 
 // X = act[0] for the batch (A1/A2 of SURVEY.md §8a)
 static int make_input(ntf_engine* e, const StepCtx& c) {
+    if (e->cfg.input_mode == NTF_INPUT_MULTIHOT) return NTF_OK;  // layer 0 reads the skill CSR itself
     Scope t(e, F_GATHER);
     const int D = e->cfg.dims[0];
     if (e->cfg.input_mode == NTF_INPUT_DENSE) launch_gather_dense_rows(e->st, e->Xall, D, c.rows_dev, c.B, e->act[0]);
-    else if (e->cfg.input_mode == NTF_INPUT_MEANPOOL) launch_gather_meanpool(e->st, e->s_indptr, e->s_indices, e->table, c.rows_dev, c.B, D, 1, e->act[0]);
-    else launch_densify_rows(e->st, e->s_indptr, e->s_indices, c.rows_dev, c.B, D, e->act[0]);
+    else launch_gather_meanpool(e->st, e->s_indptr, e->s_indices, e->table, c.rows_dev, c.B, D, 1, e->act[0]);
     return NTF_OK;
 }
 
@@ -472,6 +473,14 @@ static int forward_layers(ntf_engine* e, const StepCtx& c, bool want_logits, boo
                                    1.0 / (double)li.nw(), e->d_kl);
             launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_BIAS], kl ? b : nullptr, li.out, normal_spec(e, c, l, T_EPS_B), e->bp[l],
                                    1.0 / (double)li.out, e->d_kl);
+        }
+        if (l == 0 && e->cfg.input_mode == NTF_INPUT_MULTIHOT) {
+            Scope t(e, F_MULTIHOT);
+            SignSpec si, so;
+            if (e->cfg.bayesian) { si = sign_spec(e, c, 0, T_S_IN, li.in); so = sign_spec(e, c, 0, T_S_OUT, li.out); }
+            launch_multihot_fwd(e->st, c.rows_dev, B, li.in, li.out, e->s_indptr, e->s_indices, W, b, e->cfg.bayesian ? e->Wp[0] : nullptr,
+                                e->cfg.bayesian ? e->bp[0] : nullptr, si, so, e->act[1]);
+            continue;
         }
         Scope t(e, last ? F_OUT_FWD : F_GEMM_HIDDEN);
         GemmArgs g;
@@ -681,7 +690,12 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         } else {
             const float* dZ = last ? e->dZout : e->dAct[(l + 1) & 1];
             { Scope t(e, F_BIAS_GRAD); launch_bias_grad(e->st, dZ, li.out, B, li.out, sout_, gb, gRb); }
-            {
+            if (l == 0 && e->cfg.input_mode == NTF_INPUT_MULTIHOT) {
+                Scope t(e, F_MULTIHOT);
+                HIPCHK(e, hipMemsetAsync(gW, 0, (size_t)li.nw() * 4, e->st));
+                if (gRW) HIPCHK(e, hipMemsetAsync(gRW, 0, (size_t)li.nw() * 4, e->st));
+                launch_multihot_bwd(e->st, c.rows_dev, B, li.in, li.out, e->s_indptr, e->s_indices, dZ, sin_, sout_, gW, gRW);
+            } else {
                 Scope t(e, last ? F_OUT_BWD_DW : F_GEMM_HIDDEN);
                 GemmArgs g;
                 g.M = li.out; g.N = li.in; g.K = B;

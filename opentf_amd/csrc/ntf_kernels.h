@@ -44,8 +44,11 @@ void launch_gemm(hipStream_t st, const GemmArgs& a);
 void launch_gather_meanpool(hipStream_t st, const int64_t* indptr, const int32_t* indices, const float* table,
                             const int64_t* rows, int64_t n, int d, int mean, float* out);
 void launch_gather_dense_rows(hipStream_t st, const float* X, int d, const int64_t* rows, int64_t n, float* out);
-void launch_densify_rows(hipStream_t st, const int64_t* indptr, const int32_t* indices, const int64_t* rows,
-                         int64_t n, int width, float* out);
+// multi-hot input: layer 0 as a gather-sum of W columns / scatter-add of its gradient over the skill CSR (no dense X)
+void launch_multihot_fwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,
+                         const float* W, const float* b, const float* Wp /*nullable*/, const float* bp, SignSpec sin, SignSpec sout, float* act);
+void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,
+                         const float* dZ, SignSpec sin, SignSpec sout, float* gW /*zeroed*/, float* gWp /*nullable, zeroed*/);
 
 // Wp = softplus(rho) * eps  (eps generated or injected)
 // also accumulates w * KL(N(mu, softplus(rho)^2) || N(0,1)) summed over the tensor into kl_out when mu != nullptr

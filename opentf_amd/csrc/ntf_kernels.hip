@@ -191,16 +191,59 @@ void launch_gather_dense_rows(hipStream_t st, const float* X, int d, const int64
     hipLaunchKernelGGL(k_gather_dense_rows, dim3((unsigned)n), dim3(d >= 256 ? 256 : 64), 0, st, X, d, rows, n, out);
 }
 
-__global__ void k_densify_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const int64_t* __restrict__ rows,
-                               int width, float* __restrict__ out) {
-    const int64_t i = blockIdx.x, team = rows[i];
-    for (int c = threadIdx.x; c < width; c += blockDim.x) out[i * width + c] = 0.f;
-    __syncthreads();
-    for (int64_t p = indptr[team] + threadIdx.x; p < indptr[team + 1]; p += blockDim.x) out[i * width + indices[p]] = 1.f;
+// Multi-hot input (src/mdl/ntf.py:23: the team's skill row densified to 0/1): the first layer x W^T is the SUM of the W columns
+// of the team's skills, so X is never materialised.  W is in the reference layout [H, S] (out x in); one thread per (row, h).
+//   z = b + sum_s W[h,s]  (+ (sum_s s_in(i,s) Wp[h,s] + bp[h]) * s_out(i,h) for Flipout);   act = leaky_relu(z)
+__global__ void k_multihot_fwd(const int64_t* __restrict__ rows, int S, int H, const int64_t* __restrict__ indptr,
+                               const int32_t* __restrict__ indices, const float* __restrict__ W, const float* __restrict__ b,
+                               const float* __restrict__ Wp, const float* __restrict__ bp, SignSpec sin, SignSpec sout,
+                               float* __restrict__ act) {
+    const int i = blockIdx.x, h = blockIdx.y * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const int64_t team = rows[i], p0 = indptr[team], p1 = indptr[team + 1];
+    const float* w = W + (int64_t)h * S;
+    float z = b[h];
+    if (Wp) {
+        const float* wp = Wp + (int64_t)h * S;
+        float zp = 0.f;
+        for (int64_t p = p0; p < p1; ++p) { const int s = indices[p]; z += w[s]; zp += wp[s] * sign_at(sin, i, s); }
+        z += (zp + bp[h]) * sign_at(sout, i, h);
+    } else {
+        for (int64_t p = p0; p < p1; ++p) z += w[indices[p]];
+    }
+    act[(int64_t)i * H + h] = z > 0.f ? z : kLeakySlope * z;
 }
-void launch_densify_rows(hipStream_t st, const int64_t* indptr, const int32_t* indices, const int64_t* rows, int64_t n, int width, float* out) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_densify_rows, dim3((unsigned)n), dim3(256), 0, st, indptr, indices, rows, width, out);
+void launch_multihot_fwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,
+                         const float* W, const float* b, const float* Wp, const float* bp, SignSpec sin, SignSpec sout, float* act) {
+    if (B <= 0) return;
+    const int bs = H >= 256 ? 256 : (H + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_multihot_fwd, dim3((unsigned)B, (unsigned)((H + bs - 1) / bs)), dim3(bs), 0, st, rows, S, H, indptr, indices, W, b, Wp, bp,
+                       sin, sout, act);
+}
+// its weight gradient is a scatter: gW[h,s] += dz[i,h] for every skill s of row i (gWp[h,s] += dz*s_out(i,h)*s_in(i,s)); gW/gWp zeroed by
+// the caller.  Hardware f32 atomics at L2: the per-element sums have at most (batch frequency of s) terms.
+__global__ void k_multihot_bwd(const int64_t* __restrict__ rows, int S, int H, const int64_t* __restrict__ indptr,
+                               const int32_t* __restrict__ indices, const float* __restrict__ dZ, SignSpec sin, SignSpec sout,
+                               float* __restrict__ gW, float* __restrict__ gWp) {
+    const int i = blockIdx.x, h = blockIdx.y * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const int64_t team = rows[i], p0 = indptr[team], p1 = indptr[team + 1];
+    const float dz = dZ[(int64_t)i * H + h];
+    float* g = gW + (int64_t)h * S;
+    if (gWp) {
+        float* gp = gWp + (int64_t)h * S;
+        const float dzs = dz * sign_at(sout, i, h);
+        for (int64_t p = p0; p < p1; ++p) { const int s = indices[p]; unsafeAtomicAdd(g + s, dz); unsafeAtomicAdd(gp + s, dzs * sign_at(sin, i, s)); }
+    } else {
+        for (int64_t p = p0; p < p1; ++p) unsafeAtomicAdd(g + indices[p], dz);
+    }
+}
+void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,
+                         const float* dZ, SignSpec sin, SignSpec sout, float* gW, float* gWp) {
+    if (B <= 0) return;
+    const int bs = H >= 256 ? 256 : (H + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_multihot_bwd, dim3((unsigned)B, (unsigned)((H + bs - 1) / bs)), dim3(bs), 0, st, rows, S, H, indptr, indices, dZ, sin, sout,
+                       gW, gWp);
 }
 
 // =====================================================================================

@@ -141,6 +141,48 @@ def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
 
 
 @pytest.mark.parametrize("bayesian", [False, True])
+@pytest.mark.parametrize("S,H,M,B", [(700, [128], 1500, 90), (90, [64, 32], 300, 33), (3000, [256], 2000, 257)])
+def test_multihot_first_layer_step_vs_oracle(bayesian, S, H, M, B):
+    """BASELINE config 3's input: the skill row itself (src/mdl/ntf.py:23).  The engine never densifies it — layer 0 is a gather-sum
+    of W0 columns and its gradient a scatter-add — and must equal the oracle fed the dense 0/1 matrix."""
+    from opentf_amd import libntf
+    torch.manual_seed(3)
+    sd = O.bnn_init(S, H, M) if bayesian else O.fnn_init(S, H, M)
+    rng = np.random.default_rng(S)
+    Xd = np.zeros((B, S), np.float32)
+    for i in range(B):
+        Xd[i, rng.choice(S, 1 + rng.poisson(7.5), replace=False)] = 1
+    Xd[3] = 0                                     # a team without skills: only the bias reaches the hidden layer
+    X = torch.from_numpy(Xd)
+    y = (torch.rand(B, M) < 0.01).float(); y[torch.arange(B), torch.randint(0, M, (B,))] = 1
+    e = _engine([S] + H + [M], bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT, max_batch=B, ns=5, nsd="uniform", lr=1e-3)
+    e.load_state_dict(sd); e.set_skill_csr(_csr_from_dense(Xd)); e.set_member(_csr_from_dense(y.numpy()))
+    rows = np.arange(B)
+    opt = O.Adam(sd, 1e-3)
+    for s in range(2):
+        noise = O.draw_flipout_noise(sd, B) if bayesian else None
+        neg = O.ns_uniform(y, 5)
+        inj = {"neg_idx": neg.numpy()}
+        if bayesian:
+            inj.update({"eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise],
+                        "s_in": [n["s_in"] for n in noise], "s_out": [n["s_out"] for n in noise]})
+        ref_logits = (O.bnn_forward(sd, X, noise) if bayesian else O.fnn_forward(sd, X)).detach().numpy()
+        got = e.logits(rows, inject=inj)
+        assert _rel(got, ref_logits) < RTOL_LOGITS
+        ref_loss, ref_grads = O.train_step(sd, opt, X, y, neg, 10.0, 1.0, noise)
+        loss = e.train_step(rows, inject=inj)
+        assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss)
+        grads, state = e.grads(), e.state_dict()
+        for k in sd:
+            assert _rel(grads[k], ref_grads[k].numpy()) < 3e-4, (s, k, _rel(grads[k], ref_grads[k].numpy()))
+            _close(state[k], sd[k].numpy(), 1e-3, 2e-5)
+        # both sides continue from the engine's parameters: a 1e-7 difference left by Adam is enough to put one pre-activation on the
+        # other side of leaky_relu's kink, which moves a whole row of dh (seen on this case) — that is not what this test is about
+        with torch.no_grad():
+            for k in sd: sd[k].copy_(torch.from_numpy(state[k]))
+
+
+@pytest.mark.parametrize("bayesian", [False, True])
 def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian):
     """cfg.fuse_adam moves the output layer's Adam into the dW kernel's epilogue: same parameters, step for step."""
     sd, X, y = _bnn_case(64, [128], 900, 150, 3)
