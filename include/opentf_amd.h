@@ -168,6 +168,19 @@ int ntf_skill_coverage(int device, const int32_t* topk_idx, int64_t n, int32_t K
                        int64_t n_skill_rows, const int64_t* rows, const int64_t* cov_indptr, const int32_t* cov_indices, int64_t n_experts,
                        const int32_t* cutoffs, int32_t n_cut, float* out_cov);
 
+/* ---- member-skill co-occurrence on the device                                                 src/cmn/team.py:302-337
+ * `Team.gen_skill_coverage`: C = member^T . skill over the teams NOT listed in skip_rows (the reference empties the test teams' rows,
+ * team.py:327-331), as scipy computes it on the two uint8 matrices: counts wrap mod 256, entries whose wrapped count is 0 are not stored.
+ * CSR inputs are host pointers (column ids unique inside a row); the result [n_members, n_skills] stays on the device behind an opaque
+ * handle: *nnz tells the caller how much to allocate, ntf_csr_result_fetch copies indptr [n_members+1] / indices / data (column ids
+ * ascending inside a row = scipy's result after sort_indices()) and reports the device time of the build. */
+typedef struct ntf_csr_result ntf_csr_result;
+int ntf_skill_cooccurrence(int device, int64_t n_teams, int32_t n_members, int32_t n_skills, const int64_t* m_indptr, const int32_t* m_indices,
+                           const int64_t* s_indptr, const int32_t* s_indices, const int64_t* skip_rows, int64_t n_skip,
+                           ntf_csr_result** out, int64_t* nnz);
+int ntf_csr_result_fetch(ntf_csr_result* r, int64_t* indptr, int32_t* indices, uint8_t* data, double* device_ms);
+void ntf_csr_result_free(ntf_csr_result* r);
+
 /* device generators behind Flipout's eps / signs (dev_out = device pointers), for statistical tests */
 int ntf_k_fill_normal(void* stream, uint64_t seed, uint64_t step, int layer, int64_t n, float* dev_out);
 int ntf_k_fill_sign(void* stream, uint64_t seed, uint64_t step, int layer, int rows, int cols, float* dev_out);

@@ -79,6 +79,9 @@ SYMBOLS = {
     "ntf_kernel_times": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     "ntf_rank_metrics": (C.c_int, [C.c_int, _P, _I64, _I32, _P, _P, _I64, _P, _P, _I32, _P]),
     "ntf_skill_coverage": (C.c_int, [C.c_int, _P, _I64, _I32, _P, _P, _I64, _P, _P, _P, _I64, _P, _I32, _P]),
+    "ntf_skill_cooccurrence": (C.c_int, [C.c_int, _I64, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "ntf_csr_result_fetch": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ntf_csr_result_free": (None, [_P]),
     "ntf_k_gemm_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
     "ntf_k_fill_normal": (C.c_int, [_P, _U64, _U64, C.c_int, _I64, _P]),
     "ntf_k_fill_sign": (C.c_int, [_P, _U64, _U64, C.c_int, C.c_int, C.c_int, _P]),

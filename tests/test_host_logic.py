@@ -148,3 +148,27 @@ def test_synthetic_dataset_statistics():
     assert freq[0] > 20 * max(freq[2500], 1)  # heavy tail
     i2, x2 = zipf_csr(20000, 5000, 8.57, seed=1)
     assert np.array_equal(indptr, i2) and np.array_equal(indices, x2)  # deterministic
+
+
+def test_lil_ingestion_as_csr_and_validate():
+    """teamsvecs.pkl holds scipy lil uint8 matrices (src/cmn/team.py:215,295): one pass over the row lists gives the CSR the engine wants."""
+    import scipy.sparse
+    from opentf_amd.cmn.team import lil_to_csr, validate
+    rng = np.random.default_rng(0)
+    dense = (rng.random((200, 37)) < 0.1).astype(np.uint8)
+    dense[np.arange(200), 1 + np.arange(200) % 3] = 1        # no accidental empty teams
+    dense[:, 5] = 0; dense[7] = 0
+    lil = scipy.sparse.lil_matrix(dense)
+    ip, ix, shape = lil_to_csr(lil)
+    ref = scipy.sparse.csr_matrix(dense); ref.sort_indices()
+    assert ip.dtype == np.int64 and ix.dtype == np.int32 and shape == (200, 37)
+    assert np.array_equal(ip, ref.indptr) and np.array_equal(ix, ref.indices)
+    ip2, ix2, _ = lil_to_csr(ref)
+    assert np.array_equal(ip2, ip) and np.array_equal(ix2, ix)
+    ok, msg = validate({"skill": lil, "member": lil})
+    assert not ok and "have no skills" in msg and "[7]" in msg
+    dense[7, 0] = 1
+    ok, msg = validate({"skill": scipy.sparse.lil_matrix(dense), "member": scipy.sparse.lil_matrix(dense)})
+    assert not ok and "used in no teams" in msg and "5" in msg
+    dense[0, 5] = 1
+    assert validate({"skill": scipy.sparse.lil_matrix(dense), "member": scipy.sparse.lil_matrix(dense)}) == (True, "")

@@ -163,3 +163,16 @@ def test_flipout_self_consistency():
     rho1 = float(np.log(np.expm1(1.0)))
     prior = {k: (torch.zeros_like(v) if "mu" in k else torch.full_like(v, rho1)) for k, v in sd.items()}
     assert abs(float(O.get_kl_loss(prior))) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ member-skill co-occurrence (§8f rank 3)
+@pytest.mark.parametrize("name", ["dblp", "imdb", "uspt", "gith", "wrap", "rand"])
+def test_cooc_oracle_matches_reference_skillcoverage(name):
+    """dblp/imdb/uspt/gith: the `skillcoverage.pkl` files committed by the reference's authors; wrap/rand: the reference's expression
+    (src/cmn/team.py:327-335) run on synthetic lil matrices whose counts pass 255 (uint8 wrap, zero sums dropped)."""
+    from oracle import cooc_oracle as CO
+    g = golden("g11_cooc")
+    n, M, S = [int(v) for v in g[f"{name}.shape"]]
+    ip, ix, data = CO.skill_cooccurrence(g[f"{name}.m_indptr"], g[f"{name}.m_indices"], g[f"{name}.s_indptr"], g[f"{name}.s_indices"], M, S, g[f"{name}.skip"])
+    assert np.array_equal(ip, g[f"{name}.c_indptr"]) and np.array_equal(ix, g[f"{name}.c_indices"]) and np.array_equal(data, g[f"{name}.c_data"])
+    assert data.dtype == np.uint8 and (data != 0).all()
