@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--experts", type=int, default=0, help="override the number of experts (debug)")
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--fuse-adam", type=int, default=2, help="0 flat Adam, 1 in the dW epilogue, 2 chunked beside dW on a side stream (N=1 only)")
+    ap.add_argument("--mfma", default="default", choices=["default", "f32", "bf16x6"], help="arithmetic of the fused output-layer products (include/opentf_amd.h ntf_mfma)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-bench", action="store_true", help="also time the whole-dataset gather (get_dense_vecs)")
     ap.add_argument("--force-dist", action="store_true", help="init RCCL and all-reduce the gradient buffer even at world_size 1 (validation)")
@@ -128,7 +129,7 @@ def main():
     with torch.cuda.stream(stream):
         e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
                           lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
-                          fuse_adam=a.fuse_adam if world == 1 else 0)
+                          fuse_adam=a.fuse_adam if world == 1 else 0, mfma=a.mfma)
         if not multihot: e.set_skill_table(ds["table"])
         e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
         e.load_state_dict(init_params(dims, bayesian, 0))

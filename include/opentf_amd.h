@@ -42,6 +42,8 @@ enum ntf_nsd { NTF_NSD_NONE = 0, NTF_NSD_UNIFORM = 1, NTF_NSD_UNIGRAM = 2, NTF_N
  * mu_weight, rho_weight, mu_bias, rho_bias (src/mdl/bnn.py:25 via bayesian-torch LinearFlipout) */
 enum ntf_param_kind { NTF_P_WEIGHT = 0, NTF_P_BIAS = 1, NTF_P_RHO_WEIGHT = 2, NTF_P_RHO_BIAS = 3 };
 
+enum ntf_mfma { NTF_MFMA_DEFAULT = 0, NTF_MFMA_F32 = 1, NTF_MFMA_BF16X6 = 2 };
+
 typedef struct ntf_config {
     int32_t abi_version;        /* NTF_ABI_VERSION */
     int32_t device;             /* HIP device ordinal ("cuda:N" of src/__config__.yaml:10) */
@@ -60,7 +62,10 @@ typedef struct ntf_config {
     int32_t fuse_adam;          /* single-GPU train steps only.  0: one flat Adam kernel after backward.  1: the output layer's Adam runs inside
                                    the dW kernel's epilogue (its gradients are not materialised).  2: the dW kernel is launched in expert chunks
                                    and Adam of a finished chunk runs on a side stream beside the next chunk's dW */
-    int32_t reserved[6];
+    int32_t mfma;               /* arithmetic of the fused output-layer products: NTF_MFMA_DEFAULT (0) = the engine's choice,
+                                   NTF_MFMA_F32 = v_mfma_f32_32x32x2_f32 (bit-exact f32 fma chain), NTF_MFMA_BF16X6 = each f32 operand split exactly into
+                                   three bf16 values and a product taken as six bf16 MFMA products accumulated in f32 (f32-accurate, ~2.7x the rate) */
+    int32_t reserved[5];
 } ntf_config;
 
 /* Random tensors of one step, injected instead of generated (parity tests).  Any pointer may be NULL

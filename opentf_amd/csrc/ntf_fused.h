@@ -35,6 +35,7 @@ struct FusedDw {
     SignSpec s_out; int s_out_inj = 0;              // s_out keys; s_out_inj: signs were injected this step (packed image in ws)
     // adam != 0 (single GPU): Adam on mu / rho runs in the epilogue (in place), g_mu / g_rho are not written
     int adam = 0;
+    int bf16x6 = 0;                                 // 1: bf16 split-product MFMAs (f32-accurate, see ntf_fused.hip) instead of the f32 MFMA
     int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the expert tiles [wg_begin, wg_begin + wg_count) of fused_dw_tile() experts each
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
@@ -48,6 +49,7 @@ int fused_ldb(int B);
 int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are padded to a multiple of it)
 // phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
 
 }  // namespace ntf

@@ -41,7 +41,7 @@ static Geom geom(int B, int M) {
 }
 int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)NCG_MAX * BM * H; }
 
-struct WsLayout { size_t sbits, sbitsT, sinbits, hs, hz, lossp, total; };
+struct WsLayout { size_t sbits, sbitsT, sinbits, hs, hz, lossp, hb, total; };
 static WsLayout ws_layout(int Bmax, int H, int M) {
     const int Bpad = rup(Bmax, BM), nCB = rup((M + 31) / 32, 2);
     WsLayout w; size_t o = 0;
@@ -52,6 +52,7 @@ static WsLayout ws_layout(int Bmax, int H, int M) {
     w.hs = take((size_t)Bpad * H * 4);
     w.hz = take((size_t)Bpad * H * 4);
     w.lossp = take((size_t)Bpad * NCG_MAX * 4);
+    w.hb = take((size_t)Bpad * H * 2 * 6);   // bf16 split planes of h and h*s_in, K-block tiled (k_prep_planes_T)
     w.total = o;
     return w;
 }
@@ -499,7 +500,8 @@ struct DwArgs {
     // fused Adam (single GPU): update mu / rho and their moments in the epilogue instead of writing the gradients
     float *__restrict__ w_mu, *__restrict__ w_rho, *__restrict__ m_mu, *__restrict__ v_mu, *__restrict__ m_rho, *__restrict__ v_rho;
     float lr_over_bc1, b1, b2, eps, bc2_sqrt;
-    int wg_begin;   // first 128-expert tile of this launch (the expert range can be launched in chunks)
+    int wg_begin;   // first expert tile of this launch (the expert range can be launched in chunks)
+    const uint16_t* hb;   // bf16x6: split planes of h / h*s_in (k_prep_planes_T)
 };
 
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
@@ -671,6 +673,203 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
     }
 }
 
+// ================================================================================================
+// bf16x6 variant: every f32 operand x is split exactly into three bf16 values x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = bf16(x - x1 - x2); 24 mantissa bits in all), and a product a*b is taken as the six bf16 MFMA products
+// a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 accumulated in f32.  Each bf16 x bf16 product is exact in f32 and the dropped terms are
+// <= 2^-24 relative, so the result carries f32 accuracy (measured: the same error against f64 as the f32 MFMA) while the matrix
+// pipe does 6 x 32 cycles per 16-deep k-step of a 32x32 tile instead of 8 x 64 (v_mfma_f32_32x32x2_f32) — and, unlike the f32 MFMA,
+// v_mfma_f32_32x32x16_bf16 leaves 24 of its 32 cycles free for vector instructions of the same wave.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// two f32 -> three packed bf16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p1) : "v"(x0), "v"(x1));
+    const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p2) : "v"(r0), "v"(r1));
+    const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p3) : "v"(s0), "v"(s1));
+}
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+// acc += a*b with a = a1+a2+a3, b = b1+b2+b3 (smallest terms first)
+__device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[2]), as_frag(b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[0]), as_frag(b[2]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[1]), as_frag(b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[1]), as_frag(b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[0]), as_frag(b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[0]), as_frag(b[0]), acc, 0, 0, 0);
+    return acc;
+}
+
+// hb: for every 32-row K block ib of the batch, the planes [p = h1,h2,h3,(hs1,hs2,hs3)][j][r = 0..31] of bf16 — the B operand
+// (k = batch row, n = hidden unit) of the dW products reads 8 consecutive batch rows of one hidden unit as one 16-byte chunk.
+__global__ void k_prep_planes_T(const float* __restrict__ hz, const float* __restrict__ hs, int bayes, int Bpad, int H, uint16_t* __restrict__ hb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;          // (ib, j, r), r fastest
+    if (t >= Bpad * H) return;
+    const int r = t & 31, j = (t >> 5) % H, ib = t / (32 * H);
+    const int npl = bayes ? 6 : 3;
+    uint16_t* tile = hb + (size_t)ib * npl * H * 32;
+    for (int q = 0; q < (bayes ? 2 : 1); ++q) {
+        const float x = (q ? hs : hz)[(int64_t)(ib * 32 + r) * H + j];
+        uint32_t p1, p2, p3;
+        split_pair(x, 0.f, p1, p2, p3);
+        tile[((q * 3 + 0) * H + j) * 32 + r] = (uint16_t)p1;
+        tile[((q * 3 + 1) * H + j) * 32 + r] = (uint16_t)p2;
+        tile[((q * 3 + 2) * H + j) * 32 + r] = (uint16_t)p3;
+    }
+}
+
+// dW with bf16x6 products.  Workgroup = 8 waves x 32 experts; K = batch in 32-row blocks, two LDS stages filled by LDS-DMA:
+//   A (k = batch row): the f32 dzT tile [256 experts][32 rows], 16-byte chunks XOR-swizzled ((row>>1)&7) exactly as in k_out_dw; a lane reads
+//     the 8 consecutive values of ITS expert (two ds_read_b128) and splits them in registers;
+//   B: the bf16 planes of h / h*s_in for the K block ([plane][j][32 rows], chunks swizzled with (j>>2)&3): one ds_read_b128 per fragment.
+// No compiler-visible global load sits in the loop: hipcc would wait for it with a vmcnt that, in the real in-order queue, also waits
+// for the DMA issued just before.
+template <int H, bool BAYES>
+__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NJT = H / 32;
+    constexpr int NPL = BAYES ? 6 : 3;
+    constexpr int TA = DW_TC * 32 * 4;            // dzT tile bytes
+    constexpr int PLANE = H * 64;                 // bytes of one plane of one K block: [H][32 rows] bf16
+    constexpr int TB = NPL * PLANE;
+    constexpr int STAGE = TA + TB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    const int c0 = (p.wg_begin + blockIdx.x) * DW_TC;
+    const int crow = wave * 32 + il;
+    const int c = c0 + crow;
+    const int nib = p.Bpad / 32;
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* hb = reinterpret_cast<const char*>(p.hb);
+
+    f32x16 acc1[NJT], acc2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
+    float sum1 = 0.f, sum2 = 0.f;
+
+    auto stage = [&](int ib, int buf) {
+        const uint32_t sb = smem_base + buf * STAGE;
+#pragma unroll
+        for (int n = 0; n < TA / 1024 / DW_WAVES; ++n) {      // 1 KiB wave-instructions: 8 expert rows x 128 B
+            const int inst = wave_u * (TA / 1024 / DW_WAVES) + n;
+            const int row = inst * 8 + (lane >> 3), pch = lane & 7;
+            const int q = pch ^ ((row >> 1) & 7);
+            glds16(p.dzT + (int64_t)(c0 + row) * p.Bpad + ib * 32 + 4 * q, sb + inst * 1024);
+        }
+        const char* src = hb + (size_t)ib * TB;
+        constexpr int NINST = TB / 1024;
+#pragma unroll
+        for (int n = 0; n < (NINST + DW_WAVES - 1) / DW_WAVES; ++n) {
+            const int inst = wave_u * ((NINST + DW_WAVES - 1) / DW_WAVES) + n;
+            if (inst < NINST) {
+                const int pos = inst * 1024 + lane * 16;          // destination byte inside the plane area
+                const int j = (pos % PLANE) >> 6, cd = (pos >> 4) & 3;
+                glds16(src + (pos & ~63) + 16 * (cd ^ ((j >> 2) & 3)), sb + TA + inst * 1024);
+            }
+        }
+    };
+    const uint32_t cb = (uint32_t)((c0 + wave * 32) >> 5);
+    auto sign_col_word = [&](int ib) -> uint32_t {   // bit k = s_out sign of (batch row ib*32 + k, this lane's expert)
+        const int i = ib * 32 + il;
+        uint32_t w = 0u;
+        if (p.so_inj) { if ((int)cb < p.nCB) w = p.sbits[(int64_t)i * p.nCB + cb]; }
+        else w = sign_word(p.so_k0, p.so_k1, (uint32_t)i, cb);
+        return transpose32(w, il);
+    };
+    uint32_t word_next = 0;
+    if (BAYES) word_next = sign_col_word(0);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ib = 0; ib < nib; ++ib) {
+        const int buf = ib & 1;
+        const uint32_t word = word_next;
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + TA;
+        // the K block as a flat, software-pipelined sequence of half-groups hg = (ks, jt, plain | signed): 3 fragment reads + 6 MFMAs
+        // each; the reads of half-group hg+1 are in flight while the MFMAs of hg run (explicit double buffer: left to itself hipcc
+        // reuses the fragment registers and waits for every ds_read right before the MFMA that needs it)
+        constexpr int NHG = 2 * NJT * (BAYES ? 2 : 1);
+        const char* bbase = sB + il * 64;
+        const int swz = (il >> 2) & 3;
+        auto load_b = [&](int hg, u32x4 (&dst)[3]) {
+            const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
+            const char* bp = bbase + jt * 2048 + 16 * ((2 * ks + half) ^ swz) + which * 3 * PLANE;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dst[q] = *reinterpret_cast<const u32x4*>(bp + q * PLANE);
+        };
+        u32x4 a[2][3], as[2][3];
+        auto prep_a = [&](int ks) {
+            const int ch = 4 * ks + 2 * half, sw = (crow >> 1) & 7;
+            const float4 lo = *reinterpret_cast<const float4*>(sA + crow * 128 + 16 * (ch ^ sw));
+            const float4 hi = *reinterpret_cast<const float4*>(sA + crow * 128 + 16 * ((ch + 1) ^ sw));
+            const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const uint32_t w8 = word >> (ks * 16 + half * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t p1, p2, p3;
+                split_pair(x[2 * q], x[2 * q + 1], p1, p2, p3);
+                a[ks][0][q] = p1; a[ks][1][q] = p2; a[ks][2][q] = p3;
+                sum1 += x[2 * q] + x[2 * q + 1];
+                if (BAYES) {
+                    const uint32_t m = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+                    as[ks][0][q] = p1 ^ m; as[ks][1][q] = p2 ^ m; as[ks][2][q] = p3 ^ m;
+                    sum2 += __uint_as_float(__float_as_uint(x[2 * q]) ^ ((w8 << (31 - 2 * q)) & 0x80000000u)) +
+                            __uint_as_float(__float_as_uint(x[2 * q + 1]) ^ ((w8 << (30 - 2 * q)) & 0x80000000u));
+                }
+            }
+        };
+        u32x4 bq[2][3];
+        load_b(0, bq[0]);
+        prep_a(0);
+#pragma unroll
+        for (int hg = 0; hg < NHG; ++hg) {
+            if (hg + 1 < NHG) load_b(hg + 1, bq[(hg + 1) & 1]);
+            asm volatile("" ::: "memory");   // keep the prefetch above this half-group's MFMAs
+            const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
+            if (which) acc2[jt] = mfma6(as[ks], bq[hg & 1], acc2[jt]);
+            else acc1[jt] = mfma6(a[ks], bq[hg & 1], acc1[jt]);
+            if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);   // before the first k-step-1 half-group; its vector work runs in the shadow of the following MFMAs
+            // next K block: DMA issue + sign words in the middle of the MFMA phase, not in front of it — the two waves of a SIMD leave
+            // every barrier in phase, and vector work bunched at the top of the iteration would meet the partner's vector work there
+            if (hg == NHG / 2 && ib + 1 < nib) { stage(ib + 1, buf ^ 1); if (BAYES && !p.so_inj) word_next = sign_col_word(ib + 1); }
+        }
+        if (BAYES && p.so_inj && ib + 1 < nib) word_next = sign_col_word(ib + 1);   // injected signs (tests): a visible load, kept out of the MFMA phase
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next K block (DMA) has landed
+        __syncthreads();
+    }
+
+    // each half of the wave summed its 8 of every 16 batch rows
+    sum1 += __shfl_xor(sum1, 32, 64);
+    sum2 += __shfl_xor(sum2, 32, 64);
+    if (half == 0 && c < p.M) { p.g_b[c] = sum1; if (BAYES) p.g_bp[c] = sum2; }
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cr = c0 + wave * 32 + rowmap(r, half);
+        if (cr >= p.M) continue;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int64_t idx = (int64_t)cr * H + 32 * jt + il;
+            if (!BAYES) { p.g_mu[idx] = acc1[jt][r]; continue; }
+            const float rh = p.rho[idx], w = p.wp[idx], m = p.mu[idx];
+            // sigma = log1p(e^rho), sigmoid(rho) = e^rho / (1 + e^rho) on the hardware exp2/log2/rcp (the library expf/log1pf cost more vector
+            // instructions here than the whole K loop); the short series keeps log1p accurate where 1 + e^rho rounds
+            const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
+            const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
+            const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
+            p.g_mu[idx] = acc1[jt][r] + p.klw * m;
+            p.g_rho[idx] = acc2[jt][r] * (w * isig) * sg + p.klw * (sigma - isig) * sg;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
 static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
@@ -740,12 +939,33 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     const int grid = f.wg_count > 0 ? std::min(f.wg_count, total - f.wg_begin) : total;
     a.wg_begin = f.wg_count > 0 ? f.wg_begin : 0;
     if (grid <= 0) return;
+    a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
+    if (f.bf16x6 && !f.adam) {
+#define NTF_DWB(HH) do { const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 6 : 3) * HH * 64);                                                     \
+        if (f.bayes) { auto kf = k_out_dw_b6<HH, true>; hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                       hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); }                                                 \
+        else { auto kf = k_out_dw_b6<HH, false>; hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } } while (0)
+        if (f.H == 128) NTF_DWB(128); else if (f.H == 64) NTF_DWB(64); else NTF_DWB(32);
+#undef NTF_DWB
+        return;
+    }
 #define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
 #define NTF_DW(HH) do { if (f.bayes) NTF_DW1(HH, true); else NTF_DW1(HH, false); } while (0)
     if (f.H == 128) NTF_DW(128); else if (f.H == 64) NTF_DW(64); else NTF_DW(32);
 #undef NTF_DW
+}
+
+// bf16 split planes of the hidden activations for the dW kernel (once per step, after launch_fused_out_fwd's phase 1)
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws_) {
+    const Geom g = geom(B, M);
+    const WsLayout w = ws_layout(B, H, M);
+    char* ws = static_cast<char*>(ws_);
+    const int n = g.Bpad * H;
+    hipLaunchKernelGGL(k_prep_planes_T, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(ws + w.hz), reinterpret_cast<const float*>(ws + w.hs),
+                       bayes, g.Bpad, H, reinterpret_cast<uint16_t*>(ws + w.hb));
 }
 
 }  // namespace ntf

@@ -29,7 +29,7 @@ class ntf_config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p), ("n_layers", C.c_int32),
                 ("dims", C.c_int32 * (NTF_MAX_LAYERS + 1)), ("bayesian", C.c_int32), ("input_mode", C.c_int32),
                 ("max_batch", C.c_int32), ("ns", C.c_int32), ("nsd", C.c_int32), ("tpw", C.c_float), ("tnw", C.c_float),
-                ("lr", C.c_float), ("seed", C.c_uint64), ("fused", C.c_int32), ("fuse_adam", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("lr", C.c_float), ("seed", C.c_uint64), ("fused", C.c_int32), ("fuse_adam", C.c_int32), ("mfma", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class ntf_inject(C.Structure):
@@ -127,7 +127,7 @@ class Engine:
     """One Fnn/Bnn model resident on one MI355X.  dims = [D, *h, M]."""
 
     def __init__(self, dims, bayesian=False, input_mode=INPUT_DENSE, max_batch=1000, ns=5, nsd="uniform", tpw=10.0, tnw=1.0,
-                 lr=1e-3, seed=0, device=0, stream=None, fused=True, fuse_adam=False):
+                 lr=1e-3, seed=0, device=0, stream=None, fused=True, fuse_adam=False, mfma=None):
         self.dims = [int(d) for d in dims]
         self.L = len(self.dims) - 1
         if not 1 <= self.L <= NTF_MAX_LAYERS:
@@ -141,6 +141,7 @@ class Engine:
             cfg.dims[i] = d
         cfg.bayesian, cfg.input_mode, cfg.max_batch = int(self.bayesian), int(input_mode), self.max_batch
         cfg.ns, cfg.nsd, cfg.tpw, cfg.tnw, cfg.lr, cfg.seed, cfg.fused = max(self.ns, 0), NSD[nsd], float(tpw), float(tnw), float(lr), int(seed) & (2**64 - 1), int(bool(fused))
+        cfg.mfma = {None: 0, "default": 0, "f32": 1, "bf16x6": 2}[mfma] if not isinstance(mfma, int) or isinstance(mfma, bool) else int(mfma)
         cfg.fuse_adam = int(fuse_adam)  # 0: flat Adam kernel; 1: inside the dW epilogue; 2: chunked beside the dW kernel on a side stream
         self._h = C.c_void_p()
         rc = lib().ntf_engine_create(C.byref(cfg), C.byref(self._h))

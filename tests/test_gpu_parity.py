@@ -83,13 +83,14 @@ def test_fnn_logits_vs_reference_golden(name, fused):
 
 
 @pytest.mark.parametrize("tag", ["imdb", "mid"])
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "f32"])
 def test_fnn_train_steps_vs_reference_golden(tag, fused):
     g = golden(f"g4_step_{tag}")
     sd = params_from(g, "p0.")
     X, y = g["X"], g["y"]
     dims = [X.shape[1]] + [sd[f"layers.{i}.weight"].shape[0] for i in range(O.n_layers(sd))]
-    e = _engine(dims, max_batch=len(X), ns=5, nsd="uniform", tpw=float(g["tpw"]), tnw=float(g["tnw"]), lr=float(g["lr"]), fused=fused)
+    e = _engine(dims, max_batch=len(X), ns=5, nsd="uniform", tpw=float(g["tpw"]), tnw=float(g["tnw"]), lr=float(g["lr"]), fused=bool(fused),
+                mfma="f32" if fused == "f32" else None)
     e.load_state_dict(sd); e.set_dense_input(X); e.set_member(_csr_from_dense(y))
     rows = np.arange(len(X))
     for s in range(3):
@@ -113,10 +114,11 @@ def _bnn_case(D, H, M, B, seed):
 
 @pytest.mark.parametrize("D,H,M,B", [(18, [32], 112, 19), (128, [128], 1500, 70), (40, [64, 32], 300, 33), (128, [128], 5000, 130),
                                      (24, [64], 777, 129), (16, [128], 13, 1), (16, [32], 63, 257), (50, [], 90, 21), (32, [], 100, 40)])
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "f32"])
 def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
+    """fused=True: the fused kernels in their default arithmetic (bf16x6 split products where implemented); "f32": the exact-f32 MFMA kernels."""
     sd, X, y = _bnn_case(D, H, M, B, 5)
-    e = _engine([D] + H + [M], bayesian=True, max_batch=B, ns=5, nsd="uniform", lr=1e-3, fused=fused)
+    e = _engine([D] + H + [M], bayesian=True, max_batch=B, ns=5, nsd="uniform", lr=1e-3, fused=bool(fused), mfma="f32" if fused == "f32" else None)
     e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
     rows = np.arange(B)
     opt = O.Adam(sd, 1e-3)
@@ -189,7 +191,8 @@ def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian):
     if not bayesian:
         torch.manual_seed(3); sd = O.fnn_init(64, [128], 900)
     def run(fuse):
-        e = _engine([64, 128, 900], bayesian=bayesian, max_batch=150, ns=4, nsd="uniform", seed=21, lr=1e-2, fuse_adam=fuse)
+        # mfma="f32": mode 1 exists only for the f32-MFMA dW kernel; this test is about WHERE Adam runs, not about the product arithmetic
+        e = _engine([64, 128, 900], bayesian=bayesian, max_batch=150, ns=4, nsd="uniform", seed=21, lr=1e-2, fuse_adam=fuse, mfma="f32")
         e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
         losses = [e.train_step(np.arange(150)) for _ in range(4)]
         return losses, e.state_dict()
