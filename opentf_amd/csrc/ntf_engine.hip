@@ -78,6 +78,7 @@ struct ntf_engine {
     // unigram_b staging (sparse per-batch alias table)
     std::vector<int32_t> ub_entries; void* ub_host[2] = {nullptr, nullptr}; void* ub_dev[2] = {nullptr, nullptr}; hipEvent_t ub_ev[2] = {nullptr, nullptr};
     bool ub_used[2] = {false, false}; size_t ub_cap = 0; int ub_slot = 0, ub_nsup = 0; double ub_total = 0;
+    uint16_t* pl_mu = nullptr; uint16_t* pl_wp = nullptr;   // bf16 split planes of the output layer's mu / Wp (bf16x6 arithmetic)
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
 };
@@ -194,6 +195,10 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (rc == NTF_OK && fused_ok(e)) {
         A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
         A(dmalloc(e, &e->fws, (int64_t)fused_workspace_bytes(B, e->layers[e->L - 1].in, M)));
+        if (cfg->mfma != NTF_MFMA_F32 && e->layers[e->L - 1].in == 128) {
+            A(dmalloc(e, &e->pl_mu, fused_planes_elems(M, 128)));
+            if (cfg->bayesian) A(dmalloc(e, &e->pl_wp, fused_planes_elems(M, 128)));
+        }
     }
     e->inj_eps_w.assign(e->L, nullptr); e->inj_eps_b.assign(e->L, nullptr); e->inj_s_in.assign(e->L, nullptr); e->inj_s_out.assign(e->L, nullptr);
     if (rc != NTF_OK) { g_create_error = e->err; ntf_engine_destroy(e); return rc; }
@@ -218,7 +223,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto& p : e->Wp) dfree(p);
     for (auto& p : e->bp) dfree(p);
     dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_acc); dfree(e->d_acc_steps);
-    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws); dfree(e->gemm_slab); dfree(e->tk_vals); dfree(e->tk_idx);
+    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws); dfree(e->pl_mu); dfree(e->pl_wp); dfree(e->gemm_slab); dfree(e->tk_vals); dfree(e->tk_idx);
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
@@ -607,6 +612,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
             f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         }
+        f.bf16x6 = e->pl_mu != nullptr; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }

@@ -21,6 +21,8 @@ struct FusedOut {
     // sparse fix-up
     const int64_t* rows = nullptr; const int64_t* m_indptr = nullptr; const int32_t* m_indices = nullptr;
     const int64_t* neg = nullptr; int ns = 0; float* row_fix = nullptr;
+    // bf16x6 arithmetic (H = 128): scratch for the bf16 split planes of mu / Wp, fused_planes_elems(M, H) uint16 each
+    int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
 };
 
 // weight / bias gradients of the output layer from dzT (K = batch); for Flipout the rho gradient is finalised here
@@ -46,6 +48,7 @@ int fused_loss_slots(int M);
 int64_t fused_dh_slab_floats(int B, int H, int M);
 size_t fused_workspace_bytes(int B, int H, int M);
 int fused_ldb(int B);
+int64_t fused_planes_elems(int M, int H);   // uint16 elements of one matrix's split planes
 int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are padded to a multiple of it)
 // phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);

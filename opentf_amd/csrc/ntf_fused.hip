@@ -28,6 +28,7 @@ constexpr int DW_TC = 32 * DW_WAVES;      // experts per workgroup of the dW ker
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 int fused_ldb(int B) { return rup(B, BM); }
 int fused_dw_tile() { return DW_TC; }
+int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 31) / 32 * 32 * H * 3; }
 bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
 int fused_loss_slots(int) { return 0; }
 
@@ -871,6 +872,268 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward + loss + dz + dh of the output layer in bf16x6 arithmetic (H = 128).
+// Weights arrive pre-split: k_split_planes writes, per 32-expert tile, the three bf16 planes [32 rows][H] of mu (and of Wp); a tile
+// (2 matrices x 3 planes x 8 KiB + biases) is one LDS stage, filled by LDS-DMA.  In LDS a plane is the dual-use image
+//   off(row, ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))          (ch = 16-byte chunk = 8 hidden units)
+// read by rows (ds_read_b128: A operand of zT = mu . hT, k = hidden unit) and by columns (ds_read_b64_tr_b16: B operand of
+// dh = dz . mu, k = expert), conflict free both ways.  h's planes stay in registers (B operand of zT); the zT accumulator (lane = batch
+// row, register = expert) is, converted pairwise, the A operand of the dh products, whose k order the transposed reads follow:
+// element e of lane half h  <->  expert 16s + 8(e>>2) + 4h + (e&3).
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int BN6 = 32;   // experts per tile of the bf16x6 forward kernel
+
+// planes[tile][plane][row][H] (bf16) of a row-major f32 matrix W [M, H]; rows past M are zero
+__global__ void k_split_planes(const float* __restrict__ W, int M, int H, uint16_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // one thread per pair of hidden units
+    const int hp = H / 2;
+    const int64_t row = t / hp; const int j = (int)(t % hp) * 2;
+    const int64_t Mp = ((int64_t)M + BN6 - 1) / BN6 * BN6;
+    if (row >= Mp) return;
+    float x0 = 0.f, x1 = 0.f;
+    if (row < M) { const float2 v = *reinterpret_cast<const float2*>(W + row * H + j); x0 = v.x; x1 = v.y; }
+    uint32_t p1, p2, p3;
+    split_pair(x0, x1, p1, p2, p3);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + ((row / BN6) * 3 * BN6 + (row % BN6)) * H + j);
+    o[0] = p1; o[(size_t)BN6 * H / 2] = p2; o[(size_t)BN6 * H] = p3;
+}
+
+struct OutFwd6Args {
+    OutFwdArgs a;
+    const uint16_t *mu_pl, *wp_pl;   // k_split_planes images of mu and Wp
+};
+
+template <bool BAYES, bool TRAIN, bool DH, bool INJ>
+__global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OutFwdArgs& p = pp.a;
+    constexpr int H = 128, NJT = 4, NKS = H / 16;
+    constexpr int PLANE = BN6 * H * 2;          // 8 KiB
+    constexpr int TM = 3 * PLANE;               // one matrix of a tile
+    constexpr int NMAT = BAYES ? 2 : 1;
+    constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int cg = bid / p.NRB, rb = bid % p.NRB;
+    const int T = (p.M + BN6 - 1) / BN6;
+    const int t_beg = (int)((int64_t)cg * T / p.NCG), t_end = (int)((int64_t)(cg + 1) * T / p.NCG);
+    const int i0 = rb * BM + wave * 32;
+    const int i = i0 + il;
+    const bool row_ok = i < p.B;
+
+    // B operand of zT: h[i][16s + 8*half + e] split into planes; sign masks of s_in for the same elements
+    u32x4 hp[NKS][3], hm[NKS];
+    {
+        uint32_t sinw[NJT];
+#pragma unroll
+        for (int w = 0; w < NJT; ++w)
+            sinw[w] = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) : 0u;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
+            const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t p1, p2, p3;
+                split_pair(x[2 * q], x[2 * q + 1], p1, p2, p3);
+                hp[s][0][q] = p1; hp[s][1][q] = p2; hp[s][2][q] = p3;
+                hm[s][q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+            }
+        }
+    }
+    const float rmask = row_ok ? 1.f : 0.f;
+    const float rscale = row_ok ? p.tnw * p.inv_B : 0.f;
+
+    // lane parts of the LDS addresses
+    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
+    int aoff[NKS];                                  // row read of chunk 2s + half of row il
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) aoff[s] = 256 * il + 16 * ((2 * s + half) ^ fil);
+    int troff[2][NJT];                              // transposed read (rr, jt): rows 8*rr + 4*half + q (+16 s' as an immediate)
+    {
+        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int row = 8 * rr + 4 * half + q;
+                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
+            }
+    }
+
+    f32x16 Y1[NJT], Y2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
+    float lsum = 0.f;
+
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage_tile = [&](int t, int buf) {
+        const uint32_t sb = smem_base + buf * STAGE;
+        constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
+#pragma unroll
+        for (int n = 0; n < PER_WAVE; ++n) {
+            const int inst = wave_u * PER_WAVE + n;
+            const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row, physical chunk
+            const int row = (pos >> 8) & 31, chp = (pos >> 4) & 15;
+            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            const size_t src = (size_t)t * TM + (pos & ~255) + 16 * ch;
+            glds16(reinterpret_cast<const char*>(pp.mu_pl) + src, sb + inst * 1024);
+            if (BAYES) glds16(reinterpret_cast<const char*>(pp.wp_pl) + src, sb + TM + inst * 1024);
+        }
+        const int c0 = t * BN6;
+        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TM);
+        if (BAYES && wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TM + 256);
+    };
+    auto sign_word_t = [&](int t) -> uint32_t {     // s_out signs of (row i, experts 32t .. 32t+31)
+        if (!BAYES || !row_ok) return 0u;
+        if (INJ) return p.sbits[(int64_t)i * p.nCB + t];
+        return sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)t);
+    };
+    if (t_beg < t_end) stage_tile(t_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        const uint32_t sw = sign_word_t(t) >> (4 * half);
+        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
+        char* sb = smem + buf * STAGE;
+        const int c0 = t * BN6;
+        if (c0 + BN6 > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
+            if (tid < BN6 && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -1e30f;
+            __syncthreads();
+        }
+        f32x16 X1, X2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { X1[r] = 0.f; X2[r] = 0.f; }
+
+        // ---- zT = mu . hT (+ Wp . (h*s_in)T): 8 k-steps of 16 hidden units, A fragments double buffered
+        auto z_load = [&](int s, u32x4 (&am)[3], u32x4 (&aw)[3]) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                am[q] = *reinterpret_cast<const u32x4*>(sb + aoff[s] + q * PLANE);
+                if (BAYES) aw[q] = *reinterpret_cast<const u32x4*>(sb + aoff[s] + TM + q * PLANE);
+            }
+        };
+        {
+            u32x4 am[2][3], aw[2][3];
+            z_load(0, am[0], aw[0]);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                if (s + 1 < NKS) z_load(s + 1, am[(s + 1) & 1], aw[(s + 1) & 1]);
+                X1 = mfma6(am[s & 1], hp[s], X1);
+                if (BAYES) {
+                    u32x4 hs[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) hs[q] = hp[s][q] ^ hm[s];
+                    X2 = mfma6(aw[s & 1], hs, X2);
+                }
+            }
+        }
+
+        // ---- epilogue: lane = batch row i, register r <-> expert c0 + rowmap(r, half)
+        const int dz_row_bytes = p.Bpad * 4;
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BN6 * dz_row_bytes, 0x00020000);
+        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
+        const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
+        const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
+        uint32_t sbit[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cr = (r & 3) + 8 * (r >> 2);
+            float z = X1[r] + bias_mu[cr];
+            sbit[r] = 0u;
+            if (BAYES) {
+                sbit[r] = (sw << (31 - cr)) & 0x80000000u;
+                z += __uint_as_float(__float_as_uint(X2[r] + bias_p[cr]) ^ sbit[r]);
+            }
+            const bool pos = z > 0.f;
+            const float l = pos ? z : z * kLeakySlope;
+            const float lc = fmaxf(l, -80.f);
+            const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
+            lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
+            if (TRAIN) {
+                const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
+                X1[r] = dz;
+            }
+        }
+
+        // ---- dh += dz . mu_tile (+ (dz*s_out) . Wp_tile): the accumulator registers, split, are the A operand
+        if (TRAIN && DH) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 ad[3], as[3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t p1, p2, p3;
+                    split_pair(X1[8 * s2 + 2 * q], X1[8 * s2 + 2 * q + 1], p1, p2, p3);
+                    ad[0][q] = p1; ad[1][q] = p2; ad[2][q] = p3;
+                    if (BAYES) {
+                        const uint32_t m = (sbit[8 * s2 + 2 * q] >> 16) | sbit[8 * s2 + 2 * q + 1];
+                        as[0][q] = p1 ^ m; as[1][q] = p2 ^ m; as[2][q] = p3 ^ m;
+                    }
+                }
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    u32x4 bm[3], bw[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const auto* a0 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[0][jt] + 4096 * s2 + q * PLANE);
+                        const auto* a1 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[1][jt] + 4096 * s2 + q * PLANE);
+                        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0));
+                        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1));
+                        bm[q][0] = lo.x; bm[q][1] = lo.y; bm[q][2] = hi.x; bm[q][3] = hi.y;
+                        if (BAYES) {
+                            const auto* b0 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[0][jt] + 4096 * s2 + q * PLANE + TM);
+                            const auto* b1 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[1][jt] + 4096 * s2 + q * PLANE + TM);
+                            const uint2 l2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b0));
+                            const uint2 h2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b1));
+                            bw[q][0] = l2.x; bw[q][1] = l2.y; bw[q][2] = h2.x; bw[q][3] = h2.y;
+                        }
+                    }
+                    Y1[jt] = mfma6(ad, bm, Y1[jt]);
+                    if (BAYES) Y2[jt] = mfma6(as, bw, Y2[jt]);
+                }
+            }
+        }
+        if (TRAIN) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next tile's DMA is older than this tile's 16 dzT stores
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+
+    if (TRAIN && DH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int irow = i0 + rowmap(r, half);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                float v = Y1[jt][r];
+                if (BAYES) {
+                    const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
+                    const float y2 = Y2[jt][r];
+                    v += ((w >> il) & 1u) ? -y2 : y2;
+                }
+                p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
 static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
@@ -919,6 +1182,33 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     const int grid = g.NRB * g.NCG;
+    if (f.bf16x6 && f.H == 128) {
+        if (phases & 1) {
+            const int64_t Mp = ((int64_t)f.M + BN6 - 1) / BN6 * BN6, n = Mp * (f.H / 2);
+            hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.mu, f.M, f.H, f.mu_pl);
+            if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, f.wp_pl);
+        }
+        if (phases & 2) {
+            OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl;
+            const bool dh = f.dh != nullptr;
+            const size_t lds = 2 * ((size_t)(f.bayes ? 2 : 1) * 3 * BN6 * 128 * 2 + 512);
+#define NTF_L6(BY, TR, DHF, IJ) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ>;                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
+#define NTF_L6B(BY, IJ) do { if (!f.train) NTF_L6(BY, false, false, IJ); else if (dh) NTF_L6(BY, true, true, IJ); else NTF_L6(BY, true, false, IJ); } while (0)
+            if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
+#undef NTF_L6B
+#undef NTF_L6
+        }
+        if (phases & 4) {
+#define NTF_SP(BY) do { if (!f.train) hipLaunchKernelGGL((k_out_special<128, BY, false, false>), dim3(f.B), dim3(64), 0, st, s);         \
+            else if (f.dh) hipLaunchKernelGGL((k_out_special<128, BY, true, true>), dim3(f.B), dim3(64), 0, st, s);                       \
+            else hipLaunchKernelGGL((k_out_special<128, BY, true, false>), dim3(f.B), dim3(64), 0, st, s); } while (0)
+            if (f.bayes) NTF_SP(true); else NTF_SP(false);
+#undef NTF_SP
+        }
+        return;
+    }
 #define NTF_H(HH) do { if (f.bayes) fwd_dispatch<HH, true>(st, f, a, s, grid, phases); else fwd_dispatch<HH, false>(st, f, a, s, grid, phases); } while (0)
     if (f.H == 128) NTF_H(128); else if (f.H == 64) NTF_H(64); else NTF_H(32);
 #undef NTF_H
