@@ -926,25 +926,21 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
     const bool row_ok = i < p.B;
 
     // B operand of zT: h[i][16s + 8*half + e] split into planes; sign masks of s_in for the same elements
-    u32x4 hp[NKS][3], hm[NKS];
-    {
-        uint32_t sinw[NJT];
+    u32x4 hp[NKS][3];
+    uint32_t sinw[NJT];      // s_in sign words of this row: the signed B operand h*s_in is hp ^ (mask built from these bits), per use
 #pragma unroll
-        for (int w = 0; w < NJT; ++w)
-            sinw[w] = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) : 0u;
+    for (int w = 0; w < NJT; ++w)
+        sinw[w] = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) : 0u;
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
-            const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
-            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
+    for (int s = 0; s < NKS; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
+        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t p1, p2, p3;
-                split_pair(x[2 * q], x[2 * q + 1], p1, p2, p3);
-                hp[s][0][q] = p1; hp[s][1][q] = p2; hp[s][2][q] = p3;
-                hm[s][q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
-            }
+        for (int q = 0; q < 4; ++q) {
+            uint32_t p1, p2, p3;
+            split_pair(x[2 * q], x[2 * q + 1], p1, p2, p3);
+            hp[s][0][q] = p1; hp[s][1][q] = p2; hp[s][2][q] = p3;
         }
     }
     const float rmask = row_ok ? 1.f : 0.f;
@@ -952,9 +948,6 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
 
     // lane parts of the LDS addresses
     const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
-    int aoff[NKS];                                  // row read of chunk 2s + half of row il
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) aoff[s] = 256 * il + 16 * ((2 * s + half) ^ fil);
     int troff[2][NJT];                              // transposed read (rr, jt): rows 8*rr + 4*half + q (+16 s' as an immediate)
     {
         const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
@@ -1016,27 +1009,35 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
         f32x16 X1, X2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { X1[r] = 0.f; X2[r] = 0.f; }
+        const uint32_t sbase = lds_addr(sb);
 
-        // ---- zT = mu . hT (+ Wp . (h*s_in)T): 8 k-steps of 16 hidden units, A fragments double buffered
-        auto z_load = [&](int s, u32x4 (&am)[3], u32x4 (&aw)[3]) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                am[q] = *reinterpret_cast<const u32x4*>(sb + aoff[s] + q * PLANE);
-                if (BAYES) aw[q] = *reinterpret_cast<const u32x4*>(sb + aoff[s] + TM + q * PLANE);
-            }
-        };
+        // ---- zT = mu . hT (+ Wp . (h*s_in)T): 8 k-steps of 16 hidden units; half-groups (k-step, matrix) of 3 fragment reads + 6 MFMAs,
+        // the reads of the next half-group in flight under the MFMAs of the current one
         {
-            u32x4 am[2][3], aw[2][3];
-            z_load(0, am[0], aw[0]);
+            constexpr int NHG = NKS * NMAT;
+            auto z_load = [&](int hg, u32x4 (&fr)[3]) {
+                const int s = hg / NMAT, mat = hg % NMAT;
+                const char* ap = sb + 256 * il + 16 * ((2 * s + half) ^ fil) + mat * TM;
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                if (s + 1 < NKS) z_load(s + 1, am[(s + 1) & 1], aw[(s + 1) & 1]);
-                X1 = mfma6(am[s & 1], hp[s], X1);
-                if (BAYES) {
+                for (int q = 0; q < 3; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
+            };
+            u32x4 fr[2][3];
+            z_load(0, fr[0]);
+#pragma unroll
+            for (int hg = 0; hg < NHG; ++hg) {
+                if (hg + 1 < NHG) z_load(hg + 1, fr[(hg + 1) & 1]);
+                asm volatile("" ::: "memory");
+                const int s = hg / NMAT, mat = hg % NMAT;
+                if (mat == 0) X1 = mfma6(fr[hg & 1], hp[s], X1);
+                else {
                     u32x4 hs[3];
+                    const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
+                    u32x4 hm;
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) hs[q] = hp[s][q] ^ hm[s];
-                    X2 = mfma6(aw[s & 1], hs, X2);
+                    for (int q = 0; q < 4; ++q) hm[q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) hs[q] = hp[s][q] ^ hm;
+                    X2 = mfma6(fr[hg & 1], hs, X2);
                 }
             }
         }
@@ -1047,16 +1048,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
         const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
         const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
-        uint32_t sbit[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        auto epilogue = [&](int r) {
             const int cr = (r & 3) + 8 * (r >> 2);
             float z = X1[r] + bias_mu[cr];
-            sbit[r] = 0u;
-            if (BAYES) {
-                sbit[r] = (sw << (31 - cr)) & 0x80000000u;
-                z += __uint_as_float(__float_as_uint(X2[r] + bias_p[cr]) ^ sbit[r]);
-            }
+            if (BAYES) z += __uint_as_float(__float_as_uint(X2[r] + bias_p[cr]) ^ ((sw << (31 - cr)) & 0x80000000u));
             const bool pos = z > 0.f;
             const float l = pos ? z : z * kLeakySlope;
             const float lc = fmaxf(l, -80.f);
@@ -1067,43 +1062,58 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
                 X1[r] = dz;
             }
-        }
-
-        // ---- dh += dz . mu_tile (+ (dz*s_out) . Wp_tile): the accumulator registers, split, are the A operand
-        if (TRAIN && DH) {
+        };
+        if (!(TRAIN && DH)) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 ad[3], as[3];
+            for (int r = 0; r < 16; ++r) epilogue(r);
+        } else {
+            // ---- dh += dz . mu_tile (+ (dz*s_out) . Wp_tile): the accumulator registers, split, are the A operand.  Only the first half of
+            // the epilogue stands alone; the second half is spread over the MFMAs of the first k-step
+            auto split_a = [&](int s2, u32x4 (&ad)[3], u32x4 (&as)[3]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     uint32_t p1, p2, p3;
-                    split_pair(X1[8 * s2 + 2 * q], X1[8 * s2 + 2 * q + 1], p1, p2, p3);
+                    const int r0 = 8 * s2 + 2 * q;
+                    split_pair(X1[r0], X1[r0 + 1], p1, p2, p3);
                     ad[0][q] = p1; ad[1][q] = p2; ad[2][q] = p3;
                     if (BAYES) {
-                        const uint32_t m = (sbit[8 * s2 + 2 * q] >> 16) | sbit[8 * s2 + 2 * q + 1];
+                        const int c0r = (r0 & 3) + 8 * (r0 >> 2);   // registers r0, r0+1 are experts c0r, c0r+1 (+4*half, folded into sw)
+                        const uint32_t m = (((sw << (31 - c0r)) & 0x80000000u) >> 16) | ((sw << (30 - c0r)) & 0x80000000u);
                         as[0][q] = p1 ^ m; as[1][q] = p2 ^ m; as[2][q] = p3 ^ m;
                     }
                 }
+            };
+            auto tr_load = [&](int g, u32x4 (&bf)[3]) {   // g = (s2, jt, mat): B fragments (k = expert, n = hidden unit 32 jt + il)
+                const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
 #pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) {
-                    u32x4 bm[3], bw[3];
+                for (int q = 0; q < 3; ++q) {
+                    const uint32_t o = 4096 * s2 + q * PLANE + mat * TM;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[0][jt] + o)));
+                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[1][jt] + o)));
+                    bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
+                }
+            };
+            constexpr int NG = 2 * NJT * NMAT;
+            u32x4 bf[2][3];
+            tr_load(0, bf[0]);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const auto* a0 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[0][jt] + 4096 * s2 + q * PLANE);
-                        const auto* a1 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[1][jt] + 4096 * s2 + q * PLANE);
-                        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0));
-                        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1));
-                        bm[q][0] = lo.x; bm[q][1] = lo.y; bm[q][2] = hi.x; bm[q][3] = hi.y;
-                        if (BAYES) {
-                            const auto* b0 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[0][jt] + 4096 * s2 + q * PLANE + TM);
-                            const auto* b1 = reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_addr(sb) + troff[1][jt] + 4096 * s2 + q * PLANE + TM);
-                            const uint2 l2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b0));
-                            const uint2 h2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b1));
-                            bw[q][0] = l2.x; bw[q][1] = l2.y; bw[q][2] = h2.x; bw[q][3] = h2.y;
-                        }
+            for (int r = 0; r < 8; ++r) epilogue(r);
+            u32x4 ad[2][3], as[2][3];
+            split_a(0, ad[0], as[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) tr_load(g + 1, bf[(g + 1) & 1]);
+                asm volatile("" ::: "memory");
+                const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
+                if (mat == 0) Y1[jt] = mfma6(ad[s2], bf[g & 1], Y1[jt]);
+                else Y2[jt] = mfma6(as[s2], bf[g & 1], Y2[jt]);
+                if (s2 == 0) {   // second half of the epilogue in the shadow of the first k-step's MFMAs
+                    constexpr int PER = 8 / (NJT * NMAT) > 0 ? 8 / (NJT * NMAT) : 1;
+                    if (g * PER < 8) {
+#pragma unroll
+                        for (int rr = 0; rr < PER; ++rr) epilogue(8 + g * PER + rr);
                     }
-                    Y1[jt] = mfma6(ad, bm, Y1[jt]);
-                    if (BAYES) Y2[jt] = mfma6(as, bw, Y2[jt]);
+                    if (g == NJT * NMAT - 1) split_a(1, ad[1], as[1]);
                 }
             }
         }
