@@ -60,6 +60,23 @@ __device__ __forceinline__ void normal4(const NormalSpec& s, int64_t q, int64_t 
     z[2] = r1 * __builtin_amdgcn_cosf(a1); z[3] = r1 * __builtin_amdgcn_sinf(a1);
 }
 
+// two f32 -> three packed bf16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p1) : "v"(x0), "v"(x1));
+    const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p2) : "v"(r0), "v"(r1));
+    const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p3) : "v"(s0), "v"(s1));
+}
+// bf16 split planes of a row-major [M, H] f32 matrix for the bf16x6 forward kernel: [tile of 32 rows][plane 0..2][row in tile][H];
+// stores the planes of the element pair (row, j), (row, j+1), j even
+__device__ __forceinline__ void planes_store_pair(uint16_t* planes, int64_t row, int j, int H, float x0, float x1) {
+    uint32_t p1, p2, p3;
+    split_pair(x0, x1, p1, p2, p3);
+    uint32_t* o = reinterpret_cast<uint32_t*>(planes + ((row >> 5) * 96 + (row & 31)) * H + j);
+    o[0] = p1; o[(size_t)16 * H] = p2; o[(size_t)32 * H] = p3;
+}
+
 __device__ __forceinline__ float softplus_rho(float rho) { return log1pf(expf(rho)); }  // sigma = log1p(exp(rho))
 
 // terms of binary_cross_entropy_with_logits on l = leaky_relu(z) (src/mdl/fnn.py:25,46):

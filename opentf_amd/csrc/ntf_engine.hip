@@ -198,6 +198,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
         if (cfg->mfma != NTF_MFMA_F32 && e->layers[e->L - 1].in == 128) {
             A(dmalloc(e, &e->pl_mu, fused_planes_elems(M, 128)));
             if (cfg->bayesian) A(dmalloc(e, &e->pl_wp, fused_planes_elems(M, 128)));
+            if (rc == NTF_OK) { hipMemsetAsync(e->pl_mu, 0, (size_t)fused_planes_elems(M, 128) * 2, e->st); if (e->pl_wp) hipMemsetAsync(e->pl_wp, 0, (size_t)fused_planes_elems(M, 128) * 2, e->st); }
         }
     }
     e->inj_eps_w.assign(e->L, nullptr); e->inj_eps_b.assign(e->L, nullptr); e->inj_s_in.assign(e->L, nullptr); e->inj_s_out.assign(e->L, nullptr);
@@ -606,7 +607,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if (e->cfg.bayesian) {
             { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                     1.0 / (double)lo.nw(), e->d_kl);
+                                     1.0 / (double)lo.nw(), e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in);   // + the bf16 planes of Wp and mu
+              f.planes_ready = e->pl_wp != nullptr;
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                      1.0 / (double)lo.out, e->d_kl); }
             f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];

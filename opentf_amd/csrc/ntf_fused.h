@@ -23,6 +23,7 @@ struct FusedOut {
     const int64_t* neg = nullptr; int ns = 0; float* row_fix = nullptr;
     // bf16x6 arithmetic (H = 128): scratch for the bf16 split planes of mu / Wp, fused_planes_elems(M, H) uint16 each
     int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
+    int planes_ready = 0;                           // the planes were already written this step (by the Flipout operand producer)
 };
 
 // weight / bias gradients of the output layer from dzT (K = batch); for Flipout the rho gradient is finalised here

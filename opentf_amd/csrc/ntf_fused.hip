@@ -685,14 +685,6 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// two f32 -> three packed bf16 pairs (element 0 in the low half)
-__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p1) : "v"(x0), "v"(x1));
-    const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p2) : "v"(r0), "v"(r1));
-    const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p3) : "v"(s0), "v"(s1));
-}
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 // acc += a*b with a = a1+a2+a3, b = b1+b2+b3 (smallest terms first)
 __device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc) {
@@ -893,10 +885,7 @@ __global__ void k_split_planes(const float* __restrict__ W, int M, int H, uint16
     if (row >= Mp) return;
     float x0 = 0.f, x1 = 0.f;
     if (row < M) { const float2 v = *reinterpret_cast<const float2*>(W + row * H + j); x0 = v.x; x1 = v.y; }
-    uint32_t p1, p2, p3;
-    split_pair(x0, x1, p1, p2, p3);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + ((row / BN6) * 3 * BN6 + (row % BN6)) * H + j);
-    o[0] = p1; o[(size_t)BN6 * H / 2] = p2; o[(size_t)BN6 * H] = p3;
+    planes_store_pair(out, row, j, H, x0, x1);
 }
 
 struct OutFwd6Args {
@@ -1193,7 +1182,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     const int grid = g.NRB * g.NCG;
     if (f.bf16x6 && f.H == 128) {
-        if (phases & 1) {
+        if ((phases & 1) && !f.planes_ready) {
             const int64_t Mp = ((int64_t)f.M + BN6 - 1) / BN6 * BN6, n = Mp * (f.H / 2);
             hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.mu, f.M, f.H, f.mu_pl);
             if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, f.wp_pl);

@@ -251,8 +251,10 @@ void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 // =====================================================================================
 // out = softplus(rho) * eps; when mu is given, also adds this tensor's KL(N(mu, sigma^2) || N(0,1)) * w to kl_out.
 // Grid-stride over quads with a bounded grid, so that the KL costs one double atomic per workgroup (<= 2048 in all).
+// planes_w / planes_mu (output layer, bf16x6 arithmetic): also the bf16 split planes of out and of pmu for the forward kernel.
 __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict__ rho, const float* __restrict__ mu, int64_t n, NormalSpec eps,
-                                                         float* __restrict__ out, double w, double* kl_out) {
+                                                         float* __restrict__ out, double w, double* kl_out, uint16_t* __restrict__ planes_w,
+                                                         uint16_t* __restrict__ planes_mu, const float* __restrict__ pmu, int H) {
     const int64_t quads = (n + 3) / 4;
     float kl = 0.f;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -271,6 +273,14 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
                 if (mu) kl += -logf(sigma) + 0.5f * (sigma * sigma + mv[j] * mv[j]) - 0.5f;
             }
             *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            if (planes_w) {   // H % 4 == 0: the quad lies in one row
+                const int64_t row = e0 / H; const int j = (int)(e0 - row * H);
+                planes_store_pair(planes_w, row, j, H, ov[0], ov[1]); planes_store_pair(planes_w, row, j + 2, H, ov[2], ov[3]);
+                if (planes_mu) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(pmu + e0);
+                    planes_store_pair(planes_mu, row, j, H, m4.x, m4.y); planes_store_pair(planes_mu, row, j + 2, H, m4.z, m4.w);
+                }
+            }
         } else {
             for (int j = 0; j < 4 && e0 + j < n; ++j) {
                 const float sigma = softplus_rho(rho[e0 + j]);
@@ -284,11 +294,12 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
         if (threadIdx.x == 0) atomicAdd(kl_out, s * w);
     }
 }
-void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out) {
+void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out,
+                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H) {
     if (n <= 0) return;
     const int64_t quads = (n + 3) / 4;
     const int blocks = (int)std::min<int64_t>((quads + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out);
+    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H);
 }
 
 __global__ void k_flipout_grad_finalize(const float* __restrict__ mu, const float* __restrict__ rho, float* __restrict__ g_mu,
