@@ -653,7 +653,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.dzT = e->dZout; f.h = in; f.g_mu = gW; f.g_rho = gRW; f.g_b = gb; f.g_bp = gRb; f.ws = e->fws;
             f.mu = e->P + li.off[NTF_P_WEIGHT];
             f.s_out = sout_; f.s_out_inj = e->cfg.bayesian && (sout_.inj != nullptr || sin_.inj != nullptr);
-            f.bf16x6 = e->cfg.mfma != NTF_MFMA_F32 && !(c.fuse_adam && e->cfg.fuse_adam == 1);   // default: bf16x6
+            f.bf16x6 = e->cfg.mfma != NTF_MFMA_F32;   // default: bf16x6
             if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws); }
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
             if (c.defer_dw) {

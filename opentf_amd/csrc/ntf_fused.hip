@@ -721,8 +721,8 @@ __global__ void k_prep_planes_T(const float* __restrict__ hz, const float* __res
 //   B: the bf16 planes of h / h*s_in for the K block ([plane][j][32 rows], chunks swizzled with (j>>2)&3): one ds_read_b128 per fragment.
 // No compiler-visible global load sits in the loop: hipcc would wait for it with a vmcnt that, in the real in-order queue, also waits
 // for the DMA issued just before.
-template <int H, bool BAYES>
-__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {
+template <int H, bool BAYES, bool ADAM>
+__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   // ADAM: update mu / rho and their moments in the epilogue (see DwArgs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NJT = H / 32;
     constexpr int NPL = BAYES ? 6 : 3;
@@ -850,15 +850,30 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
             const int64_t idx = (int64_t)cr * H + 32 * jt + il;
-            if (!BAYES) { p.g_mu[idx] = acc1[jt][r]; continue; }
-            const float rh = p.rho[idx], w = p.wp[idx], m = p.mu[idx];
-            // sigma = log1p(e^rho), sigmoid(rho) = e^rho / (1 + e^rho) on the hardware exp2/log2/rcp (the library expf/log1pf cost more vector
-            // instructions here than the whole K loop); the short series keeps log1p accurate where 1 + e^rho rounds
-            const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
-            const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
-            const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
-            p.g_mu[idx] = acc1[jt][r] + p.klw * m;
-            p.g_rho[idx] = acc2[jt][r] * (w * isig) * sg + p.klw * (sigma - isig) * sg;
+            float gm = acc1[jt][r], gr = 0.f, pm = 0.f, rh = 0.f;
+            if (BAYES) {
+                rh = ADAM ? p.w_rho[idx] : p.rho[idx];
+                pm = ADAM ? p.w_mu[idx] : p.mu[idx];
+                const float w = p.wp[idx];
+                // sigma = log1p(e^rho), sigmoid(rho) = e^rho / (1 + e^rho) on the hardware exp2/log2/rcp (the library expf/log1pf cost more vector
+                // instructions here than the whole K loop); the short series keeps log1p accurate where 1 + e^rho rounds
+                const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
+                const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
+                const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
+                gm += p.klw * pm;
+                gr = acc2[jt][r] * (w * isig) * sg + p.klw * (sigma - isig) * sg;
+            } else if (ADAM) pm = p.w_mu[idx];
+            if (!ADAM) { p.g_mu[idx] = gm; if (BAYES) p.g_rho[idx] = gr; }
+            else {
+                float m = p.m_mu[idx], v = p.v_mu[idx];
+                p.w_mu[idx] = adam_update(pm, gm, m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                p.m_mu[idx] = m; p.v_mu[idx] = v;
+                if (BAYES) {
+                    float m2 = p.m_rho[idx], v2 = p.v_rho[idx];
+                    p.w_rho[idx] = adam_update(rh, gr, m2, v2, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                    p.m_rho[idx] = m2; p.v_rho[idx] = v2;
+                }
+            }
         }
     }
 }
@@ -1229,14 +1244,15 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.wg_begin = f.wg_count > 0 ? f.wg_begin : 0;
     if (grid <= 0) return;
     a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
-    if (f.bf16x6 && !f.adam) {
-#define NTF_DWB(HH) do { const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 6 : 3) * HH * 64);                                                     \
-        if (f.bayes) { auto kf = k_out_dw_b6<HH, true>; hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                       hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); }                                                 \
-        else { auto kf = k_out_dw_b6<HH, false>; hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-               hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } } while (0)
+    if (f.bf16x6) {
+#define NTF_DWB1(HH, BY, AD) do { auto kf = k_out_dw_b6<HH, BY, AD>; const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(BY ? 6 : 3) * HH * 64);         \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
+#define NTF_DWB(HH) do { if (f.bayes) { if (f.adam) NTF_DWB1(HH, true, true); else NTF_DWB1(HH, true, false); }                                            \
+                         else { if (f.adam) NTF_DWB1(HH, false, true); else NTF_DWB1(HH, false, false); } } while (0)
         if (f.H == 128) NTF_DWB(128); else if (f.H == 64) NTF_DWB(64); else NTF_DWB(32);
 #undef NTF_DWB
+#undef NTF_DWB1
         return;
     }
 #define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \

@@ -268,9 +268,10 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
             if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + e0); mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float sigma = softplus_rho(rv[j]);
+                float ls;
+                const float sigma = softplus_rho_fast(rv[j], ls);
                 ov[j] = sigma * z[j];
-                if (mu) kl += -logf(sigma) + 0.5f * (sigma * sigma + mv[j] * mv[j]) - 0.5f;
+                if (mu) kl += -ls + 0.5f * (sigma * sigma + mv[j] * mv[j]) - 0.5f;
             }
             *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
             if (planes_w) {   // H % 4 == 0: the quad lies in one row

@@ -184,15 +184,16 @@ def test_multihot_first_layer_step_vs_oracle(bayesian, S, H, M, B):
             for k in sd: sd[k].copy_(torch.from_numpy(state[k]))
 
 
+@pytest.mark.parametrize("mfma", ["f32", None])
 @pytest.mark.parametrize("bayesian", [False, True])
-def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian):
+def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian, mfma):
     """cfg.fuse_adam moves the output layer's Adam into the dW kernel's epilogue: same parameters, step for step."""
     sd, X, y = _bnn_case(64, [128], 900, 150, 3)
     if not bayesian:
         torch.manual_seed(3); sd = O.fnn_init(64, [128], 900)
     def run(fuse):
-        # mfma="f32": mode 1 exists only for the f32-MFMA dW kernel; this test is about WHERE Adam runs, not about the product arithmetic
-        e = _engine([64, 128, 900], bayesian=bayesian, max_batch=150, ns=4, nsd="uniform", seed=21, lr=1e-2, fuse_adam=fuse, mfma="f32")
+        # the three modes share one product arithmetic (exact-f32 MFMA or the default bf16x6): this test is about WHERE Adam runs
+        e = _engine([64, 128, 900], bayesian=bayesian, max_batch=150, ns=4, nsd="uniform", seed=21, lr=1e-2, fuse_adam=fuse, mfma=mfma)
         e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
         losses = [e.train_step(np.arange(150)) for _ in range(4)]
         return losses, e.state_dict()
