@@ -404,6 +404,25 @@ def test_forward_probs_topk_and_uncertainty():
     assert np.array_equal(np.sort(idx, axis=1), np.sort(ti.numpy(), axis=1))
 
 
+@pytest.mark.parametrize("M,K,ties", [(40000, 50, False), (70001, 100, False), (40000, 20, True), (33000, 256, False)])
+def test_topk_sampled_threshold_path_is_exact(M, K, ties):
+    """Rows long enough for the sampled-threshold selection (ntf_kernels.hip k_topk_rows): the result must be the exact, deterministic
+    ranking (value descending, expert id ascending among equals) — also when a tie group straddles the K-th place."""
+    torch.manual_seed(M)
+    fsd = O.fnn_init(16, [32], M)
+    if ties:   # many experts share one weight row and bias -> identical probabilities
+        fsd["layers.1.weight"][100:400] = fsd["layers.1.weight"][100]; fsd["layers.1.bias"][100:400] = 3.0
+    X = torch.randn(12, 16)
+    f = _engine([16, 32, M], max_batch=12)
+    f.load_state_dict(fsd); f.set_dense_input(X.numpy())
+    p = f.forward(np.arange(12))
+    vals, idx = f.forward_topk(np.arange(12), K)
+    for i in range(12):
+        order = np.lexsort((np.arange(M), -p[i].astype(np.float64)))[:K]     # value desc, id asc
+        assert np.array_equal(idx[i], order), i
+        assert np.array_equal(vals[i], p[i][order])
+
+
 def test_epoch_api_matches_step_api():
     sd, X, y = _bnn_case(16, [16], 90, 50, 1)
     fsd = O.fnn_init(16, [16], 90)
