@@ -952,11 +952,53 @@ extern "C" int ntf_logits(ntf_engine* e, const int64_t* rows, int32_t B, const n
     return NTF_OK;
 }
 
+// one MC pass of the inference through the fused bf16x6 forward kernel: probabilities accumulate in the transposed buffer dZout
+static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, int pass, int passes, bool want_unc) {
+    int r;
+    if ((r = check_ready(e, false))) return r;
+    StepCtx c; c.B = B; c.global_B = B; c.inj = inj; c.train = false; c.step = e->step++;
+    if ((r = stage_rows(e, rows, B, false, &c.rows_dev))) return r;
+    StepCtx ci = c;
+    ntf_inject noneg;
+    if (inj) { noneg = *inj; noneg.neg_idx = nullptr; ci.inj = &noneg; }
+    if ((r = stage_all_inj(e, ci))) return r;
+    if ((r = make_input(e, c))) return r;
+    if ((r = forward_layers(e, c, true, true))) return r;   // hidden layers only
+    const int M = e->cfg.dims[e->L];
+    const LayerInfo& lo = e->layers[e->L - 1];
+    FusedOut f;
+    f.B = B; f.H = lo.in; f.M = M; f.bayes = e->cfg.bayesian; f.train = 0;
+    f.h = e->act[e->L - 1];
+    f.mu = e->P + lo.off[NTF_P_WEIGHT]; f.mu_b = e->P + lo.off[NTF_P_BIAS];
+    f.tnw = e->cfg.tnw; f.tpw = e->cfg.tpw; f.inv_B = 1.f / (float)B;
+    f.dzT = e->dZout; f.dh_slab = e->dh_slab; f.ws = e->fws;
+    f.bf16x6 = 1; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
+    if (e->cfg.bayesian) {
+        { Scope t(e, F_FLIPOUT_OPERAND);
+          launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, e->d_kl,
+                                 e->pl_wp, e->pl_mu, f.mu, lo.in);
+          launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], nullptr, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1], 0.0, e->d_kl); }
+        f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
+        f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
+        f.planes_ready = 1;
+    }
+    f.probs = 1; f.pacc = pass > 0; f.pscale = 1.0f / (float)passes;
+    { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
+    { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
+    { Scope t(e, F_INFER); launch_fused_probs_finish(e->st, B, lo.in, M, e->fws, e->dZout, e->Pbuf, want_unc ? e->ent_mc : nullptr, 1.0f / (float)passes, pass == passes - 1); }
+    return NTF_OK;
+}
+
 static int infer_probs(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, const ntf_inject* inj_per_mc, bool want_unc) {
     const int M = e->cfg.dims[e->L];
     if (!e->Pbuf) DM(e, &e->Pbuf, (int64_t)e->cfg.max_batch * M);
     const int passes = e->cfg.bayesian ? std::max(1, nmc) : 1;
     if (want_unc) HIPCHK(e, hipMemsetAsync(e->ent_mc, 0, (size_t)B * 4, e->st));
+    if (e->pl_mu && fused_ok(e)) {     // bf16x6 forward kernel (H = 128): no dense logits, MC mean accumulated on the fly
+        for (int p = 0; p < passes; ++p) { int r = infer_pass_fused(e, rows, B, inj_per_mc ? &inj_per_mc[p] : nullptr, p, passes, want_unc); if (r) return r; }
+        if (want_unc) { Scope t(e, F_INFER); launch_row_entropy(e->st, e->Pbuf, B, M, e->ent_mean); }
+        return NTF_OK;
+    }
     for (int p = 0; p < passes; ++p) {
         StepCtx c; int r = infer_pass(e, rows, B, inj_per_mc ? &inj_per_mc[p] : nullptr, c); if (r) return r;
         Scope t(e, F_INFER);

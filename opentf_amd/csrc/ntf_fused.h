@@ -23,7 +23,9 @@ struct FusedOut {
     const int64_t* neg = nullptr; int ns = 0; float* row_fix = nullptr;
     // bf16x6 arithmetic (H = 128): scratch for the bf16 split planes of mu / Wp, fused_planes_elems(M, H) uint16 each
     int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
-    int planes_ready = 0;                           // the planes were already written this step (by the Flipout operand producer)
+    int planes_ready = 0;
+    // inference (train = 0, probs = 1): dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale instead of the loss; the row entropy partials go to the workspace
+    int probs = 0, pacc = 0; float pscale = 1.f;                           // the planes were already written this step (by the Flipout operand producer)
 };
 
 // weight / bias gradients of the output layer from dzT (K = batch); for Flipout the rho gradient is finalised here
@@ -55,5 +57,7 @@ int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are p
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
 void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
+// after a probs pass: ent_rows[i] += scale * the pass's entropy terms (nullable); transpose: P [B, M] = PT^T
+void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws, const float* PT, float* P, float* ent_rows, float scale, bool transpose);
 
 }  // namespace ntf

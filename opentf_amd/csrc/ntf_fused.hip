@@ -906,9 +906,12 @@ __global__ void k_split_planes(const float* __restrict__ W, int M, int H, uint16
 struct OutFwd6Args {
     OutFwdArgs a;
     const uint16_t *mu_pl, *wp_pl;   // k_split_planes images of mu and Wp
+    float pscale; int pacc;          // PROBS: dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale; pacc: accumulate onto the previous MC passes
 };
 
-template <bool BAYES, bool TRAIN, bool DH, bool INJ>
+// PROBS (inference, TRAIN = false): instead of the loss, the probabilities sigmoid(leaky_relu(z)) go (accumulated over the MC passes) to the
+// transposed buffer dzT [expert][batch], and lossp gets the row's entropy terms sum_c -p log(p + 1e-15) of this pass (src/mdl/fnn.py:196-208)
+template <bool BAYES, bool TRAIN, bool DH, bool INJ, bool PROBS = false>
 __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const OutFwdArgs& p = pp.a;
@@ -1014,6 +1017,15 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { X1[r] = 0.f; X2[r] = 0.f; }
         const uint32_t sbase = lds_addr(sb);
+        const int dz_row_bytes = p.Bpad * 4;
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BN6 * dz_row_bytes, 0x00020000);
+        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
+        float pold[16];      // PROBS, later MC passes: the running sums of this tile, fetched under the zT products
+        if (PROBS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                pold[r] = pp.pacc ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dz_rsrc, dz_voff, ((r & 3) + 8 * (r >> 2)) * dz_row_bytes, 0)) : 0.f;
+        }
 
         // ---- zT = mu . hT (+ Wp . (h*s_in)T): 8 k-steps of 16 hidden units; half-groups (k-step, matrix) of 3 fragment reads + 6 MFMAs,
         // the reads of the next half-group in flight under the MFMAs of the current one
@@ -1047,9 +1059,6 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
         }
 
         // ---- epilogue: lane = batch row i, register r <-> expert c0 + rowmap(r, half)
-        const int dz_row_bytes = p.Bpad * 4;
-        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BN6 * dz_row_bytes, 0x00020000);
-        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
         const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
         auto epilogue = [&](int r) {
@@ -1060,6 +1069,13 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
             const float l = pos ? z : z * kLeakySlope;
             const float lc = fmaxf(l, -80.f);
             const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
+            if (PROBS) {
+                const float pr = __builtin_amdgcn_rcpf(tt) * rmask;       // experts past M: bias -1e30 -> tt = 1 + e^80 -> 0
+                lsum = fmaf(-pr * 0.6931471805599453f, __builtin_amdgcn_logf(pr + 1e-15f), lsum);
+                const float o = fmaf(pr, pp.pscale, pold[r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
+                return;
+            }
             lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
             if (TRAIN) {
                 const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
@@ -1127,7 +1143,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
     }
 
     lsum += __shfl_xor(lsum, 32, 64);
-    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = PROBS ? lsum : p.tnw * lsum;
 
     if (TRAIN && DH) {
 #pragma unroll
@@ -1203,18 +1219,24 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
             if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, f.wp_pl);
         }
         if (phases & 2) {
-            OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl;
+            OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc;
             const bool dh = f.dh != nullptr;
             const size_t lds = 2 * ((size_t)(f.bayes ? 2 : 1) * 3 * BN6 * 128 * 2 + 512);
 #define NTF_L6(BY, TR, DHF, IJ) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ>;                                                   \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
 #define NTF_L6B(BY, IJ) do { if (!f.train) NTF_L6(BY, false, false, IJ); else if (dh) NTF_L6(BY, true, true, IJ); else NTF_L6(BY, true, false, IJ); } while (0)
-            if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
+            if (f.probs) {
+#define NTF_L6P(BY, IJ) do { auto kf = k_out_fwd_b6<BY, false, false, IJ, true>;                                                \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+                hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
+                if (f.bayes) { if (inj) NTF_L6P(true, true); else NTF_L6P(true, false); } else NTF_L6P(false, false);
+#undef NTF_L6P
+            } else if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
 #undef NTF_L6B
 #undef NTF_L6
         }
-        if (phases & 4) {
+        if ((phases & 4) && !f.probs) {
 #define NTF_SP(BY) do { if (!f.train) hipLaunchKernelGGL((k_out_special<128, BY, false, false>), dim3(f.B), dim3(64), 0, st, s);         \
             else if (f.dh) hipLaunchKernelGGL((k_out_special<128, BY, true, true>), dim3(f.B), dim3(64), 0, st, s);                       \
             else hipLaunchKernelGGL((k_out_special<128, BY, true, false>), dim3(f.B), dim3(64), 0, st, s); } while (0)
@@ -1226,6 +1248,28 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_H(HH) do { if (f.bayes) fwd_dispatch<HH, true>(st, f, a, s, grid, phases); else fwd_dispatch<HH, false>(st, f, a, s, grid, phases); } while (0)
     if (f.H == 128) NTF_H(128); else if (f.H == 64) NTF_H(64); else NTF_H(32);
 #undef NTF_H
+}
+
+// inference helpers: ent[i] += sum over the column groups of the per-row entropy partials; P[i][c] = PT[c][i] (tiled transpose through LDS)
+__global__ void k_ent_slots(const float* __restrict__ lossp, int B, int NCG, float scale, float* __restrict__ ent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float s = 0.f;
+    for (int cg = 0; cg < NCG; ++cg) s += lossp[(int64_t)i * NCG + cg];
+    ent[i] += s * scale;
+}
+__global__ __launch_bounds__(256) void k_transpose_pt(const float* __restrict__ PT, int M, int Bpad, int B, float* __restrict__ P) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, i0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) { const int c = c0 + r; tile[r][tx] = c < M ? PT[(int64_t)c * Bpad + i0 + tx] : 0.f; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int i = i0 + r, c = c0 + tx; if (i < B && c < M) P[(int64_t)i * M + c] = tile[tx][r]; }
+}
+void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws_, const float* PT, float* P, float* ent_rows /*nullable: += this pass * scale*/, float scale, bool transpose) {
+    const Geom g = geom(B, M);
+    const WsLayout w = ws_layout(B, H, M);
+    if (ent_rows) hipLaunchKernelGGL(k_ent_slots, dim3((B + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(static_cast<char*>(ws_) + w.lossp), B, g.NCG, scale, ent_rows);
+    if (transpose) hipLaunchKernelGGL(k_transpose_pt, dim3((M + 31) / 32, g.Bpad / 32), dim3(256), 0, st, PT, M, g.Bpad, B, P);
 }
 
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {

@@ -404,6 +404,32 @@ def test_forward_probs_topk_and_uncertainty():
     assert np.array_equal(np.sort(idx, axis=1), np.sort(ti.numpy(), axis=1))
 
 
+@pytest.mark.parametrize("bayesian", [True, False])
+@pytest.mark.parametrize("mfma", [None, "f32"])
+def test_forward_probs_uncertainty_h128(bayesian, mfma):
+    """H = 128: in the default arithmetic the inference runs through the fused bf16x6 forward kernel (probabilities accumulated over the MC
+    passes in a transposed buffer, no dense logits); mfma="f32" keeps the generic GEMM route.  Both against the oracle with injected noise."""
+    D, M, B, nmc = 24, 1777, 45, 3
+    sd, X, y = _bnn_case(D, [128], M, B, 4)
+    if not bayesian:
+        torch.manual_seed(2); sd = O.fnn_init(D, [128], M); nmc = 1
+    e = _engine([D, 128, M], bayesian=bayesian, max_batch=B, mfma=mfma)
+    e.load_state_dict(sd); e.set_dense_input(X.numpy())
+    noises = [O.draw_flipout_noise(sd, B) for _ in range(nmc)] if bayesian else None
+    injs = [{"eps_w": [n["eps_w"] for n in nz], "eps_b": [n["eps_b"] for n in nz], "s_in": [n["s_in"] for n in nz],
+             "s_out": [n["s_out"] for n in nz]} for nz in noises] if bayesian else None
+    mc = O.predict(sd, X, nmc, noises).numpy()
+    mc = mc if mc.ndim == 3 else mc[None]
+    probs, pu, mu = e.forward(np.arange(B), nmc=nmc, injects=injs, uncertainty=True)
+    _close(probs, mc.mean(0), 1e-5, 1e-7)
+    _close(pu, O.predictive_entropy(mc), 1e-4, 1e-4)
+    if bayesian: _close(mu, O.mutual_information(mc), 1e-3, 2e-4)
+    vals, idx = e.forward_topk(np.arange(B), 40, nmc=1) if not bayesian else (None, None)
+    if not bayesian:
+        order = np.argsort(-probs, axis=1, kind="stable")[:, :40]
+        assert np.array_equal(idx, order)
+
+
 @pytest.mark.parametrize("M,K,ties", [(40000, 50, False), (70001, 100, False), (40000, 20, True), (33000, 256, False)])
 def test_topk_sampled_threshold_path_is_exact(M, K, ties):
     """Rows long enough for the sampled-threshold selection (ntf_kernels.hip k_topk_rows): the result must be the exact, deterministic
