@@ -4,6 +4,7 @@
 #include "ntf_kernels.h"
 #include "ntf_device.h"
 #include <algorithm>
+#include <cstdint>
 
 namespace ntf {
 
@@ -618,22 +619,35 @@ void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, i
 // =====================================================================================
 // Adam (torch.optim.Adam defaults, src/mdl/fnn.py:104,139) over the flat parameter buffer
 // =====================================================================================
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+    m = m + (1.f - b1) * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * b2 + (1.f - b2) * g * g;               // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    p = p - lr_over_bc1 * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+// 16-byte accesses (the segments of the flat buffers are 256-byte aligned and a multiple of 4 floats long up to a scalar tail): a quarter of
+// the memory instructions, which matters when this kernel runs on the side stream beside the dW kernel and competes for issue slots
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                       float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        const float gg = g[e];
-        const float mm = m[e] + (1.f - b1) * (gg - m[e]);          // exp_avg.lerp_(grad, 1 - beta1)
-        const float vv = v[e] * b2 + (1.f - b2) * gg * gg;          // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        m[e] = mm; v[e] = vv;
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        p[e] = p[e] - lr_over_bc1 * (mm / denom);
+                       float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt, int vec) {
+    const int64_t nq = vec ? (n >> 2) : 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[q], mm = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
+        const float4 gg = reinterpret_cast<const float4*>(g)[q];
+        adam_one(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        adam_one(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        reinterpret_cast<float4*>(p)[q] = pp; reinterpret_cast<float4*>(m)[q] = mm; reinterpret_cast<float4*>(v)[q] = vv;
+    }
+    for (int64_t e = (nq << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float pe = p[e], me = m[e], ve = v[e];
+        adam_one(pe, g[e], me, ve, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        p[e] = pe; m[e] = me; v[e] = ve;
     }
 }
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                  float bc1, float bc2_sqrt) {
     if (n <= 0) return;
-    int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr / bc1, b1, b2, eps, bc2_sqrt);
+    const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    const int blocks = (int)std::min<int64_t>(((aligned ? n / 4 : n) + 255) / 256 + 1, 256 * 8);   // unaligned: never the case for the engine's segments
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr / bc1, b1, b2, eps, bc2_sqrt, aligned ? 1 : 0);
 }
 
 __global__ void k_fill(float* p, int64_t n, float v) {
