@@ -507,3 +507,21 @@ def test_device_ranking_metrics_match_committed_reference_results():
         sparse_pred = scipy.sparse.csr_matrix((np.take_along_axis(yp, idx, 1).ravel(), idx.ravel(), np.arange(0, n * k + 1, k)), shape=(n, M))
         df2, _ = metric.calculate_metrics(Y, sparse_pred, 1000, True, trec)
         np.testing.assert_allclose(df2.values, df.values, atol=1e-7)
+
+
+def test_engine_create_destroy_returns_device_memory():
+    """The C ABI owns every device allocation behind the handle (ntf_engine_destroy frees all of it, lazily created buffers included)."""
+    import gc
+    torch.cuda.synchronize()
+    sd, X, y = _bnn_case(64, [128], 20000, 64, 3)
+    def cycle():
+        e = _engine([64, 128, 20000], bayesian=True, max_batch=64, ns=3, nsd="unigram_b", fuse_adam=2)
+        e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
+        e.train_step(np.arange(64)); e.eval_step(np.arange(64)); e.forward_topk(np.arange(64), 10, nmc=2, uncertainty=True)
+        del e; gc.collect()
+    cycle(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(8): cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)     # one engine of this shape holds ~250 MB
