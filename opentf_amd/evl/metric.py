@@ -72,9 +72,48 @@ def calculate_metrics(Y, Y_, topK=None, per_instance=False, metrics=("P_2,5", "r
     return (df if per_instance else None), df_mean
 
 
+def micro_auc_sparse(Y, Y_):
+    """Micro-averaged ROC AUC of a SPARSE score matrix against sparse 0/1 truth without densifying either: the Mann-Whitney statistic
+    with mid-ranks, U = sum over positives of (#negatives scored lower + 0.5 #negatives scored equal), AUC = U / (P * N_neg).  All the
+    entries a top-K prediction does not store are one tie group at score 0.  Equals sklearn's `roc_auc_score(Y.toarray(),
+    Y_.toarray(), average='micro')` (what src/evl/metric.py:36-41 computes) — which needs the dense [n_test, M] pair."""
+    Y = sp.csr_matrix(Y); Y_ = sp.csr_matrix(Y_)
+    n, M = Y_.shape
+    total = n * M
+    P = int((Y.data != 0).sum())
+    if P == 0 or P == total:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    Yb = Y.copy(); Yb.data = (Yb.data != 0).astype(np.int8); Yb.eliminate_zeros(); Yb.sort_indices()
+    S = Y_.copy(); S.sum_duplicates(); S.sort_indices()
+    # label of every stored score: flat keys row * M + col looked up among the positives' keys
+    key_s = (np.repeat(np.arange(n, dtype=np.int64), np.diff(S.indptr)) * M + S.indices.astype(np.int64))
+    key_p = (np.repeat(np.arange(n, dtype=np.int64), np.diff(Yb.indptr)) * M + Yb.indices.astype(np.int64))
+    is_pos = np.isin(key_s, key_p, assume_unique=True)
+    scores = S.data.astype(np.float64)
+    pos_stored = int(is_pos.sum())
+    # tie groups over the stored scores plus the implicit zeros
+    vals, inv = np.unique(scores, return_inverse=True)
+    p_g = np.bincount(inv, weights=is_pos.astype(np.float64), minlength=len(vals))
+    n_g = np.bincount(inv, minlength=len(vals)).astype(np.float64) - p_g
+    imp_total = total - len(scores)
+    imp_pos = P - pos_stored
+    z = np.searchsorted(vals, 0.0)
+    if z < len(vals) and vals[z] == 0.0:
+        p_g[z] += imp_pos; n_g[z] += imp_total - imp_pos
+    else:
+        vals = np.insert(vals, z, 0.0); p_g = np.insert(p_g, z, imp_pos); n_g = np.insert(n_g, z, imp_total - imp_pos)
+    neg_below = np.concatenate([[0.0], np.cumsum(n_g)[:-1]])
+    U = float(np.sum(p_g * (neg_below + 0.5 * n_g)))
+    return U / (float(P) * float(total - P))
+
+
 def calculate_auc_roc(Y, Y_, curve=False):
-    from sklearn import metrics as skm
+    """src/evl/metric.py:36-41.  Sparse predictions (the top-K `.pred` files) go through `micro_auc_sparse`; dense ones, and the curve
+    itself, through sklearn as in the reference."""
     assert Y.shape == Y_.shape
+    if sp.issparse(Y_) and not curve:
+        return micro_auc_sparse(Y, Y_), None
+    from sklearn import metrics as skm
     dense = Y_.toarray() if sp.issparse(Y_) else np.asarray(Y_)
     auc = skm.roc_auc_score(Y.toarray(), dense, average="micro", multi_class="ovr")
     if curve:

@@ -172,3 +172,27 @@ def test_lil_ingestion_as_csr_and_validate():
     assert not ok and "used in no teams" in msg and "5" in msg
     dense[0, 5] = 1
     assert validate({"skill": scipy.sparse.lil_matrix(dense), "member": scipy.sparse.lil_matrix(dense)}) == (True, "")
+
+
+def test_micro_auc_on_sparse_predictions_equals_sklearn_dense():
+    """`calculate_auc_roc` (src/evl/metric.py:36-41) on top-K sparse predictions without the dense [n_test, M] pair the reference builds:
+    equal to sklearn's micro-averaged roc_auc_score of the densified matrices, ties (the implicit zeros, repeated scores) included."""
+    import scipy.sparse as sp
+    from sklearn import metrics as skm
+    from opentf_amd.evl.metric import calculate_auc_roc, micro_auc_sparse
+    rng = np.random.default_rng(0)
+    for n, M, K, dens in [(40, 300, 10, 0.02), (7, 50, 50, 0.2), (100, 64, 5, 0.1), (3, 1000, 1, 0.003)]:
+        Y = (rng.random((n, M)) < dens).astype(np.uint8); Y[0, 0] = 1
+        P = np.zeros((n, M), np.float32)
+        for i in range(n):
+            cols = rng.choice(M, K, replace=False)
+            P[i, cols] = np.round(rng.random(K).astype(np.float32), 2 if K > 5 else 6)    # rounded: ties among stored scores too
+            if K > 2: P[i, cols[0]] = 0.0                                                 # an explicitly stored zero
+        ref = skm.roc_auc_score(Y, P, average="micro")
+        S = sp.csr_matrix(P)
+        got, curve = calculate_auc_roc(sp.csr_matrix(Y), S)
+        assert curve is None and abs(got - ref) < 1e-12, (n, M, K, got, ref)
+        S2 = sp.coo_matrix(P).tocsr()   # without the explicit zero: the entry is part of the implicit tie group
+        assert abs(micro_auc_sparse(sp.lil_matrix(Y), S2) - ref) < 1e-12
+    dense_auc, _ = calculate_auc_roc(sp.csr_matrix(Y), P)   # dense predictions keep the reference's sklearn route
+    assert abs(dense_auc - ref) < 1e-12
