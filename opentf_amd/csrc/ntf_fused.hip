@@ -977,6 +977,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
 
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // forward-only tiles (eval, inference) take about as long as a DMA round trip: keep TWO tiles in flight there (three LDS stages)
+    constexpr bool DEEP = !TRAIN && !INJ;
+    constexpr int NST = DEEP ? 3 : 2;
+    constexpr int NDMA = (TM / 1024 / 4) * NMAT + NMAT;   // DMA instructions per wave per tile (DEEP)
     auto stage_tile = [&](int t, int buf) {
         const uint32_t sb = smem_base + buf * STAGE;
         constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
@@ -991,8 +995,8 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
             if (BAYES) glds16(reinterpret_cast<const char*>(pp.wp_pl) + src, sb + TM + inst * 1024);
         }
         const int c0 = t * BN6;
-        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TM);
-        if (BAYES && wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TM + 256);
+        if (DEEP || wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TM);     // DEEP: every wave, so that all issue NDMA instructions
+        if (BAYES && (DEEP || wave_u == 1)) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TM + 256);
     };
     auto sign_word_t = [&](int t) -> uint32_t {     // s_out signs of (row i, experts 32t .. 32t+31)
         if (!BAYES || !row_ok) return 0u;
@@ -1000,13 +1004,15 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
         return sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)t);
     };
     if (t_beg < t_end) stage_tile(t_beg, 0);
+    if (DEEP && t_beg + 1 < t_end) stage_tile(t_beg + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = t_beg; t < t_end; ++t) {
-        const int buf = (t - t_beg) & 1;
+        const int buf = (t - t_beg) % NST;
         const uint32_t sw = sign_word_t(t) >> (4 * half);
-        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
+        if (DEEP) { if (t + 2 < t_end) stage_tile(t + 2, (buf + 2) % NST); }
+        else if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
         char* sb = smem + buf * STAGE;
         const int c0 = t * BN6;
         if (c0 + BN6 > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
@@ -1138,7 +1144,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
             }
         }
         if (TRAIN) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next tile's DMA is older than this tile's 16 dzT stores
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (DEEP && t + 2 < t_end) {   // tile t+1 has landed once only tile t+2's DMA (and, PROBS, this tile's 16 stores) are outstanding
+            if (PROBS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + 16) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
@@ -1221,7 +1230,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
         if (phases & 2) {
             OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc;
             const bool dh = f.dh != nullptr;
-            const size_t lds = 2 * ((size_t)(f.bayes ? 2 : 1) * 3 * BN6 * 128 * 2 + 512);
+            const size_t lds = (size_t)((!f.train && !inj) ? 3 : 2) * ((size_t)(f.bayes ? 2 : 1) * 3 * BN6 * 128 * 2 + 512);
 #define NTF_L6(BY, TR, DHF, IJ) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ>;                                                   \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
