@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2516.6 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 = 1024 FLOP/clk/SIMD = 16 x the f32 MFMA, dense (no sparsity)
+BF16_MFMA_PEAK_TFLOPS = 2516.6 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 / _f16 = 1024 FLOP/clk/SIMD = 16 x the f32 MFMA, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--experts", type=int, default=0, help="override the number of experts (debug)")
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--fuse-adam", type=int, default=2, help="0 flat Adam, 1 in the dW epilogue, 2 chunked beside dW on a side stream (N=1 only)")
-    ap.add_argument("--mfma", default="default", choices=["default", "f32", "bf16x6"], help="arithmetic of the fused output-layer products (include/opentf_amd.h ntf_mfma)")
+    ap.add_argument("--mfma", default="default", choices=["default", "f32", "bf16x6", "fp16x3"], help="arithmetic of the fused output-layer products (include/opentf_amd.h ntf_mfma)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-bench", action="store_true", help="(default at N=1) also time the whole-dataset gather (get_dense_vecs)")
     ap.add_argument("--no-gather-bench", action="store_true")
@@ -90,7 +90,7 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=5):
 def pmc_traffic(family, a, ds):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
     as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
-    path = os.path.join(ROOT, "profiles", "r1_d_pmc_traffic_and_sq.json" if a.mfma != "f32" else "r1_c_pmc_traffic_and_sq.json")
+    path = os.path.join(ROOT, "profiles", {"f32": "r1_c_pmc_traffic_and_sq.json", "bf16x6": "r1_d_pmc_traffic_and_sq.json"}.get(a.mfma, "r1_e_pmc_traffic_and_sq.json"))
     if not (os.path.exists(path) and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
             and a.input == "meanpool" and not a.rows and not a.experts):
         return None
@@ -193,16 +193,19 @@ def main():
         ach = flops_per_launch[dom] / (ms / calls * 1e-3) / 1e12
         # arithmetic of the dominant kernel: "bf16x6" = every f32 operand split exactly into 3 bf16 values, a product = 6 bf16 MFMA products
         # accumulated in f32 (f32-accurate).  The roof for ALGORITHMIC flops is then the dense bf16 MFMA peak / 6.
-        b6 = a.mfma != "f32" and not a.no_fused and ((dom == "out_fused_dw_adam" and a.fuse_adam != 1) or (dom == "out_fused_fwd_loss_dh" and a.hidden == 128))
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if b6 else F32_MFMA_PEAK_TFLOPS
+        split = a.mfma != "f32" and not a.no_fused and ((dom == "out_fused_dw_adam") or (dom == "out_fused_fwd_loss_dh" and a.hidden == 128))
+        nprod = (6 if a.mfma == "bf16x6" else 3) if split else 1
+        peak = BF16_MFMA_PEAK_TFLOPS / nprod if split else F32_MFMA_PEAK_TFLOPS
+        arith = {1: "f32 MFMA (v_mfma_f32_32x32x2_f32)",
+                 6: "bf16x6: operands split exactly into 3 bf16 values, 6 bf16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 6",
+                 3: "fp16x3: operands * 2^k split into 2 fp16 values (22 bits), 3 fp16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 3"}[nprod]
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": pmc_traffic(dom, a, ds), "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[dom],
-                "arithmetic": ("bf16x6: 6 bf16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 6" if b6 else "f32 MFMA (v_mfma_f32_32x32x2_f32)"),
-                "hw_mfma_tflops": ach * (6.0 if b6 else 1.0)}
+                "arithmetic": arith, "hw_mfma_tflops": ach * nprod}
     out = {
         "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if a.mfma == "f32" else "f32 (bf16x6 split products, f32 accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"f32": "f32", "bf16x6": "f32 (bf16x6 split products, f32 accumulate)"}.get(a.mfma, "f32 (fp16x3 split products, f32 accumulate)"), "data": "synthetic",
         "config": {"workload": f"{a.dataset} mt10.ts2 shapes N={ds['N']} S={ds['S']} M={M}; {a.model}{' (Flipout)' if bayesian else ''} on " +
                                (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
                                f"h=[{H}], b={B}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3", "global_batch": gB, "parallelism": f"dp{world}"},

@@ -68,13 +68,31 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p1, uin
     const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p3) : "v"(s0), "v"(s1));
 }
-// bf16 split planes of a row-major [M, H] f32 matrix for the bf16x6 forward kernel: [tile of 32 rows][plane 0..2][row in tile][H];
+// two f32 -> two packed fp16 pairs, x = x1 + x2 to 22 bits (both conversions round to nearest; fp16 subnormals are honoured by the MFMA)
+__device__ __forceinline__ void split_pair_h(float x0, float x1, uint32_t& p1, uint32_t& p2) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t x = {x0, x1};
+    const h2_t a1 = __builtin_convertvector(x, h2_t);
+    const f2_t r = x - __builtin_convertvector(a1, f2_t);
+    const h2_t a2 = __builtin_convertvector(r, h2_t);
+    p1 = __builtin_bit_cast(uint32_t, a1); p2 = __builtin_bit_cast(uint32_t, a2);
+}
+// NP = 3: bf16 three-way split (bf16x6 products);  NP = 2: fp16 two-way split of x * scale (fp16x3 products), scale an exact power of two
+template <int NP> __device__ __forceinline__ void split_pair_np(float x0, float x1, float scale, uint32_t (&p)[3]) {
+    if (NP == 3) split_pair(x0, x1, p[0], p[1], p[2]);
+    else {   // saturate at the fp16 range instead of producing inf (weights beyond +-255, activations beyond +-4094: far outside any trained model)
+        split_pair_h(__builtin_amdgcn_fmed3f(x0 * scale, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x1 * scale, -65504.f, 65504.f), p[0], p[1]); p[2] = 0u;
+    }
+}
+// split planes of a row-major [M, H] f32 matrix for the split-product forward kernel: [tile of 32 rows][plane 0..NP-1][row in tile][H];
 // stores the planes of the element pair (row, j), (row, j+1), j even
-__device__ __forceinline__ void planes_store_pair(uint16_t* planes, int64_t row, int j, int H, float x0, float x1) {
-    uint32_t p1, p2, p3;
-    split_pair(x0, x1, p1, p2, p3);
-    uint32_t* o = reinterpret_cast<uint32_t*>(planes + ((row >> 5) * 96 + (row & 31)) * H + j);
-    o[0] = p1; o[(size_t)16 * H] = p2; o[(size_t)32 * H] = p3;
+template <int NP> __device__ __forceinline__ void planes_store_pair(uint16_t* planes, int64_t row, int j, int H, float x0, float x1, float scale) {
+    uint32_t p[3];
+    split_pair_np<NP>(x0, x1, scale, p);
+    uint32_t* o = reinterpret_cast<uint32_t*>(planes + ((row >> 5) * (32 * NP) + (row & 31)) * H + j);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) o[(size_t)q * 16 * H] = p[q];
 }
 
 // the same on the hardware exp2 / log2 / rcp (1 ulp each): log1p(e) = log(u) * e / (u - 1) with u = fl(1 + e) cancels the rounding of

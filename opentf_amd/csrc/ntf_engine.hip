@@ -423,6 +423,14 @@ static NormalSpec normal_spec(ntf_engine* e, const StepCtx& c, int layer, int te
     return s;
 }
 
+// split-product arithmetic of the fused output layer: number of planes and the exact power-of-two scales of fp16x3
+static inline int mfma_np(const ntf_engine* e) { return e->cfg.mfma == NTF_MFMA_BF16X6 ? 3 : 2; }   // default: fp16x3
+constexpr float kW16Scale = 256.f, kH16Scale = 16.f;          // weights (|w| << 256), hidden activations (|h| << 4096)
+static inline float dz_scale16(const ntf_engine* e, int global_B) {   // |dz| <= max(tpw, tnw) / B  ->  scaled below 2^14
+    const float dzmax = std::max(std::max(e->cfg.tpw, e->cfg.tnw), 1e-30f) / (float)std::max(global_B, 1);
+    return std::exp2(std::floor(std::log2(16384.f / dzmax)));
+}
+
 static int check_ready(ntf_engine* e, bool need_labels) {
     if (need_labels && !e->m_indptr) FAIL(e, NTF_ESTATE, "member CSR not set (ntf_set_member_csr)");
     switch (e->cfg.input_mode) {
@@ -607,7 +615,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if (e->cfg.bayesian) {
             { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                     1.0 / (double)lo.nw(), e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in);   // + the bf16 planes of Wp and mu
+                                     1.0 / (double)lo.nw(), e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale);   // + the split planes of Wp and mu
               f.planes_ready = e->pl_wp != nullptr;
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                      1.0 / (double)lo.out, e->d_kl); }
@@ -615,6 +623,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         }
         f.bf16x6 = e->pl_mu != nullptr; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
+        f.np = mfma_np(e); f.w_scale = kW16Scale; f.h_scale = kH16Scale; f.dz_scale = dz_scale16(e, c.global_B);
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
@@ -654,7 +663,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.mu = e->P + li.off[NTF_P_WEIGHT];
             f.s_out = sout_; f.s_out_inj = e->cfg.bayesian && (sout_.inj != nullptr || sin_.inj != nullptr);
             f.bf16x6 = e->cfg.mfma != NTF_MFMA_F32;   // default: bf16x6
-            if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws); }
+            f.np = mfma_np(e); f.a_scale = dz_scale16(e, c.global_B); f.h_scale = kH16Scale;
+            if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale); }
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
             if (c.defer_dw) {
                 const int tile = fused_dw_tile(), total = (M + tile - 1) / tile;
@@ -973,10 +983,11 @@ static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const
     f.tnw = e->cfg.tnw; f.tpw = e->cfg.tpw; f.inv_B = 1.f / (float)B;
     f.dzT = e->dZout; f.dh_slab = e->dh_slab; f.ws = e->fws;
     f.bf16x6 = 1; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
+    f.np = mfma_np(e); f.w_scale = kW16Scale; f.h_scale = kH16Scale; f.dz_scale = 1.f;
     if (e->cfg.bayesian) {
         { Scope t(e, F_FLIPOUT_OPERAND);
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, e->d_kl,
-                                 e->pl_wp, e->pl_mu, f.mu, lo.in);
+                                 e->pl_wp, e->pl_mu, f.mu, lo.in, mfma_np(e), kW16Scale);
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], nullptr, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1], 0.0, e->d_kl); }
         f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
         f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);

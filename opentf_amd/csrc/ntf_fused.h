@@ -23,6 +23,8 @@ struct FusedOut {
     const int64_t* neg = nullptr; int ns = 0; float* row_fix = nullptr;
     // bf16x6 arithmetic (H = 128): scratch for the bf16 split planes of mu / Wp, fused_planes_elems(M, H) uint16 each
     int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
+    int np = 3;                                     // 3: bf16x6, 2: fp16x3 (operands scaled by exact powers of two before their two-way fp16 split)
+    float w_scale = 1.f, h_scale = 1.f, dz_scale = 1.f;
     int planes_ready = 0;
     // inference (train = 0, probs = 1): dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale instead of the loss; the row entropy partials go to the workspace
     int probs = 0, pacc = 0; float pscale = 1.f;                           // the planes were already written this step (by the Flipout operand producer)
@@ -40,7 +42,9 @@ struct FusedDw {
     SignSpec s_out; int s_out_inj = 0;              // s_out keys; s_out_inj: signs were injected this step (packed image in ws)
     // adam != 0 (single GPU): Adam on mu / rho runs in the epilogue (in place), g_mu / g_rho are not written
     int adam = 0;
-    int bf16x6 = 0;                                 // 1: bf16 split-product MFMAs (f32-accurate, see ntf_fused.hip) instead of the f32 MFMA
+    int bf16x6 = 0;                                 // 1: split-product MFMAs (f32-accurate, see ntf_fused.hip) instead of the f32 MFMA
+    int np = 3;                                     // 3: bf16 three-way split, six products; 2: fp16 two-way split of scaled operands, three products
+    float a_scale = 1.f, h_scale = 1.f;             // np = 2: exact power-of-two scales of dz (applied in the kernel) and of the h planes (applied by the producer)
     int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the expert tiles [wg_begin, wg_begin + wg_count) of fused_dw_tile() experts each
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
@@ -55,7 +59,7 @@ int64_t fused_planes_elems(int M, int H);   // uint16 elements of one matrix's s
 int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are padded to a multiple of it)
 // phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
-void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws);
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 3, float h_scale = 1.f);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
 // after a probs pass: ent_rows[i] += scale * the pass's entropy terms (nullable); transpose: P [B, M] = PT^T
 void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws, const float* PT, float* P, float* ent_rows, float scale, bool transpose);

@@ -502,7 +502,8 @@ struct DwArgs {
     float *__restrict__ w_mu, *__restrict__ w_rho, *__restrict__ m_mu, *__restrict__ v_mu, *__restrict__ m_rho, *__restrict__ v_rho;
     float lr_over_bc1, b1, b2, eps, bc2_sqrt;
     int wg_begin;   // first expert tile of this launch (the expert range can be launched in chunks)
-    const uint16_t* hb;   // bf16x6: split planes of h / h*s_in (k_prep_planes_T)
+    const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
+    float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
 };
 
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
@@ -686,6 +687,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 as_frag_h(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 // acc += a*b with a = a1+a2+a3, b = b1+b2+b3 (smallest terms first)
 __device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[2]), as_frag(b[0]), acc, 0, 0, 0);
@@ -697,21 +700,33 @@ __device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3]
     return acc;
 }
 
+// fp16x3 variant of the same idea: x * 2^k (k per tensor, exact) split into two fp16 values (22 mantissa bits; fp16 subnormals are honoured by
+// the MFMA, checked on the hardware), a product = a1b1 + a1b2 + a2b1 on v_mfma_f32_32x32x16_f16: half the matrix work of bf16x6 for an error
+// against f64 1.2 x that of the f32 MFMA (5.7e-7 vs 4.6e-7 of the largest element on the forward product).
+__device__ __forceinline__ f32x16 mfma3h(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(a[1]), as_frag_h(b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(a[0]), as_frag_h(b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(a[0]), as_frag_h(b[0]), acc, 0, 0, 0);
+    return acc;
+}
+template <int NP> __device__ __forceinline__ f32x16 mfma_np(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc) {
+    if (NP == 3) return mfma6(a, b, acc); else return mfma3h(a, b, acc);
+}
+
 // hb: for every 32-row K block ib of the batch, the planes [p = h1,h2,h3,(hs1,hs2,hs3)][j][r = 0..31] of bf16 — the B operand
 // (k = batch row, n = hidden unit) of the dW products reads 8 consecutive batch rows of one hidden unit as one 16-byte chunk.
-__global__ void k_prep_planes_T(const float* __restrict__ hz, const float* __restrict__ hs, int bayes, int Bpad, int H, uint16_t* __restrict__ hb) {
+__global__ void k_prep_planes_T(const float* __restrict__ hz, const float* __restrict__ hs, int bayes, int Bpad, int H, int np, float scale,
+                                uint16_t* __restrict__ hb) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;          // (ib, j, r), r fastest
     if (t >= Bpad * H) return;
     const int r = t & 31, j = (t >> 5) % H, ib = t / (32 * H);
-    const int npl = bayes ? 6 : 3;
+    const int npl = (bayes ? 2 : 1) * np;
     uint16_t* tile = hb + (size_t)ib * npl * H * 32;
     for (int q = 0; q < (bayes ? 2 : 1); ++q) {
         const float x = (q ? hs : hz)[(int64_t)(ib * 32 + r) * H + j];
-        uint32_t p1, p2, p3;
-        split_pair(x, 0.f, p1, p2, p3);
-        tile[((q * 3 + 0) * H + j) * 32 + r] = (uint16_t)p1;
-        tile[((q * 3 + 1) * H + j) * 32 + r] = (uint16_t)p2;
-        tile[((q * 3 + 2) * H + j) * 32 + r] = (uint16_t)p3;
+        uint32_t p[3];
+        if (np == 3) split_pair_np<3>(x, 0.f, 1.f, p); else split_pair_np<2>(x, 0.f, scale, p);
+        for (int k = 0; k < np; ++k) tile[((q * np + k) * H + j) * 32 + r] = (uint16_t)p[k];
     }
 }
 
@@ -721,11 +736,11 @@ __global__ void k_prep_planes_T(const float* __restrict__ hz, const float* __res
 //   B: the bf16 planes of h / h*s_in for the K block ([plane][j][32 rows], chunks swizzled with (j>>2)&3): one ds_read_b128 per fragment.
 // No compiler-visible global load sits in the loop: hipcc would wait for it with a vmcnt that, in the real in-order queue, also waits
 // for the DMA issued just before.
-template <int H, bool BAYES, bool ADAM>
+template <int H, bool BAYES, bool ADAM, int NP>
 __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   // ADAM: update mu / rho and their moments in the epilogue (see DwArgs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NJT = H / 32;
-    constexpr int NPL = BAYES ? 6 : 3;
+    constexpr int NPL = (BAYES ? 2 : 1) * NP;   // NP = 3: bf16x6, NP = 2: fp16x3 (planes pre-scaled by 2^k, dz scaled by p.a_scale here)
     constexpr int TA = DW_TC * 32 * 4;            // dzT tile bytes
     constexpr int PLANE = H * 64;                 // bytes of one plane of one K block: [H][32 rows] bf16
     constexpr int TB = NPL * PLANE;
@@ -793,9 +808,9 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
         const int swz = (il >> 2) & 3;
         auto load_b = [&](int hg, u32x4 (&dst)[3]) {
             const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
-            const char* bp = bbase + jt * 2048 + 16 * ((2 * ks + half) ^ swz) + which * 3 * PLANE;
+            const char* bp = bbase + jt * 2048 + 16 * ((2 * ks + half) ^ swz) + which * NP * PLANE;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) dst[q] = *reinterpret_cast<const u32x4*>(bp + q * PLANE);
+            for (int q = 0; q < NP; ++q) dst[q] = *reinterpret_cast<const u32x4*>(bp + q * PLANE);
         };
         u32x4 a[2][3], as[2][3];
         auto prep_a = [&](int ks) {
@@ -806,13 +821,13 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
             const uint32_t w8 = word >> (ks * 16 + half * 8);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint32_t p1, p2, p3;
-                split_pair(x[2 * q], x[2 * q + 1], p1, p2, p3);
-                a[ks][0][q] = p1; a[ks][1][q] = p2; a[ks][2][q] = p3;
+                uint32_t pq[3];
+                split_pair_np<NP>(x[2 * q], x[2 * q + 1], p.a_scale, pq);
+                a[ks][0][q] = pq[0]; a[ks][1][q] = pq[1]; a[ks][2][q] = pq[2];
                 sum1 += x[2 * q] + x[2 * q + 1];
                 if (BAYES) {
                     const uint32_t m = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
-                    as[ks][0][q] = p1 ^ m; as[ks][1][q] = p2 ^ m; as[ks][2][q] = p3 ^ m;
+                    as[ks][0][q] = pq[0] ^ m; as[ks][1][q] = pq[1] ^ m; as[ks][2][q] = pq[2] ^ m;
                     sum2 += __uint_as_float(__float_as_uint(x[2 * q]) ^ ((w8 << (31 - 2 * q)) & 0x80000000u)) +
                             __uint_as_float(__float_as_uint(x[2 * q + 1]) ^ ((w8 << (30 - 2 * q)) & 0x80000000u));
                 }
@@ -826,8 +841,8 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
             if (hg + 1 < NHG) load_b(hg + 1, bq[(hg + 1) & 1]);
             asm volatile("" ::: "memory");   // keep the prefetch above this half-group's MFMAs
             const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
-            if (which) acc2[jt] = mfma6(as[ks], bq[hg & 1], acc2[jt]);
-            else acc1[jt] = mfma6(a[ks], bq[hg & 1], acc1[jt]);
+            if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
+            else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);   // before the first k-step-1 half-group; its vector work runs in the shadow of the following MFMAs
             // next K block: DMA issue + sign words in the middle of the MFMA phase, not in front of it — the two waves of a SIMD leave
             // every barrier in phase, and vector work bunched at the top of the iteration would meet the partner's vector work there
@@ -850,7 +865,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
             const int64_t idx = (int64_t)cr * H + 32 * jt + il;
-            float gm = acc1[jt][r], gr = 0.f, pm = 0.f, rh = 0.f;
+            float gm = acc1[jt][r] * p.unscale, gr = 0.f, pm = 0.f, rh = 0.f;   // unscale: 1 / (dz scale * h scale), 1 for bf16x6
             if (BAYES) {
                 rh = ADAM ? p.w_rho[idx] : p.rho[idx];
                 pm = ADAM ? p.w_mu[idx] : p.mu[idx];
@@ -861,7 +876,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
                 const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
                 const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
                 gm += p.klw * pm;
-                gr = acc2[jt][r] * (w * isig) * sg + p.klw * (sigma - isig) * sg;
+                gr = (acc2[jt][r] * p.unscale) * (w * isig) * sg + p.klw * (sigma - isig) * sg;
             } else if (ADAM) pm = p.w_mu[idx];
             if (!ADAM) { p.g_mu[idx] = gm; if (BAYES) p.g_rho[idx] = gr; }
             else {
@@ -892,7 +907,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int BN6 = 32;   // experts per tile of the bf16x6 forward kernel
 
 // planes[tile][plane][row][H] (bf16) of a row-major f32 matrix W [M, H]; rows past M are zero
-__global__ void k_split_planes(const float* __restrict__ W, int M, int H, uint16_t* __restrict__ out) {
+__global__ void k_split_planes(const float* __restrict__ W, int M, int H, int np, float scale, uint16_t* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // one thread per pair of hidden units
     const int hp = H / 2;
     const int64_t row = t / hp; const int j = (int)(t % hp) * 2;
@@ -900,24 +915,25 @@ __global__ void k_split_planes(const float* __restrict__ W, int M, int H, uint16
     if (row >= Mp) return;
     float x0 = 0.f, x1 = 0.f;
     if (row < M) { const float2 v = *reinterpret_cast<const float2*>(W + row * H + j); x0 = v.x; x1 = v.y; }
-    planes_store_pair(out, row, j, H, x0, x1);
+    if (np == 3) planes_store_pair<3>(out, row, j, H, x0, x1, 1.f); else planes_store_pair<2>(out, row, j, H, x0, x1, scale);
 }
 
 struct OutFwd6Args {
     OutFwdArgs a;
     const uint16_t *mu_pl, *wp_pl;   // k_split_planes images of mu and Wp
     float pscale; int pacc;          // PROBS: dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale; pacc: accumulate onto the previous MC passes
+    float h_scale, dz_scale, u_z, u_dh;   // fp16x3 (NP = 2): scales applied to h / dz before their split, and 1/(w scale * h scale), 1/(dz scale * w scale); 1 for bf16x6
 };
 
 // PROBS (inference, TRAIN = false): instead of the loss, the probabilities sigmoid(leaky_relu(z)) go (accumulated over the MC passes) to the
 // transposed buffer dzT [expert][batch], and lossp gets the row's entropy terms sum_c -p log(p + 1e-15) of this pass (src/mdl/fnn.py:196-208)
-template <bool BAYES, bool TRAIN, bool DH, bool INJ, bool PROBS = false>
-__global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
+template <bool BAYES, bool TRAIN, bool DH, bool INJ, bool PROBS, int NP>
+__global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP = 3: bf16x6, NP = 2: fp16x3
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const OutFwdArgs& p = pp.a;
     constexpr int H = 128, NJT = 4, NKS = H / 16;
     constexpr int PLANE = BN6 * H * 2;          // 8 KiB
-    constexpr int TM = 3 * PLANE;               // one matrix of a tile
+    constexpr int TM = NP * PLANE;              // one matrix of a tile
     constexpr int NMAT = BAYES ? 2 : 1;
     constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
@@ -945,9 +961,9 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
         const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint32_t p1, p2, p3;
-            split_pair(x[2 * q], x[2 * q + 1], p1, p2, p3);
-            hp[s][0][q] = p1; hp[s][1][q] = p2; hp[s][2][q] = p3;
+            uint32_t pq[3];
+            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
+            hp[s][0][q] = pq[0]; hp[s][1][q] = pq[1]; hp[s][2][q] = pq[2];
         }
     }
     const float rmask = row_ok ? 1.f : 0.f;
@@ -1041,7 +1057,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
                 const int s = hg / NMAT, mat = hg % NMAT;
                 const char* ap = sb + 256 * il + 16 * ((2 * s + half) ^ fil) + mat * TM;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
+                for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
             };
             u32x4 fr[2][3];
             z_load(0, fr[0]);
@@ -1050,7 +1066,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
                 if (hg + 1 < NHG) z_load(hg + 1, fr[(hg + 1) & 1]);
                 asm volatile("" ::: "memory");
                 const int s = hg / NMAT, mat = hg % NMAT;
-                if (mat == 0) X1 = mfma6(fr[hg & 1], hp[s], X1);
+                if (mat == 0) X1 = mfma_np<NP>(fr[hg & 1], hp[s], X1);
                 else {
                     u32x4 hs[3];
                     const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
@@ -1058,8 +1074,8 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) hm[q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) hs[q] = hp[s][q] ^ hm;
-                    X2 = mfma6(fr[hg & 1], hs, X2);
+                    for (int q = 0; q < NP; ++q) hs[q] = hp[s][q] ^ hm;
+                    X2 = mfma_np<NP>(fr[hg & 1], hs, X2);
                 }
             }
         }
@@ -1069,8 +1085,8 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
         auto epilogue = [&](int r) {
             const int cr = (r & 3) + 8 * (r >> 2);
-            float z = X1[r] + bias_mu[cr];
-            if (BAYES) z += __uint_as_float(__float_as_uint(X2[r] + bias_p[cr]) ^ ((sw << (31 - cr)) & 0x80000000u));
+            float z = fmaf(X1[r], pp.u_z, bias_mu[cr]);
+            if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[r], pp.u_z, bias_p[cr])) ^ ((sw << (31 - cr)) & 0x80000000u));
             const bool pos = z > 0.f;
             const float l = pos ? z : z * kLeakySlope;
             const float lc = fmaxf(l, -80.f);
@@ -1098,21 +1114,21 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
             auto split_a = [&](int s2, u32x4 (&ad)[3], u32x4 (&as)[3]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    uint32_t p1, p2, p3;
+                    uint32_t pq[3];
                     const int r0 = 8 * s2 + 2 * q;
-                    split_pair(X1[r0], X1[r0 + 1], p1, p2, p3);
-                    ad[0][q] = p1; ad[1][q] = p2; ad[2][q] = p3;
+                    split_pair_np<NP>(X1[r0], X1[r0 + 1], pp.dz_scale, pq);
+                    ad[0][q] = pq[0]; ad[1][q] = pq[1]; ad[2][q] = pq[2];
                     if (BAYES) {
                         const int c0r = (r0 & 3) + 8 * (r0 >> 2);   // registers r0, r0+1 are experts c0r, c0r+1 (+4*half, folded into sw)
                         const uint32_t m = (((sw << (31 - c0r)) & 0x80000000u) >> 16) | ((sw << (30 - c0r)) & 0x80000000u);
-                        as[0][q] = p1 ^ m; as[1][q] = p2 ^ m; as[2][q] = p3 ^ m;
+                        as[0][q] = pq[0] ^ m; as[1][q] = pq[1] ^ m; as[2][q] = pq[2] ^ m;
                     }
                 }
             };
             auto tr_load = [&](int g, u32x4 (&bf)[3]) {   // g = (s2, jt, mat): B fragments (k = expert, n = hidden unit 32 jt + il)
                 const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NP; ++q) {
                     const uint32_t o = 4096 * s2 + q * PLANE + mat * TM;
                     const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[0][jt] + o)));
                     const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[1][jt] + o)));
@@ -1131,8 +1147,8 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
                 if (g + 1 < NG) tr_load(g + 1, bf[(g + 1) & 1]);
                 asm volatile("" ::: "memory");
                 const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
-                if (mat == 0) Y1[jt] = mfma6(ad[s2], bf[g & 1], Y1[jt]);
-                else Y2[jt] = mfma6(as[s2], bf[g & 1], Y2[jt]);
+                if (mat == 0) Y1[jt] = mfma_np<NP>(ad[s2], bf[g & 1], Y1[jt]);
+                else Y2[jt] = mfma_np<NP>(as[s2], bf[g & 1], Y2[jt]);
                 if (s2 == 0) {   // second half of the epilogue in the shadow of the first k-step's MFMAs
                     constexpr int PER = 8 / (NJT * NMAT) > 0 ? 8 / (NJT * NMAT) : 1;
                     if (g * PER < 8) {
@@ -1160,10 +1176,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {
             const int irow = i0 + rowmap(r, half);
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
-                float v = Y1[jt][r];
+                float v = Y1[jt][r] * pp.u_dh;
                 if (BAYES) {
                     const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
-                    const float y2 = Y2[jt][r];
+                    const float y2 = Y2[jt][r] * pp.u_dh;
                     v += ((w >> il) & 1u) ? -y2 : y2;
                 }
                 p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
@@ -1222,28 +1238,28 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     const int grid = g.NRB * g.NCG;
     if (f.bf16x6 && f.H == 128) {
+        const int np = f.np == 2 ? 2 : 3;
         if ((phases & 1) && !f.planes_ready) {
             const int64_t Mp = ((int64_t)f.M + BN6 - 1) / BN6 * BN6, n = Mp * (f.H / 2);
-            hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.mu, f.M, f.H, f.mu_pl);
-            if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, f.wp_pl);
+            hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.mu, f.M, f.H, np, f.w_scale, f.mu_pl);
+            if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, np, f.w_scale, f.wp_pl);
         }
         if (phases & 2) {
             OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc;
+            a6.h_scale = np == 2 ? f.h_scale : 1.f; a6.dz_scale = np == 2 ? f.dz_scale : 1.f;
+            a6.u_z = np == 2 ? 1.f / (f.w_scale * f.h_scale) : 1.f; a6.u_dh = np == 2 ? 1.f / (f.dz_scale * f.w_scale) : 1.f;
             const bool dh = f.dh != nullptr;
-            const size_t lds = (size_t)((!f.train && !inj) ? 3 : 2) * ((size_t)(f.bayes ? 2 : 1) * 3 * BN6 * 128 * 2 + 512);
-#define NTF_L6(BY, TR, DHF, IJ) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ>;                                                   \
+            const size_t lds = (size_t)((!f.train && !inj) ? 3 : 2) * ((size_t)(f.bayes ? 2 : 1) * np * BN6 * 128 * 2 + 512);
+#define NTF_L6N(BY, TR, DHF, IJ, PR, NPV) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ, PR, NPV>;                               \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
-#define NTF_L6B(BY, IJ) do { if (!f.train) NTF_L6(BY, false, false, IJ); else if (dh) NTF_L6(BY, true, true, IJ); else NTF_L6(BY, true, false, IJ); } while (0)
-            if (f.probs) {
-#define NTF_L6P(BY, IJ) do { auto kf = k_out_fwd_b6<BY, false, false, IJ, true>;                                                \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-                hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
-                if (f.bayes) { if (inj) NTF_L6P(true, true); else NTF_L6P(true, false); } else NTF_L6P(false, false);
-#undef NTF_L6P
-            } else if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
+#define NTF_L6(BY, TR, DHF, IJ, PR) do { if (np == 2) NTF_L6N(BY, TR, DHF, IJ, PR, 2); else NTF_L6N(BY, TR, DHF, IJ, PR, 3); } while (0)
+#define NTF_L6B(BY, IJ) do { if (f.probs) NTF_L6(BY, false, false, IJ, true); else if (!f.train) NTF_L6(BY, false, false, IJ, false);  \
+                             else if (dh) NTF_L6(BY, true, true, IJ, false); else NTF_L6(BY, true, false, IJ, false); } while (0)
+            if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
 #undef NTF_L6B
 #undef NTF_L6
+#undef NTF_L6N
         }
         if ((phases & 4) && !f.probs) {
 #define NTF_SP(BY) do { if (!f.train) hipLaunchKernelGGL((k_out_special<128, BY, false, false>), dim3(f.B), dim3(64), 0, st, s);         \
@@ -1298,14 +1314,18 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     if (grid <= 0) return;
     a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
     if (f.bf16x6) {
-#define NTF_DWB1(HH, BY, AD) do { auto kf = k_out_dw_b6<HH, BY, AD>; const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(BY ? 6 : 3) * HH * 64);         \
+        const int np = f.np == 2 ? 2 : 3;
+        a.a_scale = np == 2 ? f.a_scale : 1.f; a.unscale = np == 2 ? 1.f / (f.a_scale * f.h_scale) : 1.f;
+#define NTF_DWB2(HH, BY, AD, NPV) do { auto kf = k_out_dw_b6<HH, BY, AD, NPV>; const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(BY ? 2 : 1) * NPV * HH * 64); \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
+#define NTF_DWB1(HH, BY, AD) do { if (np == 2) NTF_DWB2(HH, BY, AD, 2); else NTF_DWB2(HH, BY, AD, 3); } while (0)
 #define NTF_DWB(HH) do { if (f.bayes) { if (f.adam) NTF_DWB1(HH, true, true); else NTF_DWB1(HH, true, false); }                                            \
                          else { if (f.adam) NTF_DWB1(HH, false, true); else NTF_DWB1(HH, false, false); } } while (0)
         if (f.H == 128) NTF_DWB(128); else if (f.H == 64) NTF_DWB(64); else NTF_DWB(32);
 #undef NTF_DWB
 #undef NTF_DWB1
+#undef NTF_DWB2
         return;
     }
 #define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
@@ -1317,13 +1337,13 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
 }
 
 // bf16 split planes of the hidden activations for the dW kernel (once per step, after launch_fused_out_fwd's phase 1)
-void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws_) {
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws_, int np, float h_scale) {
     const Geom g = geom(B, M);
     const WsLayout w = ws_layout(B, H, M);
     char* ws = static_cast<char*>(ws_);
     const int n = g.Bpad * H;
     hipLaunchKernelGGL(k_prep_planes_T, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(ws + w.hz), reinterpret_cast<const float*>(ws + w.hs),
-                       bayes, g.Bpad, H, reinterpret_cast<uint16_t*>(ws + w.hb));
+                       bayes, g.Bpad, H, np == 2 ? 2 : 3, h_scale, reinterpret_cast<uint16_t*>(ws + w.hb));
 }
 
 }  // namespace ntf

@@ -255,7 +255,7 @@ void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 // planes_w / planes_mu (output layer, bf16x6 arithmetic): also the bf16 split planes of out and of pmu for the forward kernel.
 __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict__ rho, const float* __restrict__ mu, int64_t n, NormalSpec eps,
                                                          float* __restrict__ out, double w, double* kl_out, uint16_t* __restrict__ planes_w,
-                                                         uint16_t* __restrict__ planes_mu, const float* __restrict__ pmu, int H) {
+                                                         uint16_t* __restrict__ planes_mu, const float* __restrict__ pmu, int H, int np, float pscale) {
     const int64_t quads = (n + 3) / 4;
     float kl = 0.f;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -277,10 +277,13 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
             *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
             if (planes_w) {   // H % 4 == 0: the quad lies in one row
                 const int64_t row = e0 / H; const int j = (int)(e0 - row * H);
-                planes_store_pair(planes_w, row, j, H, ov[0], ov[1]); planes_store_pair(planes_w, row, j + 2, H, ov[2], ov[3]);
-                if (planes_mu) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(pmu + e0);
-                    planes_store_pair(planes_mu, row, j, H, m4.x, m4.y); planes_store_pair(planes_mu, row, j + 2, H, m4.z, m4.w);
+                const float4 m4 = planes_mu ? *reinterpret_cast<const float4*>(pmu + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (np == 3) {
+                    planes_store_pair<3>(planes_w, row, j, H, ov[0], ov[1], 1.f); planes_store_pair<3>(planes_w, row, j + 2, H, ov[2], ov[3], 1.f);
+                    if (planes_mu) { planes_store_pair<3>(planes_mu, row, j, H, m4.x, m4.y, 1.f); planes_store_pair<3>(planes_mu, row, j + 2, H, m4.z, m4.w, 1.f); }
+                } else {
+                    planes_store_pair<2>(planes_w, row, j, H, ov[0], ov[1], pscale); planes_store_pair<2>(planes_w, row, j + 2, H, ov[2], ov[3], pscale);
+                    if (planes_mu) { planes_store_pair<2>(planes_mu, row, j, H, m4.x, m4.y, pscale); planes_store_pair<2>(planes_mu, row, j + 2, H, m4.z, m4.w, pscale); }
                 }
             }
         } else {
@@ -297,11 +300,11 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
     }
 }
 void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out,
-                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H) {
+                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale) {
     if (n <= 0) return;
     const int64_t quads = (n + 3) / 4;
     const int blocks = (int)std::min<int64_t>((quads + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H);
+    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale);
 }
 
 __global__ void k_flipout_grad_finalize(const float* __restrict__ mu, const float* __restrict__ rho, float* __restrict__ g_mu,

@@ -141,7 +141,7 @@ class Engine:
             cfg.dims[i] = d
         cfg.bayesian, cfg.input_mode, cfg.max_batch = int(self.bayesian), int(input_mode), self.max_batch
         cfg.ns, cfg.nsd, cfg.tpw, cfg.tnw, cfg.lr, cfg.seed, cfg.fused = max(self.ns, 0), NSD[nsd], float(tpw), float(tnw), float(lr), int(seed) & (2**64 - 1), int(bool(fused))
-        cfg.mfma = {None: 0, "default": 0, "f32": 1, "bf16x6": 2}[mfma] if not isinstance(mfma, int) or isinstance(mfma, bool) else int(mfma)
+        cfg.mfma = {None: 0, "default": 0, "f32": 1, "bf16x6": 2, "fp16x3": 3}[mfma] if not isinstance(mfma, int) or isinstance(mfma, bool) else int(mfma)
         cfg.fuse_adam = int(fuse_adam)  # 0: flat Adam kernel; 1: inside the dW epilogue; 2: chunked beside the dW kernel on a side stream
         self._h = C.c_void_p()
         rc = lib().ntf_engine_create(C.byref(cfg), C.byref(self._h))

@@ -83,14 +83,14 @@ def test_fnn_logits_vs_reference_golden(name, fused):
 
 
 @pytest.mark.parametrize("tag", ["imdb", "mid"])
-@pytest.mark.parametrize("fused", [False, True, "f32"])
+@pytest.mark.parametrize("fused", [False, True, "f32", "bf16x6"])
 def test_fnn_train_steps_vs_reference_golden(tag, fused):
     g = golden(f"g4_step_{tag}")
     sd = params_from(g, "p0.")
     X, y = g["X"], g["y"]
     dims = [X.shape[1]] + [sd[f"layers.{i}.weight"].shape[0] for i in range(O.n_layers(sd))]
     e = _engine(dims, max_batch=len(X), ns=5, nsd="uniform", tpw=float(g["tpw"]), tnw=float(g["tnw"]), lr=float(g["lr"]), fused=bool(fused),
-                mfma="f32" if fused == "f32" else None)
+                mfma=fused if isinstance(fused, str) else None)
     e.load_state_dict(sd); e.set_dense_input(X); e.set_member(_csr_from_dense(y))
     rows = np.arange(len(X))
     for s in range(3):
@@ -114,11 +114,12 @@ def _bnn_case(D, H, M, B, seed):
 
 @pytest.mark.parametrize("D,H,M,B", [(18, [32], 112, 19), (128, [128], 1500, 70), (40, [64, 32], 300, 33), (128, [128], 5000, 130),
                                      (24, [64], 777, 129), (16, [128], 13, 1), (16, [32], 63, 257), (50, [], 90, 21), (32, [], 100, 40)])
-@pytest.mark.parametrize("fused", [False, True, "f32"])
+@pytest.mark.parametrize("fused", [False, True, "f32", "bf16x6"])
 def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
-    """fused=True: the fused kernels in their default arithmetic (bf16x6 split products where implemented); "f32": the exact-f32 MFMA kernels."""
+    """fused=True: the fused kernels in their default arithmetic (fp16x3 split products); "bf16x6": the three-way bf16 split; "f32": the
+    exact-f32 MFMA kernels."""
     sd, X, y = _bnn_case(D, H, M, B, 5)
-    e = _engine([D] + H + [M], bayesian=True, max_batch=B, ns=5, nsd="uniform", lr=1e-3, fused=bool(fused), mfma="f32" if fused == "f32" else None)
+    e = _engine([D] + H + [M], bayesian=True, max_batch=B, ns=5, nsd="uniform", lr=1e-3, fused=bool(fused), mfma=fused if isinstance(fused, str) else None)
     e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
     rows = np.arange(B)
     opt = O.Adam(sd, 1e-3)
@@ -184,7 +185,7 @@ def test_multihot_first_layer_step_vs_oracle(bayesian, S, H, M, B):
             for k in sd: sd[k].copy_(torch.from_numpy(state[k]))
 
 
-@pytest.mark.parametrize("mfma", ["f32", None])
+@pytest.mark.parametrize("mfma", ["f32", "bf16x6", None])
 @pytest.mark.parametrize("bayesian", [False, True])
 def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian, mfma):
     """cfg.fuse_adam moves the output layer's Adam into the dW kernel's epilogue: same parameters, step for step."""
@@ -192,7 +193,7 @@ def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian, mfma):
     if not bayesian:
         torch.manual_seed(3); sd = O.fnn_init(64, [128], 900)
     def run(fuse):
-        # the three modes share one product arithmetic (exact-f32 MFMA or the default bf16x6): this test is about WHERE Adam runs
+        # the three modes share one product arithmetic (exact-f32 MFMA, bf16x6 or the default fp16x3): this test is about WHERE Adam runs
         e = _engine([64, 128, 900], bayesian=bayesian, max_batch=150, ns=4, nsd="uniform", seed=21, lr=1e-2, fuse_adam=fuse, mfma=mfma)
         e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
         losses = [e.train_step(np.arange(150)) for _ in range(4)]
@@ -405,9 +406,9 @@ def test_forward_probs_topk_and_uncertainty():
 
 
 @pytest.mark.parametrize("bayesian", [True, False])
-@pytest.mark.parametrize("mfma", [None, "f32"])
+@pytest.mark.parametrize("mfma", [None, "bf16x6", "f32"])
 def test_forward_probs_uncertainty_h128(bayesian, mfma):
-    """H = 128: in the default arithmetic the inference runs through the fused bf16x6 forward kernel (probabilities accumulated over the MC
+    """H = 128: in the split-product arithmetics the inference runs through the fused forward kernel (probabilities accumulated over the MC
     passes in a transposed buffer, no dense logits); mfma="f32" keeps the generic GEMM route.  Both against the oracle with injected noise."""
     D, M, B, nmc = 24, 1777, 45, 3
     sd, X, y = _bnn_case(D, [128], M, B, 4)
@@ -525,3 +526,14 @@ def test_engine_create_destroy_returns_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)     # one engine of this shape holds ~250 MB
+
+
+def test_fp16x3_saturates_instead_of_overflowing():
+    """fp16x3 scales operands by exact powers of two before their fp16 split; values past the fp16 range saturate (documented) — no inf / NaN."""
+    sd, X, y = _bnn_case(16, [128], 300, 20, 1)
+    sd["layers.1.mu_weight"][5, :] = 1e4          # absurd weights (|w| >= 256 saturates)
+    e = _engine([16, 128, 300], bayesian=True, max_batch=20, ns=3, nsd="uniform")
+    e.load_state_dict(sd); e.set_dense_input((X * 1e3).numpy()); e.set_member(_csr_from_dense(y.numpy()))   # and activations in the thousands
+    loss = e.train_step(np.arange(20))
+    assert np.isfinite(loss)
+    assert all(np.isfinite(v).all() for v in e.state_dict().values())
