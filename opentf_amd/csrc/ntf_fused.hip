@@ -28,7 +28,7 @@ constexpr int DW_TC = 32 * DW_WAVES;      // experts per workgroup of the dW ker
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 int fused_ldb(int B) { return rup(B, BM); }
 int fused_dw_tile() { return DW_TC; }
-int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 31) / 32 * 32 * H * 3; }
+int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 63) / 64 * 64 * H * 3; }   // rows padded to the 64-expert tile of k_out_fwd_h3w
 bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
 int fused_loss_slots(int) { return 0; }
 
@@ -1189,6 +1189,261 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
 }
 
 // ------------------------------------------------------------------------------------------------
+// Training forward (loss + dz + dh) in fp16x3 with 64-expert tiles: two 32-expert sub-tiles u per tile give every stretch of vector
+// work a stretch of independent MFMAs to run under — the schedule the f32 kernel (k_out_fwd) was built on:
+//   zT(u=0) | zT(u=1) + epilogue(u=0) + split(u=0) | dh(u=0) + epilogue(u=1) + split(u=1) | dh(u=1)
+// Two LDS stages of 2 matrices x 2 planes x [64 rows][256 B] (+ biases) = 2 x 64.5 KiB; everything else as in k_out_fwd_b6<.., NP = 2>.
+// ------------------------------------------------------------------------------------------------
+template <bool BAYES, bool INJ>
+__global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OutFwdArgs& p = pp.a;
+    constexpr int H = 128, NJT = 4, NKS = H / 16, NP = 2, BNT = 64;
+    constexpr int PLANE = BNT * H * 2;          // 16 KiB
+    constexpr int TM = NP * PLANE;              // one matrix of a tile
+    constexpr int NMAT = BAYES ? 2 : 1;
+    constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int cg = bid / p.NRB, rb = bid % p.NRB;
+    const int t_beg = (int)((int64_t)cg * p.T / p.NCG), t_end = (int)((int64_t)(cg + 1) * p.T / p.NCG);   // p.T = 64-expert tiles
+    const int i0 = rb * BM + wave * 32;
+    const int i = i0 + il;
+    const bool row_ok = i < p.B;
+
+    u32x4 hp[NKS][3];
+    uint32_t sinw[NJT];
+#pragma unroll
+    for (int w = 0; w < NJT; ++w)
+        sinw[w] = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) : 0u;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
+        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t pq[3];
+            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
+            hp[s][0][q] = pq[0]; hp[s][1][q] = pq[1]; hp[s][2][q] = 0u;
+        }
+    }
+    const float rmask = row_ok ? 1.f : 0.f;
+    const float rscale = row_ok ? p.tnw * p.inv_B : 0.f;
+
+    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
+    int troff[2][NJT];                              // transposed read (rr, jt): rows 8*rr + 4*half + q (+ 16 per k-step, 32 per sub-tile as immediates)
+    {
+        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int row = 8 * rr + 4 * half + q;
+                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
+            }
+    }
+
+    f32x16 Y1[NJT], Y2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
+    float lsum = 0.f;
+
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage_tile = [&](int t, int buf) {
+        const uint32_t sb = smem_base + buf * STAGE;
+        constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
+#pragma unroll
+        for (int n = 0; n < PER_WAVE; ++n) {
+            const int inst = wave_u * PER_WAVE + n;
+            const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row (0..63), physical chunk
+            const int plane = pos / PLANE, row = (pos >> 8) & 63, chp = (pos >> 4) & 15;
+            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
+            const size_t src = ((size_t)(2 * t + (row >> 5)) * (32 * NP) + plane * 32 + (row & 31)) * 256 + 16 * ch;
+            glds16(reinterpret_cast<const char*>(pp.mu_pl) + src, sb + inst * 1024);
+            if (BAYES) glds16(reinterpret_cast<const char*>(pp.wp_pl) + src, sb + TM + inst * 1024);
+        }
+        const int c0 = t * BNT;
+        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TM);
+        if (BAYES && wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TM + 256);
+    };
+    auto sign_words = [&](int t) -> uint2 {         // s_out signs of (row i, experts 64t .. 64t+63)
+        if (!BAYES || !row_ok) return make_uint2(0u, 0u);
+        if (INJ) return *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);
+        return make_uint2(sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t)), sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t + 1)));
+    };
+    if (t_beg < t_end) stage_tile(t_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        const uint2 w2 = sign_words(t);
+        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
+        char* sb = smem + buf * STAGE;
+        const uint32_t sbase = lds_addr(sb);
+        const int c0 = t * BNT;
+        if (c0 + BNT > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
+            if (tid < BNT && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -1e30f;
+            __syncthreads();
+        }
+        f32x16 X1[2], X2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { X1[u][r] = 0.f; X2[u][r] = 0.f; }
+        const uint32_t sw[2] = {w2.x >> (4 * half), w2.y >> (4 * half)};
+        const int dz_row_bytes = p.Bpad * 4;
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BNT * dz_row_bytes, 0x00020000);
+        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
+        const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
+        const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
+
+        constexpr int NHG = NKS * NMAT;     // half-groups (k-step, matrix) of one sub-tile's zT: 2 fragment reads + 3 MFMAs each
+        constexpr int NGD = 2 * NJT * NMAT; // groups (k-step of 16 experts, jt, matrix) of one sub-tile's dh: 4 transposed reads + 3 MFMAs each
+        auto z_load = [&](int u, int hg, u32x4 (&fr)[3]) {
+            const int s = hg / NMAT, mat = hg % NMAT;
+            const char* ap = sb + 256 * (32 * u + il) + 16 * ((2 * s + half) ^ fil) + mat * TM;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
+            fr[2] = u32x4{0u, 0u, 0u, 0u};
+        };
+        auto z_mma = [&](int u, int hg, const u32x4 (&fr)[3]) {
+            const int s = hg / NMAT, mat = hg % NMAT;
+            if (mat == 0) X1[u] = mfma_np<NP>(fr, hp[s], X1[u]);
+            else {
+                u32x4 hs[3];
+                const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
+                u32x4 hm;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hm[q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) hs[q] = hp[s][q] ^ hm;
+                hs[2] = hm;
+                X2[u] = mfma_np<NP>(fr, hs, X2[u]);
+            }
+        };
+        auto epilogue = [&](int u, int r) {     // lane = batch row i, register r <-> expert c0 + 32u + rowmap(r, half)
+            const int cr = 32 * u + (r & 3) + 8 * (r >> 2);
+            float z = fmaf(X1[u][r], pp.u_z, bias_mu[cr]);
+            if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[u][r], pp.u_z, bias_p[cr])) ^ ((sw[u] << (31 - (cr & 31))) & 0x80000000u));
+            const bool pos = z > 0.f;
+            const float l = pos ? z : z * kLeakySlope;
+            const float lc = fmaxf(l, -80.f);
+            const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
+            lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
+            const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
+            X1[u][r] = dz;
+        };
+        u32x4 ad[2][2][3];      // [u][k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
+        auto split_pair_a = [&](int u, int r0) {   // registers r0, r0 + 1 (r0 even) of sub-tile u
+            uint32_t pq[3];
+            split_pair_np<NP>(X1[u][r0], X1[u][r0 + 1], pp.dz_scale, pq);
+            ad[u][r0 >> 3][0][(r0 & 7) >> 1] = pq[0]; ad[u][r0 >> 3][1][(r0 & 7) >> 1] = pq[1];
+        };
+        auto signed_a = [&](int u, int s2, u32x4 (&o)[3]) {   // planes of dz * s_out
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r0 = 8 * s2 + 2 * q, c0r = (r0 & 3) + 8 * (r0 >> 2);
+                const uint32_t m = (((sw[u] << (31 - c0r)) & 0x80000000u) >> 16) | ((sw[u] << (30 - c0r)) & 0x80000000u);
+                o[0][q] = ad[u][s2][0][q] ^ m; o[1][q] = ad[u][s2][1][q] ^ m;
+            }
+            o[2] = o[0];
+        };
+        auto tr_load = [&](int u, int g, u32x4 (&bf)[3]) {   // g = (s2, jt, mat)
+            const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const uint32_t o = 8192 * u + 4096 * s2 + q * PLANE + mat * TM;
+                const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[0][jt] + o)));
+                const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[1][jt] + o)));
+                bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
+            }
+            bf[2] = bf[0];
+        };
+        auto d_mma = [&](int u, int g, const u32x4 (&bf)[3]) {
+            const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
+            if (mat == 0) Y1[jt] = mfma_np<NP>(ad[u][s2], bf, Y1[jt]);
+            else { u32x4 asg[3]; signed_a(u, s2, asg); Y2[jt] = mfma_np<NP>(asg, bf, Y2[jt]); }
+        };
+        // vector work riding on MFMA group g of a 16- (Bayes) or 8-group phase: the epilogue of PER registers of sub-tile u, and once both
+        // registers of a pair are done, their split into dh fragments
+        constexpr int PERZ = 16 / NHG, PERD = 16 / NGD;
+        auto ride = [&](int u, int g, int per) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr < per) {
+                    const int r = g * per + rr;
+                    epilogue(u, r);
+                    if (r & 1) split_pair_a(u, r - 1);
+                }
+            }
+        };
+
+        u32x4 fr[2][3], bf[2][3];
+        // ---- zT(u = 0)
+        z_load(0, 0, fr[0]);
+#pragma unroll
+        for (int hg = 0; hg < NHG; ++hg) {
+            if (hg + 1 < NHG) z_load(0, hg + 1, fr[(hg + 1) & 1]); else z_load(1, 0, fr[(hg + 1) & 1]);
+            asm volatile("" ::: "memory");
+            z_mma(0, hg, fr[hg & 1]);
+        }
+        // ---- zT(u = 1) with the epilogue and the splits of sub-tile 0 riding on it
+#pragma unroll
+        for (int hg = 0; hg < NHG; ++hg) {
+            if (hg + 1 < NHG) z_load(1, hg + 1, fr[(NHG + hg + 1) & 1]); else tr_load(0, 0, bf[0]);
+            asm volatile("" ::: "memory");
+            z_mma(1, hg, fr[(NHG + hg) & 1]);
+            ride(0, hg, PERZ);
+        }
+        // ---- dh(u = 0) with the epilogue and the splits of sub-tile 1 riding on it
+#pragma unroll
+        for (int g = 0; g < NGD; ++g) {
+            if (g + 1 < NGD) tr_load(0, g + 1, bf[(g + 1) & 1]); else tr_load(1, 0, bf[(g + 1) & 1]);
+            asm volatile("" ::: "memory");
+            d_mma(0, g, bf[g & 1]);
+            ride(1, g, PERD);
+        }
+        // ---- dh(u = 1)
+#pragma unroll
+        for (int g = 0; g < NGD; ++g) {
+            if (g + 1 < NGD) tr_load(1, g + 1, bf[(NGD + g + 1) & 1]);
+            asm volatile("" ::: "memory");
+            d_mma(1, g, bf[(NGD + g) & 1]);
+        }
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // the next tile's DMA is older than this tile's 32 dzT stores
+        __builtin_amdgcn_s_barrier();
+    }
+
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int irow = i0 + rowmap(r, half);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            float v = Y1[jt][r] * pp.u_dh;
+            if (BAYES) {
+                const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
+                const float y2 = Y2[jt][r] * pp.u_dh;
+                v += ((w >> il) & 1u) ? -y2 : y2;
+            }
+            p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
 static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
@@ -1256,7 +1511,14 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_L6(BY, TR, DHF, IJ, PR) do { if (np == 2) NTF_L6N(BY, TR, DHF, IJ, PR, 2); else NTF_L6N(BY, TR, DHF, IJ, PR, 3); } while (0)
 #define NTF_L6B(BY, IJ) do { if (f.probs) NTF_L6(BY, false, false, IJ, true); else if (!f.train) NTF_L6(BY, false, false, IJ, false);  \
                              else if (dh) NTF_L6(BY, true, true, IJ, false); else NTF_L6(BY, true, false, IJ, false); } while (0)
-            if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
+            if (np == 2 && f.train && dh && f.wide) {    // 64-expert tiles (a.T counts them already)
+                const size_t ldsw = 2 * ((size_t)(f.bayes ? 2 : 1) * 2 * 64 * 128 * 2 + 512);
+#define NTF_LW(BY, IJ) do { auto kf = k_out_fwd_h3w<BY, IJ>;                                                                    \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
+                hipLaunchKernelGGL(kf, dim3(grid), dim3(256), ldsw, st, a6); } while (0)
+                if (f.bayes) { if (inj) NTF_LW(true, true); else NTF_LW(true, false); } else NTF_LW(false, false);
+#undef NTF_LW
+            } else if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
 #undef NTF_L6B
 #undef NTF_L6
 #undef NTF_L6N
