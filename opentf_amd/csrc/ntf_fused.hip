@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);   // before the first k-step-1 half-group; its vector work runs in the shadow of the following MFMAs
             // next K block: DMA issue + sign words in the middle of the MFMA phase, not in front of it — the two waves of a SIMD leave
             // every barrier in phase, and vector work bunched at the top of the iteration would meet the partner's vector work there
-            if (hg == NHG / 2 && ib + 1 < nib) { stage(ib + 1, buf ^ 1); if (BAYES && !p.so_inj) word_next = sign_col_word(ib + 1); }
+            if (hg == (NP == 2 ? 0 : NHG / 2) && ib + 1 < nib) { stage(ib + 1, buf ^ 1); if (BAYES && !p.so_inj) word_next = sign_col_word(ib + 1); }   // fp16x3: the K block is short, give the DMA all of it
         }
         if (BAYES && p.so_inj && ib + 1 < nib) word_next = sign_col_word(ib + 1);   // injected signs (tests): a visible load, kept out of the MFMA phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next K block (DMA) has landed
