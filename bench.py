@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dataset", default="dblp")
     ap.add_argument("--batch", type=int, default=1000, help="teams per GPU per step (cfg.b)")
     ap.add_argument("--d", type=int, default=128)
@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override the number of teams (debug)")
     ap.add_argument("--experts", type=int, default=0, help="override the number of experts (debug)")
     ap.add_argument("--no-fused", action="store_true")
-    ap.add_argument("--fuse-adam", type=int, default=-1, help="0 flat Adam, 1 in the dW epilogue, 2 chunked beside dW on a side stream (N=1 only); -1: 2 for bnn, 0 for fnn (measured best)")
+    ap.add_argument("--fuse-adam", type=int, default=0, help="0 flat Adam after backward (default: with the split-product kernels the three modes are within 2 %% of each other), 1 in the dW epilogue, 2 chunked beside dW on a side stream (N=1 only)")
     ap.add_argument("--mfma", default="default", choices=["default", "f32", "bf16x6", "fp16x3"], help="arithmetic of the fused output-layer products (include/opentf_amd.h ntf_mfma)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-bench", action="store_true", help="(default at N=1) also time the whole-dataset gather (get_dense_vecs)")
@@ -123,7 +123,6 @@ def main():
     from opentf_amd.synth import make_dataset, init_params
 
     bayesian = a.model == "bnn"
-    if a.fuse_adam < 0: a.fuse_adam = 2 if bayesian else 0
     ds = make_dataset(a.dataset, d=a.d, seed=0, n_rows=a.rows or None, n_experts=a.experts or None)
     multihot = a.input == "multihot"
     dims = [ds["S"] if multihot else a.d, a.hidden, ds["M"]]

@@ -97,7 +97,7 @@ def make_fnn(base):
                               nsd=nsd if nsd else None, tpw=float(cfg_get(self.cfg, "tpw", 1)), tnw=float(cfg_get(self.cfg, "tnw", 1)),
                               lr=float(cfg_get(self.cfg, "lr")), seed=int(self.seed or 0), device=devs[0],
                               stream=self._stream.cuda_stream if self._stream is not None else None,
-                              fuse_adam=(2 if self.is_bayesian else 0) if self._world == 1 else 0)   # measured best on one GPU: Adam chunks beside dW (Bnn), flat (Fnn)
+                              fuse_adam=0)   # flat Adam: with the split-product kernels the fused / side-stream variants are within 2 % of it
             if mode == libntf.INPUT_MEANPOOL:
                 src = teamsvecs.get("original_skill", skill)
                 e.set_skill_table(np.asarray(table, dtype=np.float32)); e.set_skill_csr(src)
