@@ -1314,7 +1314,6 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
             const char* ap = sb + 256 * (32 * u + il) + 16 * ((2 * s + half) ^ fil) + mat * TM;
 #pragma unroll
             for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
-            fr[2] = u32x4{0u, 0u, 0u, 0u};
         };
         auto z_mma = [&](int u, int hg, const u32x4 (&fr)[3]) {
             const int s = hg / NMAT, mat = hg % NMAT;
@@ -1368,7 +1367,6 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
                 const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[1][jt] + o)));
                 bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
             }
-            bf[2] = bf[0];
         };
         auto d_mma = [&](int u, int g, const u32x4 (&bf)[3]) {
             const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
@@ -1389,37 +1387,34 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
             }
         };
 
-        u32x4 fr[2][3], bf[2][3];
-        // ---- zT(u = 0)
-        z_load(0, 0, fr[0]);
+        // The 2 NHG + 2 NGD groups of 3 MFMAs run in BUNDLES of BG: the fragments of a whole bundle (BG x 8 registers) are fetched while the previous
+        // bundle's 3 BG MFMAs run — an LDS round trip under four busy waves is 2-3 groups long, and with one wave per SIMD nobody else covers it
+        constexpr int NGRP = 2 * NHG + 2 * NGD, BG = 4, NB = NGRP / BG;
+        static_assert(NHG % BG == 0 && NGD % BG == 0, "bundles must not straddle phases");
+        u32x4 fb[2][BG][3];
+        auto load_g = [&](int G, u32x4 (&dst)[3]) {
+            if (G < NHG) z_load(0, G, dst);
+            else if (G < 2 * NHG) z_load(1, G - NHG, dst);
+            else if (G < 2 * NHG + NGD) tr_load(0, G - 2 * NHG, dst);
+            else tr_load(1, G - 2 * NHG - NGD, dst);
+        };
 #pragma unroll
-        for (int hg = 0; hg < NHG; ++hg) {
-            if (hg + 1 < NHG) z_load(0, hg + 1, fr[(hg + 1) & 1]); else z_load(1, 0, fr[(hg + 1) & 1]);
-            asm volatile("" ::: "memory");
-            z_mma(0, hg, fr[hg & 1]);
-        }
-        // ---- zT(u = 1) with the epilogue and the splits of sub-tile 0 riding on it
+        for (int k = 0; k < BG; ++k) load_g(k, fb[0][k]);
 #pragma unroll
-        for (int hg = 0; hg < NHG; ++hg) {
-            if (hg + 1 < NHG) z_load(1, hg + 1, fr[(NHG + hg + 1) & 1]); else tr_load(0, 0, bf[0]);
-            asm volatile("" ::: "memory");
-            z_mma(1, hg, fr[(NHG + hg) & 1]);
-            ride(0, hg, PERZ);
-        }
-        // ---- dh(u = 0) with the epilogue and the splits of sub-tile 1 riding on it
+        for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) {
 #pragma unroll
-        for (int g = 0; g < NGD; ++g) {
-            if (g + 1 < NGD) tr_load(0, g + 1, bf[(g + 1) & 1]); else tr_load(1, 0, bf[(g + 1) & 1]);
+                for (int k = 0; k < BG; ++k) load_g((b + 1) * BG + k, fb[(b + 1) & 1][k]);
+            }
             asm volatile("" ::: "memory");
-            d_mma(0, g, bf[g & 1]);
-            ride(1, g, PERD);
-        }
-        // ---- dh(u = 1)
 #pragma unroll
-        for (int g = 0; g < NGD; ++g) {
-            if (g + 1 < NGD) tr_load(1, g + 1, bf[(NGD + g + 1) & 1]);
-            asm volatile("" ::: "memory");
-            d_mma(1, g, bf[(NGD + g) & 1]);
+            for (int k = 0; k < BG; ++k) {
+                const int G = b * BG + k;
+                if (G < NHG) z_mma(0, G, fb[b & 1][k]);
+                else if (G < 2 * NHG) { z_mma(1, G - NHG, fb[b & 1][k]); ride(0, G - NHG, PERZ); }                 // epilogue + splits of sub-tile 0
+                else if (G < 2 * NHG + NGD) { d_mma(0, G - 2 * NHG, fb[b & 1][k]); ride(1, G - 2 * NHG, PERD); }    // ... of sub-tile 1
+                else d_mma(1, G - 2 * NHG - NGD, fb[b & 1][k]);
+            }
         }
         asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // the next tile's DMA is older than this tile's 32 dzT stores
         __builtin_amdgcn_s_barrier();
