@@ -102,9 +102,20 @@ int ntf_set_unigram(ntf_engine* e, const double* freq, int64_t n);              
 int ntf_set_param(ntf_engine* e, int layer, int kind, const float* host, int64_t count);
 int ntf_get_param(ntf_engine* e, int layer, int kind, float* host, int64_t count);
 int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int64_t count); /* p.grad after backward, fnn.py:137 */
+/* d loss / d z [B, M] of the output layer (z = its pre-activation) as the last backward / train step left it: what autograd holds for
+ * `y_` of src/mdl/fnn.py:132 before leaky_relu.  The fused kernels' only dense product, exposed so that it can be checked element-wise. */
+int ntf_get_dlogits(ntf_engine* e, float* host, int64_t count);
 int ntf_reset_optimizer(ntf_engine* e);                  /* fresh Adam per fold, src/mdl/fnn.py:104 */
 int ntf_set_lr(ntf_engine* e, float lr);                 /* ReduceLROnPlateau result, fnn.py:105,163 */
 int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step);
+/* the device generators (Flipout eps, signs, sampled negatives) are keyed by (seed, step counter, global row position); every step call
+ * advances the counter.  A data-parallel rank whose shard of a global minibatch is EMPTY makes no step call: it calls this instead, so
+ * that all ranks keep drawing the same eps for the same global step. */
+int ntf_skip_step(ntf_engine* e);
+/* fp16x3 arithmetic (NTF_MFMA_FP16X3 / default) splits weights * 2^8 and activations * 2^4 into fp16 pairs: exact for |w| < 255.9,
+ * |h| < 4094.  Operands are range-checked where they are split; a step (or inference call) in which one leaves that window runs on the
+ * exact-f32 kernels instead - never on saturated values.  This reports how many steps / calls did so since the engine was created. */
+int ntf_range_fallbacks(ntf_engine* e, int64_t* steps);
 
 /* ---- the step:  body of the hot loop                              src/mdl/fnn.py:118-151
  * rows = B global team ids (host).  loss_out may be NULL: then nothing is synchronised and the loss is
@@ -143,7 +154,8 @@ int ntf_param_segment(ntf_engine* e, int layer, int kind, int64_t* off, int64_t*
  * pred_unc/model_unc [B] = predictive entropy / mutual information (may be NULL). */
 int ntf_forward(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, const ntf_inject* inj_per_mc,
                 float* probs_host, float* pred_unc, float* model_unc);
-/* pre-sigmoid post-leaky_relu logits of ONE forward (the quantity the 1e-4 parity bar is stated on) */
+/* pre-sigmoid post-leaky_relu logits of ONE forward (the quantity the 1e-4 parity bar is stated on); computed by the same kernel as
+ * ntf_forward (for H = 128: the split-product forward kernel), not by a separate reference path */
 int ntf_logits(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* logits_host);
 /* top-K per row of the probabilities, without moving [B, M] to the host   src/pkgmgr.py:125-134 */
 int ntf_forward_topk(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nmc, int32_t K,

@@ -45,7 +45,7 @@ struct ntf_engine {
     int64_t* m_indptr = nullptr; int32_t* m_indices = nullptr; int64_t m_rows = 0;
     std::vector<int64_t> h_m_indptr; std::vector<int32_t> h_m_indices;
     int64_t* s_indptr = nullptr; int32_t* s_indices = nullptr; int64_t s_rows = 0;
-    float* table = nullptr; int64_t n_skills = 0; int table_d = 0;
+    float* table = nullptr; int64_t n_skills = 0; int table_d = 0; int32_t s_max_col = -1;
     float* Xall = nullptr; int64_t x_rows = 0;
     float* al_prob = nullptr; int32_t* al_alias = nullptr; double* al_weight = nullptr; double al_total = 0; int64_t al_n = 0;
     // per-step buffers
@@ -61,6 +61,8 @@ struct ntf_engine {
     char* fws = nullptr;              // fused path: sign-bit images, h*s_in, loss partials
     float* gemm_slab = nullptr;       // split-K partial sums of the generic GEMM
     double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
+    int32_t* d_range = nullptr;       // fp16x3 range guard (lives behind d_kl[0]): [0] raised for the current step, [1] steps that fell back to the f32 kernels
+    int64_t range_fallbacks_host = 0; // inference calls redone on the generic path for the same reason
     float* tk_vals = nullptr; int32_t* tk_idx = nullptr; int64_t tk_cap = 0;
     // injection staging (device)
     std::vector<float*> inj_eps_w, inj_eps_b, inj_s_in, inj_s_out;
@@ -190,7 +192,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->Wp.assign(e->L, nullptr); e->bp.assign(e->L, nullptr);
     if (cfg->bayesian) for (int l = 0; l < e->L; ++l) { A(dmalloc(e, &e->Wp[l], e->layers[l].nw())); A(dmalloc(e, &e->bp[l], e->layers[l].out)); }
     A(dmalloc(e, &e->partial, (int64_t)B * std::max(loss_dense_nchunk(M), fused_loss_slots(M)))); A(dmalloc(e, &e->row_fix, B));
-    A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 2)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
+    A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 4)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
     A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B)); A(dmalloc(e, &e->gemm_slab, kGemmSlabFloats));
     if (rc == NTF_OK && fused_ok(e)) {
         A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
@@ -206,6 +208,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     hipMemsetAsync(e->P, 0, off * 4, e->st); hipMemsetAsync(e->G, 0, off * 4, e->st);
     hipMemsetAsync(e->M1, 0, off * 4, e->st); hipMemsetAsync(e->V2, 0, off * 4, e->st);
     hipMemsetAsync(e->d_acc, 0, 16, e->st); hipMemsetAsync(e->d_acc_steps, 0, 16, e->st);
+    hipMemsetAsync(e->d_kl, 0, 32, e->st);
+    e->d_range = reinterpret_cast<int32_t*>(e->d_kl + 1);
     if (hipStreamSynchronize(e->st) != hipSuccess) { g_create_error = "device initialisation failed"; ntf_engine_destroy(e); return NTF_EHIP; }
     *out = e;
     return NTF_OK;
@@ -264,11 +268,14 @@ extern "C" int ntf_set_skill_csr(ntf_engine* e, const int64_t* indptr, const int
     int r = upload_csr(e, indptr, indices, n_rows, &e->s_indptr, &e->s_indices, width);
     if (r) return r;
     e->s_rows = n_rows;
+    e->s_max_col = -1;   // remembered so that a table set LATER can be checked against the column ids already resident
+    for (int64_t p = 0; p < indptr[n_rows]; ++p) e->s_max_col = std::max(e->s_max_col, indices[p]);
     return NTF_OK;
 }
 extern "C" int ntf_set_skill_table(ntf_engine* e, const float* table, int64_t n_skills, int32_t d) {
     if (!e || !table || n_skills < 1 || d < 1) return NTF_EINVAL;
     if (e->cfg.input_mode == NTF_INPUT_MEANPOOL && d != e->cfg.dims[0]) FAIL(e, NTF_EINVAL, "skill table width != dims[0]");
+    if (e->s_indptr && e->s_max_col >= n_skills) FAIL(e, NTF_EINVAL, "skill table has fewer rows than the column ids of the resident skill CSR");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, hipStreamSynchronize(e->st));
     dfree(e->table);
@@ -372,6 +379,16 @@ extern "C" int ntf_reset_optimizer(ntf_engine* e) {
 }
 extern "C" int ntf_set_lr(ntf_engine* e, float lr) { if (!e) return NTF_EINVAL; e->lr = lr; return NTF_OK; }
 extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; return NTF_OK; }
+extern "C" int ntf_skip_step(ntf_engine* e) { if (!e) return NTF_EINVAL; e->step += 1; return NTF_OK; }
+extern "C" int ntf_range_fallbacks(ntf_engine* e, int64_t* steps) {
+    if (!e || !steps) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int32_t dev = 0;
+    HIPCHK(e, hipMemcpyAsync(&dev, e->d_range + 1, 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    *steps = (int64_t)dev + e->range_fallbacks_host;
+    return NTF_OK;
+}
 
 // ------------------------------------------------------------------------------------------ step
 struct StepCtx {
@@ -386,11 +403,20 @@ struct StepCtx {
     bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
 };
 
+// team ids a step may name: below the row count of EVERY resident matrix it reads (input source and, when set, the member CSR)
+static int64_t row_limit(const ntf_engine* e) {
+    int64_t lim = INT64_MAX;
+    if (e->m_indptr) lim = std::min(lim, e->m_rows);
+    if (e->cfg.input_mode == NTF_INPUT_DENSE) { if (e->Xall) lim = std::min(lim, e->x_rows); }
+    else if (e->s_indptr) lim = std::min(lim, e->s_rows);
+    return lim == INT64_MAX ? 0 : lim;
+}
+
 static int stage_rows(ntf_engine* e, const int64_t* rows, int B, bool rows_on_device, const int64_t** dev) {
     if (!rows || B < 1 || B > e->cfg.max_batch) FAIL(e, NTF_EINVAL, "step: bad rows/B (B must be in [1, max_batch])");
     if (rows_on_device) { *dev = rows; return NTF_OK; }
-    const int64_t limit = e->m_rows;
-    for (int i = 0; i < B; ++i) if (rows[i] < 0 || (limit && rows[i] >= limit)) FAIL(e, NTF_EINVAL, "step: row id out of range");
+    const int64_t limit = row_limit(e);
+    for (int i = 0; i < B; ++i) if (rows[i] < 0 || rows[i] >= limit) FAIL(e, NTF_EINVAL, "step: row id out of range");
     HIPCHK(e, hipMemcpyAsync(e->d_rows, rows, (size_t)B * 8, hipMemcpyHostToDevice, e->st));
     // the host buffer may be reused by the caller right after return
     HIPCHK(e, hipStreamSynchronize(e->st));
@@ -429,6 +455,11 @@ constexpr float kW16Scale = 256.f, kH16Scale = 16.f;          // weights (|w| <<
 static inline float dz_scale16(const ntf_engine* e, int global_B) {   // |dz| <= max(tpw, tnw) / B  ->  scaled below 2^14
     const float dzmax = std::max(std::max(e->cfg.tpw, e->cfg.tnw), 1e-30f) / (float)std::max(global_B, 1);
     return std::exp2(std::floor(std::log2(16384.f / dzmax)));
+}
+
+// the range flag of the fp16x3 arithmetic, or null when this engine never multiplies in fp16x3
+static int32_t* range_ptr(const ntf_engine* e) {
+    return (fused_ok(e) && (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3)) ? e->d_range : nullptr;
 }
 
 static int check_ready(ntf_engine* e, bool need_labels) {
@@ -599,7 +630,9 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const bool fused = fused_ok(e);
     if ((r = make_input(e, c))) return r;
     if ((r = sample_negatives(e, c))) return r;
-    if (e->cfg.bayesian) HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 8, e->st));  // the Flipout operand producers add each layer's KL
+    // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
+    if (e->cfg.bayesian) HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 12, e->st));
+    else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
     int nslots;
     if (fused) {
@@ -615,7 +648,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if (e->cfg.bayesian) {
             { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                     1.0 / (double)lo.nw(), e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale);   // + the split planes of Wp and mu
+                                     1.0 / (double)lo.nw(), e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));   // + the split planes of Wp and mu
               f.planes_ready = e->pl_wp != nullptr;
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                      1.0 / (double)lo.out, e->d_kl); }
@@ -624,6 +657,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         f.bf16x6 = e->pl_mu != nullptr; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
         f.np = mfma_np(e); f.w_scale = kW16Scale; f.h_scale = kH16Scale; f.dz_scale = dz_scale16(e, c.global_B);
+        f.rflag = range_ptr(e);
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
@@ -663,7 +697,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.mu = e->P + li.off[NTF_P_WEIGHT];
             f.s_out = sout_; f.s_out_inj = e->cfg.bayesian && (sout_.inj != nullptr || sin_.inj != nullptr);
             f.bf16x6 = e->cfg.mfma != NTF_MFMA_F32;   // default: bf16x6
-            f.np = mfma_np(e); f.a_scale = dz_scale16(e, c.global_B); f.h_scale = kH16Scale;
+            f.np = mfma_np(e); f.a_scale = dz_scale16(e, c.global_B); f.h_scale = kH16Scale; f.rflag = range_ptr(e);
             if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale); }
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
             if (c.defer_dw) {
@@ -832,7 +866,8 @@ extern "C" int ntf_apply(ntf_engine* e) {
 extern "C" int ntf_stage_order(ntf_engine* e, const int64_t* order, int64_t n) {
     if (!e || !order || n < 1) { if (e) e->err = "stage_order: bad arguments"; return NTF_EINVAL; }
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    for (int64_t i = 0; i < n; ++i) if (order[i] < 0 || (e->m_rows && order[i] >= e->m_rows)) FAIL(e, NTF_EINVAL, "stage_order: row id out of range");
+    const int64_t limit = row_limit(e);
+    for (int64_t i = 0; i < n; ++i) if (order[i] < 0 || order[i] >= limit) FAIL(e, NTF_EINVAL, "stage_order: row id out of range");
     if (e->order_cap < n) { dfree(e->d_order); DM(e, &e->d_order, n); e->order_cap = n; }
     e->h_order.assign(order, order + n);
     HIPCHK(e, hipMemcpyAsync(e->d_order, e->h_order.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->st));
@@ -953,17 +988,53 @@ static int infer_pass(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_i
     return forward_layers(e, c, true, false);  // logits (post leaky_relu) in dZout
 }
 
+static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, int pass, int passes, bool want_unc, bool logits);
+static int range_raised(ntf_engine* e, bool& raised);
+
 extern "C" int ntf_logits(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, float* logits_host) {
     if (!e || !logits_host) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
+    const int M = e->cfg.dims[e->L];
+    if (e->pl_mu && fused_ok(e)) {
+        // the kernel the inference ships (k_out_fwd_b6 in its probs mode), storing leaky_relu(z) instead of its sigmoid
+        if (!e->Pbuf) DM(e, &e->Pbuf, (int64_t)e->cfg.max_batch * M);
+        const uint64_t step0 = e->step;
+        if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
+        int r = infer_pass_fused(e, rows, B, inj, 0, 1, false, true); if (r) return r;
+        bool raised; if ((r = range_raised(e, raised))) return r;
+        if (!raised) {
+            HIPCHK(e, hipMemcpyAsync(logits_host, e->Pbuf, (size_t)B * M * 4, hipMemcpyDeviceToHost, e->st));
+            HIPCHK(e, hipStreamSynchronize(e->st));
+            return NTF_OK;
+        }
+        e->step = step0;
+    }
     StepCtx c; int r = infer_pass(e, rows, B, inj, c); if (r) return r;
-    HIPCHK(e, hipMemcpyAsync(logits_host, e->dZout, (size_t)B * e->cfg.dims[e->L] * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipMemcpyAsync(logits_host, e->dZout, (size_t)B * M * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return NTF_OK;
+}
+
+// d loss / d z of the output layer as the last backward left it (fused path: transposed dzT; generic path: [B, M]) -> host [B, M]
+extern "C" int ntf_get_dlogits(ntf_engine* e, float* host, int64_t count) {
+    if (!e || !host) return NTF_EINVAL;
+    const int M = e->cfg.dims[e->L], B = e->last_B;
+    if (B < 1) FAIL(e, NTF_ESTATE, "dlogits: no backward has run");
+    if (count != (int64_t)B * M) FAIL(e, NTF_EINVAL, "dlogits: count != B * M of the last backward");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const float* src = e->dZout;
+    if (fused_ok(e)) {
+        if (!e->Pbuf) DM(e, &e->Pbuf, (int64_t)e->cfg.max_batch * M);
+        launch_fused_probs_finish(e->st, B, e->layers[e->L - 1].in, M, e->fws, e->dZout, e->Pbuf, nullptr, 1.f, true);
+        src = e->Pbuf;
+    }
+    HIPCHK(e, hipMemcpyAsync(host, src, (size_t)B * M * 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(e, hipStreamSynchronize(e->st));
     return NTF_OK;
 }
 
 // one MC pass of the inference through the fused bf16x6 forward kernel: probabilities accumulate in the transposed buffer dZout
-static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, int pass, int passes, bool want_unc) {
+static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_inject* inj, int pass, int passes, bool want_unc, bool logits) {
     int r;
     if ((r = check_ready(e, false))) return r;
     StepCtx c; c.B = B; c.global_B = B; c.inj = inj; c.train = false; c.step = e->step++;
@@ -987,16 +1058,28 @@ static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const
     if (e->cfg.bayesian) {
         { Scope t(e, F_FLIPOUT_OPERAND);
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, e->d_kl,
-                                 e->pl_wp, e->pl_mu, f.mu, lo.in, mfma_np(e), kW16Scale);
+                                 e->pl_wp, e->pl_mu, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], nullptr, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1], 0.0, e->d_kl); }
         f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
         f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         f.planes_ready = 1;
     }
-    f.probs = 1; f.pacc = pass > 0; f.pscale = 1.0f / (float)passes;
+    f.probs = 1; f.pacc = pass > 0; f.pscale = 1.0f / (float)passes; f.plogit = logits; f.rflag = range_ptr(e);
     { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
     { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
     { Scope t(e, F_INFER); launch_fused_probs_finish(e->st, B, lo.in, M, e->fws, e->dZout, e->Pbuf, want_unc ? e->ent_mc : nullptr, 1.0f / (float)passes, pass == passes - 1); }
+    return NTF_OK;
+}
+
+// fp16x3 inference: did an operand of the passes just queued leave the fp16 window?  (one 4-byte read; the caller synchronises for its outputs anyway)
+static int range_raised(ntf_engine* e, bool& raised) {
+    raised = false;
+    if (!range_ptr(e)) return NTF_OK;
+    int32_t v = 0;
+    HIPCHK(e, hipMemcpyAsync(&v, e->d_range, 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    raised = v != 0;
+    if (raised) e->range_fallbacks_host += 1;
     return NTF_OK;
 }
 
@@ -1005,10 +1088,17 @@ static int infer_probs(ntf_engine* e, const int64_t* rows, int32_t B, int32_t nm
     if (!e->Pbuf) DM(e, &e->Pbuf, (int64_t)e->cfg.max_batch * M);
     const int passes = e->cfg.bayesian ? std::max(1, nmc) : 1;
     if (want_unc) HIPCHK(e, hipMemsetAsync(e->ent_mc, 0, (size_t)B * 4, e->st));
-    if (e->pl_mu && fused_ok(e)) {     // bf16x6 forward kernel (H = 128): no dense logits, MC mean accumulated on the fly
-        for (int p = 0; p < passes; ++p) { int r = infer_pass_fused(e, rows, B, inj_per_mc ? &inj_per_mc[p] : nullptr, p, passes, want_unc); if (r) return r; }
-        if (want_unc) { Scope t(e, F_INFER); launch_row_entropy(e->st, e->Pbuf, B, M, e->ent_mean); }
-        return NTF_OK;
+    if (e->pl_mu && fused_ok(e)) {     // split-product forward kernel (H = 128): no dense logits, MC mean accumulated on the fly
+        const uint64_t step0 = e->step;
+        if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
+        for (int p = 0; p < passes; ++p) { int r = infer_pass_fused(e, rows, B, inj_per_mc ? &inj_per_mc[p] : nullptr, p, passes, want_unc, false); if (r) return r; }
+        bool raised; int r = range_raised(e, raised); if (r) return r;
+        if (!raised) {
+            if (want_unc) { Scope t(e, F_INFER); launch_row_entropy(e->st, e->Pbuf, B, M, e->ent_mean); }
+            return NTF_OK;
+        }
+        e->step = step0;   // an operand left the fp16 window: the same passes (same generator keys) again on the exact-f32 path below
+        if (want_unc) HIPCHK(e, hipMemsetAsync(e->ent_mc, 0, (size_t)B * 4, e->st));
     }
     for (int p = 0; p < passes; ++p) {
         StepCtx c; int r = infer_pass(e, rows, B, inj_per_mc ? &inj_per_mc[p] : nullptr, c); if (r) return r;

@@ -28,7 +28,11 @@ struct FusedOut {
     int wide = 1;                                   // np = 2 training step: the 64-expert-tile kernel (0: the 32-expert-tile kernel, for A/B runs)
     int planes_ready = 0;
     // inference (train = 0, probs = 1): dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale instead of the loss; the row entropy partials go to the workspace
-    int probs = 0, pacc = 0; float pscale = 1.f;                           // the planes were already written this step (by the Flipout operand producer)
+    int probs = 0, pacc = 0; float pscale = 1.f;
+    int plogit = 0;                                 // probs pass that stores leaky_relu(z) instead of its sigmoid (ntf_logits)
+    // fp16x3 (np = 2): operands are range-checked where they are split; a raised rflag[0] turns the split-product kernels of this step into
+    // no-ops and lets the exact-f32 kernels launched right behind them run instead (rflag[1] counts such steps).  Null: no check.
+    int* rflag = nullptr;
 };
 
 // weight / bias gradients of the output layer from dzT (K = batch); for Flipout the rho gradient is finalised here
@@ -47,6 +51,7 @@ struct FusedDw {
     int np = 3;                                     // 3: bf16 three-way split, six products; 2: fp16 two-way split of scaled operands, three products
     float a_scale = 1.f, h_scale = 1.f;             // np = 2: exact power-of-two scales of dz (applied in the kernel) and of the h planes (applied by the producer)
     int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the expert tiles [wg_begin, wg_begin + wg_count) of fused_dw_tile() experts each
+    int* rflag = nullptr;                           // fp16x3 range guard, see FusedOut
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
 };

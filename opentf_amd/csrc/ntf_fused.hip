@@ -76,8 +76,9 @@ __global__ __launch_bounds__(64) void k_sign_bits(SignSpec so, int B, int M, int
 }
 
 // hz = h zero-padded to Bpad rows (so that DMA / MFMA never touch stale rows); Flipout: sinbits and hs = h * s_in
+// h_limit > 0 (fp16x3 arithmetic): an activation beyond the fp16 window of the scaled split raises *rflag (the step then runs on the f32 kernels)
 __global__ void k_prep_h(SignSpec si, int bayes, const float* __restrict__ h, int B, int H, int Bpad, uint32_t* __restrict__ sinbits,
-                         float* __restrict__ hs, float* __restrict__ hz) {
+                         float* __restrict__ hs, float* __restrict__ hz, float h_limit, int* __restrict__ rflag) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int wpr = H / 32;
     if (t >= Bpad * wpr) return;
@@ -91,6 +92,7 @@ __global__ void k_prep_h(SignSpec si, int bayes, const float* __restrict__ h, in
     for (int b = 0; b < 32; ++b) {
         const int j = wj * 32 + b;
         const float v = (i < B) ? h[(int64_t)i * H + j] : 0.f;
+        if (rflag && !(fabsf(v) <= h_limit)) *rflag = 1;   // also catches NaN / inf
         hz[(int64_t)i * H + j] = v;
         if (bayes) hs[(int64_t)i * H + j] = ((w >> b) & 1u) ? -v : v;
     }
@@ -127,7 +129,18 @@ struct OutFwdArgs {
     int so_inj, si_inj;
     float tnw, inv_B;
     float *dzT, *slab, *lossp;
+    // fp16x3 range guard: rmode 1 (split-product kernels) = do nothing when *rflag is raised; rmode 2 (the exact-f32 kernels launched right
+    // behind them) = run ONLY then, and count the step in rflag[1]; rmode 0 = unconditional
+    int* rflag; int rmode;
 };
+__device__ __forceinline__ bool range_guard_skip(int* rflag, int rmode, bool count) {
+    if (rmode == 0) return false;
+    const int raised = __builtin_nontemporal_load(rflag);
+    if (rmode == 1) return raised != 0;
+    if (raised == 0) return true;
+    if (count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(rflag + 1, 1);
+    return false;
+}
 
 template <int H, bool BAYES, bool TRAIN, bool DH, bool INJ>
 __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
@@ -139,6 +152,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
     constexpr int NE = H / 2;                // operand elements per lane (k split over the two lane halves)
     constexpr int NJT = H / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (range_guard_skip(p.rflag, p.rmode, true)) return;
 
     // XCD-aware block -> (column group, row block): blocks that stream the same weight tiles share an XCD's L2
     int bid = blockIdx.x;
@@ -502,6 +516,7 @@ struct DwArgs {
     float *__restrict__ w_mu, *__restrict__ w_rho, *__restrict__ m_mu, *__restrict__ v_mu, *__restrict__ m_rho, *__restrict__ v_rho;
     float lr_over_bc1, b1, b2, eps, bc2_sqrt;
     int wg_begin;   // first expert tile of this launch (the expert range can be launched in chunks)
+    int* rflag; int rmode;   // fp16x3 range guard, see OutFwdArgs
     const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
 };
@@ -539,6 +554,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
     constexpr int TH = KB * HROW;           // h tile [32][H] (and h*s_in behind it)
     constexpr int STAGE = TA + (BAYES ? 2 : 1) * TH;   // two stages: the DMA of K block b+1 runs under the MFMAs of K block b
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (range_guard_skip(p.rflag, p.rmode, false)) return;
     const int c0 = (p.wg_begin + blockIdx.x) * DW_TC;
     const int crow = wave * 32 + il;        // this lane's expert row inside the tile
     const int c = c0 + crow;
@@ -746,6 +762,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
     constexpr int TB = NPL * PLANE;
     constexpr int STAGE = TA + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (range_guard_skip(p.rflag, p.rmode, false)) return;
     const int c0 = (p.wg_begin + blockIdx.x) * DW_TC;
     const int crow = wave * 32 + il;
     const int c = c0 + crow;
@@ -907,7 +924,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int BN6 = 32;   // experts per tile of the bf16x6 forward kernel
 
 // planes[tile][plane][row][H] (bf16) of a row-major f32 matrix W [M, H]; rows past M are zero
-__global__ void k_split_planes(const float* __restrict__ W, int M, int H, int np, float scale, uint16_t* __restrict__ out) {
+__global__ void k_split_planes(const float* __restrict__ W, int M, int H, int np, float scale, uint16_t* __restrict__ out, int* __restrict__ rflag) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // one thread per pair of hidden units
     const int hp = H / 2;
     const int64_t row = t / hp; const int j = (int)(t % hp) * 2;
@@ -915,6 +932,7 @@ __global__ void k_split_planes(const float* __restrict__ W, int M, int H, int np
     if (row >= Mp) return;
     float x0 = 0.f, x1 = 0.f;
     if (row < M) { const float2 v = *reinterpret_cast<const float2*>(W + row * H + j); x0 = v.x; x1 = v.y; }
+    if (np == 2 && rflag && !(fmaxf(fabsf(x0), fabsf(x1)) * scale <= 65504.f)) *rflag = 1;
     if (np == 3) planes_store_pair<3>(out, row, j, H, x0, x1, 1.f); else planes_store_pair<2>(out, row, j, H, x0, x1, scale);
 }
 
@@ -922,6 +940,7 @@ struct OutFwd6Args {
     OutFwdArgs a;
     const uint16_t *mu_pl, *wp_pl;   // k_split_planes images of mu and Wp
     float pscale; int pacc;          // PROBS: dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale; pacc: accumulate onto the previous MC passes
+    int plogit;                      // PROBS: store the logit leaky_relu(z) itself instead (ntf_logits: the quantity the 1e-4 parity bar is stated on)
     float h_scale, dz_scale, u_z, u_dh;   // fp16x3 (NP = 2): scales applied to h / dz before their split, and 1/(w scale * h scale), 1/(dz scale * w scale); 1 for bf16x6
 };
 
@@ -937,6 +956,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
     constexpr int NMAT = BAYES ? 2 : 1;
     constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (NP == 2 && range_guard_skip(p.rflag, p.rmode, false)) return;
 
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
@@ -1094,7 +1114,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
             if (PROBS) {
                 const float pr = __builtin_amdgcn_rcpf(tt) * rmask;       // experts past M: bias -1e30 -> tt = 1 + e^80 -> 0
                 lsum = fmaf(-pr * 0.6931471805599453f, __builtin_amdgcn_logf(pr + 1e-15f), lsum);
-                const float o = fmaf(pr, pp.pscale, pold[r]);
+                const float o = pp.plogit ? l : fmaf(pr, pp.pscale, pold[r]);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
                 return;
             }
@@ -1204,6 +1224,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
     constexpr int NMAT = BAYES ? 2 : 1;
     constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (range_guard_skip(p.rflag, p.rmode, false)) return;
 
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
@@ -1470,16 +1491,19 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     float* hz = reinterpret_cast<float*>(ws + w.hz);
     float* lossp = reinterpret_cast<float*>(ws + w.lossp);
     const bool inj = f.bayes && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
+    const bool guard = f.np == 2 && f.rflag != nullptr;   // fp16x3 arithmetic somewhere in this step (forward and / or dW): range-checked operands
     if (inj && (phases & 1)) hipLaunchKernelGGL(k_sign_bits, dim3((g.nCB + 63) / 64, g.Bpad), dim3(64), 0, st, f.s_out, f.B, f.M, g.nCB, sbits);
     if (phases & 1) {
         const int n = g.Bpad * (f.H / 32);
-        hipLaunchKernelGGL(k_prep_h, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.bayes, f.h, f.B, f.H, g.Bpad, sinbits, hs, hz);
+        hipLaunchKernelGGL(k_prep_h, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.bayes, f.h, f.B, f.H, g.Bpad, sinbits, hs, hz,
+                           guard ? 65504.f / f.h_scale : 0.f, guard ? f.rflag : nullptr);
     }
     OutFwdArgs a;
     a.B = f.B; a.M = f.M; a.Bpad = g.Bpad; a.NRB = g.NRB; a.NCG = g.NCG; a.T = g.T; a.nCB = g.nCB;
     a.h = hz; a.hs = hs; a.mu = f.mu; a.mu_b = f.mu_b; a.wp = f.wp; a.bp = f.bp; a.sbits = sbits; a.sinbits = sinbits;
     a.tnw = f.tnw; a.inv_B = f.inv_B; a.dzT = f.dzT; a.slab = f.dh_slab; a.lossp = lossp;
     a.so_k0 = f.s_out.k0; a.so_k1 = f.s_out.k1; a.si_k0 = f.s_in.k0; a.si_k1 = f.s_in.k1; a.so_inj = f.s_out.inj != nullptr; a.si_inj = f.s_in.inj != nullptr;
+    a.rflag = f.rflag; a.rmode = 0;
     SpecialArgs s;
     s.B = f.B; s.M = f.M; s.Bpad = g.Bpad; s.NCG = g.NCG; s.nCB = g.nCB; s.ns = f.ns;
     s.h = f.h; s.hs = hs; s.mu = f.mu; s.mu_b = f.mu_b; s.wp = f.wp; s.bp = f.bp; s.slab = f.dh_slab; s.lossp = lossp; s.h_mask = f.h_mask;
@@ -1491,11 +1515,12 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
         const int np = f.np == 2 ? 2 : 3;
         if ((phases & 1) && !f.planes_ready) {
             const int64_t Mp = ((int64_t)f.M + BN6 - 1) / BN6 * BN6, n = Mp * (f.H / 2);
-            hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.mu, f.M, f.H, np, f.w_scale, f.mu_pl);
-            if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, np, f.w_scale, f.wp_pl);
+            hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.mu, f.M, f.H, np, f.w_scale, f.mu_pl, guard ? f.rflag : nullptr);
+            if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, np, f.w_scale, f.wp_pl, guard ? f.rflag : nullptr);
         }
         if (phases & 2) {
-            OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc;
+            OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc; a6.plogit = f.plogit;
+            a6.a.rmode = (guard && np == 2) ? 1 : 0;
             a6.h_scale = np == 2 ? f.h_scale : 1.f; a6.dz_scale = np == 2 ? f.dz_scale : 1.f;
             a6.u_z = np == 2 ? 1.f / (f.w_scale * f.h_scale) : 1.f; a6.u_dh = np == 2 ? 1.f / (f.dz_scale * f.w_scale) : 1.f;
             const bool dh = f.dh != nullptr;
@@ -1517,6 +1542,10 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #undef NTF_L6B
 #undef NTF_L6
 #undef NTF_L6N
+            if (guard && np == 2 && !f.probs) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
+                OutFwdArgs af = a; af.rmode = 2;
+                if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
+            }
         }
         if ((phases & 4) && !f.probs) {
 #define NTF_SP(BY) do { if (!f.train) hipLaunchKernelGGL((k_out_special<128, BY, false, false>), dim3(f.B), dim3(64), 0, st, s);         \
@@ -1570,8 +1599,11 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.wg_begin = f.wg_count > 0 ? f.wg_begin : 0;
     if (grid <= 0) return;
     a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
+    a.rflag = f.rflag; a.rmode = 0;
+    const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
     if (f.bf16x6) {
         const int np = f.np == 2 ? 2 : 3;
+        a.rmode = guard ? 1 : 0;
         a.a_scale = np == 2 ? f.a_scale : 1.f; a.unscale = np == 2 ? 1.f / (f.a_scale * f.h_scale) : 1.f;
 #define NTF_DWB2(HH, BY, AD, NPV) do { auto kf = k_out_dw_b6<HH, BY, AD, NPV>; const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(BY ? 2 : 1) * NPV * HH * 64); \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
@@ -1583,7 +1615,8 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
 #undef NTF_DWB
 #undef NTF_DWB1
 #undef NTF_DWB2
-        return;
+        if (!guard) return;
+        a.rmode = 2;   // fall through: the exact-f32 kernel, which runs only when the range flag is raised
     }
 #define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \

@@ -255,9 +255,10 @@ void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 // planes_w / planes_mu (output layer, bf16x6 arithmetic): also the bf16 split planes of out and of pmu for the forward kernel.
 __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict__ rho, const float* __restrict__ mu, int64_t n, NormalSpec eps,
                                                          float* __restrict__ out, double w, double* kl_out, uint16_t* __restrict__ planes_w,
-                                                         uint16_t* __restrict__ planes_mu, const float* __restrict__ pmu, int H, int np, float pscale) {
+                                                         uint16_t* __restrict__ planes_mu, const float* __restrict__ pmu, int H, int np, float pscale,
+                                                         int* __restrict__ rflag) {
     const int64_t quads = (n + 3) / 4;
-    float kl = 0.f;
+    float kl = 0.f, amax = 0.f;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e0 = q * 4;
         float z[4];
@@ -282,6 +283,8 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
                     planes_store_pair<3>(planes_w, row, j, H, ov[0], ov[1], 1.f); planes_store_pair<3>(planes_w, row, j + 2, H, ov[2], ov[3], 1.f);
                     if (planes_mu) { planes_store_pair<3>(planes_mu, row, j, H, m4.x, m4.y, 1.f); planes_store_pair<3>(planes_mu, row, j + 2, H, m4.z, m4.w, 1.f); }
                 } else {
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
+                    if (planes_mu) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(m4.x), fabsf(m4.y)), fmaxf(fabsf(m4.z), fabsf(m4.w))));
                     planes_store_pair<2>(planes_w, row, j, H, ov[0], ov[1], pscale); planes_store_pair<2>(planes_w, row, j + 2, H, ov[2], ov[3], pscale);
                     if (planes_mu) { planes_store_pair<2>(planes_mu, row, j, H, m4.x, m4.y, pscale); planes_store_pair<2>(planes_mu, row, j + 2, H, m4.z, m4.w, pscale); }
                 }
@@ -294,17 +297,18 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
             }
         }
     }
+    if (rflag && !(amax * pscale <= 65504.f)) *rflag = 1;   // an operand of the fp16x3 products leaves the fp16 window (or is NaN)
     if (mu) {
         const double s = block_reduce_sum_d((double)kl);
         if (threadIdx.x == 0) atomicAdd(kl_out, s * w);
     }
 }
 void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out,
-                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale) {
+                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale, int* rflag) {
     if (n <= 0) return;
     const int64_t quads = (n + 3) / 4;
     const int blocks = (int)std::min<int64_t>((quads + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale);
+    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale, (planes_w && np == 2) ? rflag : nullptr);
 }
 
 __global__ void k_flipout_grad_finalize(const float* __restrict__ mu, const float* __restrict__ rho, float* __restrict__ g_mu,

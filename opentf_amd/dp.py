@@ -48,6 +48,14 @@ class DataParallel:
     def _reduce(self, lo, hi):
         return dist.all_reduce(self._grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _skip(self, zero_grad=True):
+        """this rank's shard of the global minibatch is empty (a last batch smaller than the world size): contribute a zero gradient and
+        advance the engine's step counter all the same - it keys the Flipout eps, which every rank must draw identically"""
+        if zero_grad:
+            self._grad.zero_()
+        if hasattr(self.engine, "skip_step"):
+            self.engine.skip_step()
+
     def _train_step(self, goff, gB, lo, hi):
         """backward of this rank's shard + gradient all-reduce + Adam for one global minibatch"""
         e, have_rows = self.engine, hi > lo
@@ -56,7 +64,7 @@ class DataParallel:
             if have_rows:
                 e.step_staged_deferred(goff + lo, hi - lo, goff, gB)
             else:
-                self._grad.zero_()
+                self._skip()
             for k, (ow, orr, cnt) in enumerate(self._chunk_ranges):
                 if have_rows:
                     e.dw_chunk(k)                     # queue chunk k's kernel ...
@@ -69,7 +77,7 @@ class DataParallel:
             if have_rows:
                 e.step_staged(goff + lo, hi - lo, global_offset=goff, global_B=gB, train=True, apply=False)
             else:
-                self._grad.zero_()
+                self._skip()
             works.append(self._reduce(0, self._grad.numel()))
         for w in works:
             w.wait()
@@ -95,6 +103,8 @@ class DataParallel:
                 self._train_step(goff, gB, lo, hi)
             elif hi > lo:
                 self.engine.step_staged(goff + lo, hi - lo, global_offset=goff, global_B=gB, train=False, apply=False)
+            else:
+                self._skip(zero_grad=False)
         s, _ = self.engine.epoch_loss()  # sum over steps of this rank's share of each batch loss
         t = torch.tensor([s], dtype=torch.float64, device=self._grad.device if self._grad.is_cuda else "cpu")
         if self.world > 1:

@@ -55,6 +55,9 @@ SYMBOLS = {
     "ntf_reset_optimizer": (C.c_int, [_P]),
     "ntf_set_lr": (C.c_int, [_P, _F]),
     "ntf_set_seed": (C.c_int, [_P, _U64, _U64]),
+    "ntf_skip_step": (C.c_int, [_P]),
+    "ntf_range_fallbacks": (C.c_int, [_P, C.POINTER(_I64)]),
+    "ntf_get_dlogits": (C.c_int, [_P, _P, _I64]),
     "ntf_train_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_eval_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_backward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
@@ -244,6 +247,22 @@ class Engine:
 
     def set_seed(self, seed, step=0):
         self._ck(lib().ntf_set_seed(self._h, int(seed) & (2**64 - 1), int(step)))
+
+    def skip_step(self):
+        """advance the generators' step counter without running a step (a data-parallel rank with an empty shard)"""
+        self._ck(lib().ntf_skip_step(self._h))
+
+    def range_fallbacks(self):
+        """steps / inference calls that ran on the exact-f32 kernels because an operand left the fp16x3 window"""
+        n = C.c_int64()
+        self._ck(lib().ntf_range_fallbacks(self._h, C.byref(n)))
+        return n.value
+
+    def dlogits(self, B):
+        """d loss / d z [B, M] of the output layer after the last backward (B = that step's batch)"""
+        out = np.empty((int(B), self.dims[-1]), dtype=np.float32)
+        self._ck(lib().ntf_get_dlogits(self._h, _ptr(out), out.size))
+        return out
 
     # ---- steps
     def _inject(self, inject, B):

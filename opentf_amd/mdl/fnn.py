@@ -69,6 +69,37 @@ def make_fnn(base):
 
         # ---- engine plumbing
         def _engine(self, teamsvecs, max_batch):
+            """The engine for this dataset.  With `self.keep_engine` set (tNtf's streaming loop does) the engine - CSR / table / dense
+            input resident in HBM - survives learn() / test() and is reused while the caller passes the same matrices."""
+            key = (id(teamsvecs.get("skill_table")) if hasattr(teamsvecs, "get") else None, id(teamsvecs["skill"]), id(teamsvecs["member"]),
+                   int(max_batch), str(self.device))
+            cached = getattr(self, "_resident", None)
+            if cached is not None:
+                if cached[0] == key:
+                    return cached[1], cached[2]
+                cached[1].close()
+                self._resident = None
+            e, dims = self._new_engine(teamsvecs, max_batch)
+            if getattr(self, "keep_engine", False):
+                self._resident = (key, e, dims)
+            return e, dims
+
+        def _release(self, engine):
+            if getattr(self, "_resident", None) is None or self._resident[1] is not engine:
+                engine.close()
+
+        def release_engine(self):
+            if getattr(self, "_resident", None) is not None:
+                self._resident[1].close()
+                self._resident = None
+
+        def _barrier(self):
+            """ranks other than 0 must not read files rank 0 is still writing (checkpoints feed test() and tNtf's warm start)"""
+            import torch
+            if getattr(self, "_world", 1) > 1:
+                torch.distributed.barrier()
+
+        def _new_engine(self, teamsvecs, max_batch):
             from .. import libntf
             skill, member = teamsvecs["skill"], teamsvecs["member"]
             n_in, n_out = skill.shape[1], member.shape[1]
@@ -162,7 +193,8 @@ def make_fnn(base):
                 self._save(engine, foldidx, e, t_loss, v_loss, f"{self.output}/f{foldidx}.pt")
                 log.info(f"{self.name()} model with {cfg2str(self.cfg)} saved at {self.output}/f{foldidx}.pt")
             w.close()
-            engine.close()
+            self._barrier()   # every f{k}.pt is complete on disk before any rank goes on to test() / the next interval
+            self._release(engine)
 
         def _save(self, engine, foldidx, e, t_loss, v_loss, path):
             """Same keys and order as src/mdl/fnn.py:160,168; tensors are CPU f32 so `map_location` loads work anywhere."""
@@ -178,6 +210,12 @@ def make_fnn(base):
             assert os.path.isdir(self.output), f"No folder for {self.output} exist!"
             b = int(cfg_get(self.cfg, "b"))
             engine, dims = self._engine(teamsvecs, b)
+            if getattr(self, "_rank", 0) != 0:
+                # one writer: rank 0 runs the inference and writes the .pred files (the reference's test() is single-process);
+                # the others wait for it so that evaluate() finds complete files
+                self._barrier()
+                self._release(engine)
+                return
             M = dims[-1]
             topK = cfg_get(testcfg, "topK")
             nmc = int(cfg_get(self.cfg, "nmc", 1) or 1)
@@ -217,7 +255,8 @@ def make_fnn(base):
                         torch.save({"y_pred": y_pred, "uncertainty": {"pred": pred_uncertainty, "model": model_uncertainty} if self.is_bayesian else None},
                                    f"{self.output}/f{foldidx}.{pred_set}.{epoch}pred", pickle_protocol=4)
                         log.info(f"{self.name()} model predictions for fold{foldidx}.{pred_set}.{epoch} has saved at {self.output}/f{foldidx}.{pred_set}.{epoch}pred")
-            engine.close()
+            self._barrier()
+            self._release(engine)
 
         @staticmethod
         def _topk_sparse(probs, k):

@@ -50,6 +50,13 @@ def set_seed(seed):
         torch.cuda.manual_seed_all(seed)
 
 
+def dist_rank():
+    """rank of this process under torchrun (one process per GPU), 0 when single-process"""
+    import torch
+    d = torch.distributed
+    return d.get_rank() if d.is_available() and d.is_initialized() else 0
+
+
 class _NullWriter:
     def __init__(self, log_dir=None): pass
     def add_scalar(self, tag, scalar_value, global_step): pass
@@ -75,8 +82,7 @@ class Ntf:
         self.writer = summary_writer()
         set_seed(self.seed)
         self.output = output + self.name()
-        if not os.path.isdir(self.output):
-            os.makedirs(self.output)
+        os.makedirs(self.output, exist_ok=True)   # one process per GPU: every rank constructs the model
 
     def name(self):
         return f"/{self.__class__.__name__.lower()}.{cfg2str(self.cfg)}"
@@ -120,10 +126,14 @@ class Ntf:
                     df, df_mean = pd.DataFrame(), pd.DataFrame()
                     if trec:
                         df, df_mean = metric.calculate_metrics(Y, Y_, cfg_get(evalcfg, "topK"), per_instance, trec)
-                    if [m for m in other if "aucroc" in m]:
-                        aucroc, _ = metric.calculate_auc_roc(Y, Y_)
+                    auc = [m for m in other if "aucroc" in m]
+                    if auc:
+                        aucroc, fpr_tpr = metric.calculate_auc_roc(Y, Y_, curve=(auc[0] == "aucroc+"))
                         if df_mean.empty: df_mean = pd.DataFrame(columns=["mean"])
                         df_mean.loc["aucroc"] = aucroc
+                        if fpr_tpr:   # the (fpr, tpr) pair plot_roc consumes (src/mdl/ntf.py:67-69)
+                            import pickle
+                            with open(f"{predfile}.eval.roc.pkl", "wb") as outfile: pickle.dump(fpr_tpr, outfile)
                     skc = [m for m in other if "skill_coverage" in m]
                     if skc:
                         X = teamsvecs["skill"] if scipy.sparse.issparse(teamsvecs["skill"]) else teamsvecs["original_skill"]

@@ -1,7 +1,18 @@
-"""`tNtf`: the reference's streaming trainer (src/mdl/tntf.py:7-47): for each year interval (all but the last
-`step_ahead`), K-fold that interval's teams, point the inner model at `{output}/{year}` and fine-tune it from the
-previous interval's `f{k}.pt`.  Each interval gets a fresh Adam / scheduler / early stopper (because Fnn.learn
-creates them); only weights carry over."""
+"""`tNtf`: streaming (temporal) training over year intervals — the standalone counterpart of the reference's wrapper
+(src/mdl/tntf.py:7-44), needed wherever this package runs WITHOUT the reference tree (the GPU box, `bench.py`, the tests);
+mounted inside the reference tree the reference's own `mdl.tntf.tNtf` wraps the plugin unchanged.
+
+Same contract on disk and towards the caller (pinned by tests/golden/g13_tntf_dblp.npz, a run of the reference's class):
+one directory per interval `{output}/{year}` holding `splits.pkl` + the inner model's files; interval i is K-folded with
+`KFold(tfolds, shuffle=True, random_state=seed)` over `arange(year_idx[i][0], year_idx[i+1][0])` and written INTO the caller's
+`splits['folds']` (the reference mutates it, tntf.py:30-31); the last `step_ahead` intervals are never trained on; every
+interval warm-starts from the previous one's `f{k}.pt`; a directory that already holds more than one year resumes past the
+earliest ones (tntf.py:22-26); `inner.output` is left pointing at the last trained interval, which is where test() reads.
+
+What differs is where the data lives: the inner model's engine — skill / member CSR, embedding table, staging buffers — is
+created once and stays resident in HBM across all intervals (`keep_engine`), instead of being rebuilt and re-uploaded per
+interval as `learn()` called in a loop would do; only the K x tfolds row-id lists change between intervals.
+"""
 from __future__ import annotations
 
 import logging
@@ -10,9 +21,16 @@ import pickle
 
 import numpy as np
 
-from .ntf import Ntf, cfg_get
+from .ntf import Ntf, cfg_get, dist_rank
 
 log = logging.getLogger(__name__)
+
+
+def interval_folds(year_idx, i, tfolds, seed):
+    """[(train_ids, valid_ids)] * tfolds of interval i (team ids are contiguous per year: year_idx = [(first_team_id, year), ...])"""
+    from sklearn.model_selection import KFold
+    ids = np.arange(year_idx[i][0], year_idx[i + 1][0])
+    return [(ids[tr], ids[va]) for tr, va in KFold(n_splits=int(tfolds), random_state=seed, shuffle=True).split(ids)]
 
 
 def make_tntf(base):
@@ -25,27 +43,35 @@ def make_tntf(base):
 
         def name(self): return ""
 
+        def intervals(self):
+            """indices of the intervals that are trained on: all but the last `step_ahead` (those are the test set)"""
+            return range(len(self.year_idx) - int(cfg_get(self.cfg, "step_ahead")))
+
         def learn(self, teamsvecs, splits, prev_model):
-            from sklearn.model_selection import KFold
-            done = [int(item) for item in os.listdir(self.model.output) if item.isdigit()]
-            step_ahead = int(cfg_get(self.cfg, "step_ahead"))
-            for i, v in enumerate(self.year_idx[:-step_ahead]):  # the last intervals are the test set
-                if len(done) > 1:  # resume: this year was trained by an earlier run (tntf.py:22-26)
-                    log.info(f"The model has already been trained on year {min(done)}")
-                    done.remove(min(done))
-                    continue
-                train = np.arange(self.year_idx[i][0], self.year_idx[i + 1][0])
-                skf = KFold(n_splits=int(cfg_get(self.cfg, "tfolds")), random_state=self.seed, shuffle=True)
-                for k, (tr, va) in enumerate(skf.split(train)):
-                    splits["folds"][k]["train"] = train[tr]
-                    splits["folds"][k]["valid"] = train[va]
-                self.model.output = f"{self.output}/{self.year_idx[i][1]}"
-                if not os.path.isdir(self.model.output):
-                    os.makedirs(self.model.output)
-                with open(f"{self.model.output}/splits.pkl", "wb") as f:
-                    pickle.dump(splits, f)
-                self.model.learn(teamsvecs, splits, prev_model)
-                prev_model = {k: f"{self.model.output}/f{k}.pt" for k in splits["folds"].keys()}
+            trained = sorted(int(d) for d in os.listdir(self.model.output) if d.isdigit())   # year directories of an earlier run
+            can_keep = hasattr(self.model, "release_engine")
+            if can_keep:
+                self.model.keep_engine = True
+            try:
+                for i in self.intervals():
+                    year = self.year_idx[i][1]
+                    if len(trained) > 1:   # resume: skip as many intervals as there are finished years but the last one
+                        log.info(f"The model has already been trained on year {trained[0]}")
+                        trained.pop(0)
+                        continue
+                    for k, (tr, va) in enumerate(interval_folds(self.year_idx, i, cfg_get(self.cfg, "tfolds"), self.seed)):
+                        splits["folds"][k]["train"], splits["folds"][k]["valid"] = tr, va
+                    self.model.output = f"{self.output}/{year}"
+                    os.makedirs(self.model.output, exist_ok=True)
+                    if dist_rank() == 0:
+                        with open(f"{self.model.output}/splits.pkl", "wb") as f:
+                            pickle.dump(splits, f)
+                    self.model.learn(teamsvecs, splits, prev_model)   # fresh Adam / scheduler / early stopper per interval, weights carried over
+                    prev_model = {k: f"{self.model.output}/f{k}.pt" for k in splits["folds"].keys()}
+            finally:
+                if can_keep:
+                    self.model.keep_engine = False
+                    self.model.release_engine()
 
         def test(self, teamsvecs, splits, testcfg): self.model.test(teamsvecs, splits, testcfg)
 

@@ -131,6 +131,50 @@ def test_temporal_streaming_warm_start(tmp_path):
     assert os.path.exists(f"{inner.output}/f0.test.pred")
 
 
+def test_tntf_reproduces_the_reference_tntf_run(tmp_path):
+    """g13 = the reference's own mdl.tntf.tNtf around its own mdl.fnn.Fnn (nsd=None) on toy dblp, run by tests/golden/make_golden_tntf.py:
+    same year directories, same per-interval K-fold splits, same early-stop epochs, loss series, warm-started weights of every
+    interval and fold, and the same test predictions from the last interval's models."""
+    from opentf_amd.mdl.fnn import Fnn
+    from opentf_amd.mdl.tntf import tNtf
+    g = golden("g13_tntf_dblp")
+    cfg = Cfg(json.loads(str(g["cfg"])))
+    tv, _ = _toy("dblp")
+    seed = int(g["seed"])
+    year_idx = [(int(a), int(b)) for a, b in g["i2y"]]
+    inner = Fnn(str(tmp_path), "cuda:0", seed, cfg)
+    assert inner.name() == str(g["root_name"])
+    t = tNtf(str(tmp_path), "cuda:0", seed, Cfg(tfolds=int(g["tfolds"]), step_ahead=int(g["step_ahead"])), inner, year_idx)
+    sp = {"test": g["test"], "folds": {k: {} for k in range(int(g["tfolds"]))}}
+    Scalars.rows = []
+    inner.writer = Scalars
+    t.learn(tv, sp, None)
+    years = [int(y) for y in g["years"]]
+    assert sorted(int(d) for d in os.listdir(t.output) if d.isdigit()) == years
+    assert os.path.relpath(inner.output, t.output) == str(g["last_output_suffix"])
+    ref = json.loads(str(g["scalars"]))
+    assert [(a, c) for a, _, c in Scalars.rows] == [(a, c) for a, _, c in ref]          # same epochs per interval and fold (early stopping)
+    np.testing.assert_allclose([v for _, v, _ in Scalars.rows], [v for _, v, _ in ref], rtol=1e-4)
+    for y in years:
+        s = pickle.load(open(f"{t.output}/{y}/splits.pkl", "rb"))
+        assert np.array_equal(s["test"], g["test"])
+        for k in range(3):
+            assert np.array_equal(s["folds"][k]["train"], g[f"{y}.train{k}"]) and np.array_equal(s["folds"][k]["valid"], g[f"{y}.valid{k}"])
+            ck = torch.load(f"{t.output}/{y}/f{k}.pt", map_location="cpu", weights_only=False)
+            assert ck["e"] == int(g[f"{y}.f{k}.e"])
+            for name, v in ck["model_state_dict"].items():
+                np.testing.assert_allclose(v.numpy(), g[f"{y}.f{k}.{name}"], rtol=2e-3, atol=2e-5)
+    t.test(tv, sp, Cfg(per_epoch=False, on_train=False, topK=None))
+    for k in range(3):
+        pr = torch.load(f"{inner.output}/f{k}.test.pred", map_location="cpu", weights_only=False)
+        np.testing.assert_allclose(pr["y_pred"].numpy(), g[f"test.f{k}.y_pred"], rtol=1e-3, atol=1e-5)
+    # resume (tntf.py:22-26): a directory that already holds the five years trains nothing more and rewrites nothing
+    stamp = {y: os.path.getmtime(f"{t.output}/{y}/f0.pt") for y in years[:-1]}
+    inner.output = t.output
+    t.learn(tv, sp, None)
+    assert all(os.path.getmtime(f"{t.output}/{y}/f0.pt") == stamp[y] for y in years[:-1])
+
+
 def test_table_t2v_get_dense_vecs_and_meanpool_training(tmp_path):
     from opentf_amd.mdl.emb.t2v import TableT2v
     from opentf_amd.mdl.fnn import Fnn

@@ -1,0 +1,337 @@
+"""Round-2 parity additions on a real MI355X (through the C ABI):
+  * the kernel the training step SHIPS (fp16x3 64-expert-tile forward, and its bf16x6 / f32 siblings) checked ELEMENT-WISE: its only dense
+    product, d loss / d z, against autograd of the oracle, and the logits recovered from it at north_star's 1e-4 bar;
+  * `ntf_logits` now runs the shipped inference kernel (split-product forward in its probs mode), not the generic GEMM;
+  * fp16x3 range guard: operands outside the fp16 window make the step run on the exact-f32 kernels (equal to the f32 engine, counted);
+  * the `unigram` sampler (global f64 table) held to the reference's invariants and distribution (src/mdl/fnn.py:58-72);
+  * BASELINE configs 3, 4, 5 exercised at reduced size against the oracle and at full size through fused == generic."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse
+import torch
+import torch.nn.functional as F
+
+from oracle import ntf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LOGITS = 1e-4  # BASELINE.json north_star
+
+
+def _engine(*a, **k):
+    from opentf_amd.libntf import Engine
+    return Engine(*a, **k)
+
+
+def _csr_from_dense(y):
+    m = scipy.sparse.csr_matrix(np.asarray(y) != 0)
+    return m.indptr.astype(np.int64), m.indices.astype(np.int32)
+
+
+def _case(D, H, M, B, seed, bayesian):
+    torch.manual_seed(seed)
+    sd = O.bnn_init(D, H, M) if bayesian else O.fnn_init(D, H, M)
+    X = torch.randn(B, D)
+    y = (torch.rand(B, M) < 0.01).float(); y[torch.arange(B), torch.randint(0, M, (B,))] = 1
+    return sd, X, y
+
+
+def _inj(noise, neg):
+    d = {"neg_idx": neg.numpy()}
+    if noise is not None:
+        d.update({"eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise], "s_in": [n["s_in"] for n in noise],
+                  "s_out": [n["s_out"] for n in noise]})
+    return d
+
+
+def _oracle_last_preact(sd, X, noise):
+    """hidden layers as the oracle computes them, then the LAST layer's pre-activation z (requires grad), its leaky_relu"""
+    L = O.n_layers(sd)
+    x = X
+    for i in range(L):
+        p = f"layers.{i}."
+        if O.is_bayesian(sd):
+            z = O.flipout_linear(x, sd[p + "mu_weight"], sd[p + "rho_weight"], sd[p + "mu_bias"], sd[p + "rho_bias"], noise[i])
+        else:
+            z = F.linear(x, sd[p + "weight"], sd[p + "bias"])
+        if i == L - 1:
+            z = z.detach().requires_grad_(True)
+            return z, F.leaky_relu(z)
+        x = F.leaky_relu(z)
+
+
+# ------------------------------------------------------------------------------------------ the shipped training kernel, element-wise
+@pytest.mark.parametrize("bayesian,M,B", [(True, 1500, 70), (True, 5000, 130), (False, 4096, 64), (True, 777, 257)])
+@pytest.mark.parametrize("mfma", [None, "bf16x6", "f32"])
+def test_training_forward_kernel_dlogits_and_logits_elementwise(bayesian, M, B, mfma):
+    D, H, ns, tpw, tnw = 128, 128, 5, 10.0, 1.0
+    sd, X, y = _case(D, [H], M, B, 21, bayesian)
+    noise = O.draw_flipout_noise(sd, B) if bayesian else None
+    neg = O.ns_uniform(y, ns)
+    z, logit = _oracle_last_preact(sd, X, noise)
+    loss = O.bxe(logit, y, neg, tpw, tnw).sum(dim=1).mean()
+    (dz_ref,) = torch.autograd.grad(loss, z)
+    dz_ref, logit = dz_ref.numpy().astype(np.float64), logit.detach().numpy().astype(np.float64)
+
+    e = _engine([D, H, M], bayesian=bayesian, max_batch=B, ns=ns, nsd="uniform", tpw=tpw, tnw=tnw, mfma=mfma)
+    e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
+    e.kernel_times(True)
+    e.backward(np.arange(B), inject=_inj(noise, neg))
+    times = e.kernel_times(False)
+    assert times["out_fused_fwd_loss_dh"][1] >= 1 and times["out_fwd_gemm"][1] == 0   # the fused kernel produced it, not the generic GEMM
+    dz = e.dlogits(B).astype(np.float64)
+    assert e.range_fallbacks() == 0
+
+    # (1) every element of d loss / d z, specials (positives, sampled negatives) included.  leaky_relu' jumps at z = 0: an element with
+    #     |z| ~ 1e-7 may land on the other side in another summation order -> at most a couple of such elements, everything else to 1e-4
+    bad = np.abs(dz - dz_ref) > RTOL_LOGITS * np.abs(dz_ref) + 1e-12
+    assert bad.sum() <= 2, int(bad.sum())
+    assert (np.abs(logit[bad]) < 1e-5).all()
+
+    # (2) the logits the kernel computed, recovered from dz on the plain (un-sampled negative) entries:
+    #     dz = tnw/B * sigmoid(l) * (1 if z > 0 else 0.01), l = leaky_relu(z)  ->  u = dz * B / tnw in (0.5, 1) or (0, 0.005]
+    special = (y.numpy() != 0)
+    special[np.arange(B)[:, None], neg.numpy()] = True
+    u = dz * B / tnw
+    pos = u > 0.25
+    s = np.where(pos, u, u / 0.01)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        l_rec = np.log(s) - np.log1p(-s)
+    ok = ~special & ~bad & (np.abs(logit) < 8)          # sigmoid saturates beyond: the inversion loses the digits, not the kernel
+    assert ok.mean() > 0.95
+    err = np.abs(l_rec - logit)[ok]
+    tol = (RTOL_LOGITS * np.abs(logit) + 2e-6)[ok]      # same element-wise bar as ntf_logits is held to
+    assert (err <= tol).all(), (float(err.max()), int((err > tol).sum()))
+
+
+@pytest.mark.parametrize("bayesian", [True, False])
+def test_ntf_logits_runs_the_shipped_inference_kernel(bayesian):
+    D, H, M, B = 128, 128, 3000, 90
+    sd, X, y = _case(D, [H], M, B, 8, bayesian)
+    noise = O.draw_flipout_noise(sd, B) if bayesian else None
+    ref = O.model_forward(sd, X, noise).detach().numpy()
+    for mfma in (None, "bf16x6"):
+        e = _engine([D, H, M], bayesian=bayesian, max_batch=B, mfma=mfma)
+        e.load_state_dict(sd); e.set_dense_input(X.numpy())
+        e.kernel_times(True)
+        inj = None if noise is None else {k: v for k, v in _inj(noise, torch.zeros(B, 5, dtype=torch.long)).items() if k != "neg_idx"}
+        got = e.logits(np.arange(B), inject=inj)
+        t = e.kernel_times(False)
+        assert t["out_fused_fwd_loss_dh"][1] == 1 and t["out_fwd_gemm"][1] == 0
+        np.testing.assert_allclose(got, ref, rtol=RTOL_LOGITS, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ fp16x3 range guard
+@pytest.mark.parametrize("what", ["weight", "hidden", "sigma"])
+def test_fp16x3_range_overflow_runs_the_exact_f32_kernels(what):
+    """|w| * 2^8 or |h| * 2^4 beyond the fp16 window: no silent saturation - the step runs on the f32 MFMA kernels instead, bit-identical to
+    an engine created with mfma='f32', and is counted."""
+    D, H, M, B = 16, 128, 900, 40
+    sd, X, y = _case(D, [H], M, B, 3, True)
+    if what == "weight": sd["layers.1.mu_weight"][17, 5] = 300.0
+    if what == "sigma": sd["layers.1.rho_weight"][:] = 80.0           # sigma * eps = 80 eps: |eps| > 3.2 somewhere among 115 200 draws, every step
+    if what == "hidden": sd["layers.0.mu_bias"][:] = 5000.0
+    res = {}
+    for mfma in (None, "f32"):
+        e = _engine([D, H, M], bayesian=True, max_batch=B, ns=3, nsd="uniform", seed=4, mfma=mfma)
+        e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
+        ev = e.eval_step(np.arange(B))
+        l1 = e.train_step(np.arange(B)); g1 = e.grads()
+        l2 = e.train_step(np.arange(B))
+        e.set_seed(4, 10)
+        probs, pu, mu = e.forward(np.arange(B), nmc=2, uncertainty=True)
+        e.set_seed(4, 20)
+        lg = e.logits(np.arange(B))
+        res[mfma] = (ev, l1, l2, g1, e.state_dict(), probs, pu, lg, e.range_fallbacks())
+    a, b = res[None], res["f32"]
+    assert a[8] == 5 and b[8] == 0                      # eval + 2 train steps + forward + logits fell back; the f32 engine never does
+    assert np.isfinite([a[0], a[1], a[2]]).all()
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    for k in a[3]:
+        assert np.array_equal(a[3][k], b[3][k]), k
+        assert np.array_equal(a[4][k], b[4][k]), k
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
+    # and in range nothing falls back
+    sd2, _, _ = _case(D, [H], M, B, 3, True)
+    e = _engine([D, H, M], bayesian=True, max_batch=B, ns=3, nsd="uniform", seed=4)
+    e.load_state_dict(sd2); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
+    e.train_step(np.arange(B)); e.forward(np.arange(B), nmc=2)
+    assert e.range_fallbacks() == 0
+
+
+# ------------------------------------------------------------------------------------------ unigram sampler (global f64 table)
+@pytest.mark.parametrize("fused", [False, True])
+def test_native_unigram_sampler_invariants_distribution_and_fallback(fused):
+    """src/mdl/fnn.py:58-72: weights = the f64 expert frequency over ALL teams, zeroed on the row's own experts; ns DISTINCT picks without
+    replacement, proportional to the weights; a row whose candidates all have zero weight falls back to uniform over all columns."""
+    B, M, ns = 64, 120, 4
+    rng = np.random.default_rng(5)
+    w = np.zeros(M); w[:5] = 16.0 / 400; w[5:30] = 1.0 / 400       # support = 30 experts, five of them 16x as frequent
+    y = np.zeros((B, M), np.float32)
+    for i in range(B):
+        y[i, rng.choice(30, 2, replace=False)] = 1
+    y[0] = 0; y[0, :30] = 1                                         # row 0 owns the whole support -> fallback
+    sd = {"layers.0.weight": torch.eye(B), "layers.0.bias": torch.zeros(B), "layers.1.weight": torch.zeros(M, B), "layers.1.bias": torch.zeros(M)}
+    e = _engine([B, B, M], max_batch=B, ns=ns, nsd="unigram", tpw=1.0, tnw=0.0, seed=9, fused=fused)
+    e.load_state_dict(sd); e.set_dense_input(np.eye(B, dtype=np.float32)); e.set_member(_csr_from_dense(y)); e.set_unigram(w)
+    hits, fb = np.zeros(M), set()
+    for it in range(80):
+        e.backward(np.arange(B))
+        dw = e.grads()["layers.1.weight"]          # [M, B]: column i = row i's dz; tnw = 0 -> only positives (< 0) and picks (> 0) are non-zero
+        for i in range(B):
+            picked = np.nonzero(dw[:, i] > 0)[0]
+            if i == 0:
+                fb.update(picked.tolist())
+                # the reference's fallback draws over ALL columns (positives included, fnn.py:67-69): a pick that is a positive shows as a
+                # weaker negative gradient, so only the distinct non-member picks are visible here
+                assert len(picked) <= ns
+                continue
+            assert len(picked) == ns, (i, picked)                  # distinct, count ns
+            assert (y[i, picked] == 0).all() and (picked < 30).all()   # among the row's negatives, inside the support
+            hits[picked] += 1
+    assert hits[30:].sum() == 0
+    per_w = hits[:30] / w[:30]
+    ratio = per_w[:5].mean() / per_w[5:].mean()
+    assert 0.58 < ratio < 0.88, ratio                              # successive draws without replacement, proportional to the weights: 0.72 (simulated)
+    assert hits[:5].min() > 3 * hits[5:30].max()
+    assert max(fb) >= 30 and len(fb) > 40                          # fallback row: uniform over all 120 columns
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 4 (uspt, d = 256 table)
+@pytest.mark.parametrize("mfma", [None, "f32"])
+def test_config4_d256_table_bnn_step_vs_oracle(mfma):
+    """[256, 128, M] Bnn on a mean-pooled d = 256 table (uspt shapes at reduced M), every random tensor injected."""
+    from opentf_amd import libntf
+    S, D, H, M, B, N = 2000, 256, 128, 3000, 70, 400
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((S, D)).astype(np.float32)
+    nnz = 1 + rng.poisson(5.29, N)
+    indptr = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(S, k, replace=False)) for k in nnz]).astype(np.int32)
+    torch.manual_seed(1)
+    sd = O.bnn_init(D, [H], M)
+    yfull = (torch.rand(N, M) < 0.001).float(); yfull[torch.arange(N), torch.randint(0, M, (N,))] = 1
+    rows = rng.choice(N, B, replace=False)
+    X = torch.from_numpy(O.gather_meanpool_fast(indptr, indices, table, rows)); y = yfull[rows]
+    e = _engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", lr=1e-3, mfma=mfma)
+    e.set_skill_table(table); e.set_skill_csr((indptr, indices)); e.set_member(_csr_from_dense(yfull.numpy())); e.load_state_dict(sd)
+    opt = O.Adam(sd, 1e-3)
+    for s in range(2):
+        noise = O.draw_flipout_noise(sd, B); neg = O.ns_uniform(y, 5)
+        inj = _inj(noise, neg)
+        ref_logits = O.bnn_forward(sd, X, noise).detach().numpy()
+        np.testing.assert_allclose(e.logits(rows, inject=inj), ref_logits, rtol=RTOL_LOGITS, atol=2e-6)
+        ref_loss, ref_grads = O.train_step(sd, opt, X, y, neg, 10.0, 1.0, noise)
+        loss = e.train_step(rows, inject=inj)
+        assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss)
+        grads, state = e.grads(), e.state_dict()
+        for k in sd:
+            gr = ref_grads[k].numpy()
+            assert np.abs(grads[k] - gr).max() <= 3e-4 * np.abs(gr).max(), k
+            np.testing.assert_allclose(state[k], sd[k].numpy(), rtol=1e-3, atol=2e-5)
+
+
+def _fused_vs_generic(dims, mode, data, B, nsd, seed, unigram=None, n_rows=50_000):
+    """same device seeds -> same eps / signs / negatives on both paths: loss and every gradient must agree (independent implementations)"""
+    from opentf_amd import libntf
+    from opentf_amd.synth import init_params
+    sd = init_params(dims, True, 0)
+    rows = np.random.default_rng(1).integers(0, n_rows, B)
+    res = []
+    for fused in (True, False):
+        e = libntf.Engine(dims, bayesian=True, input_mode=mode, max_batch=B, ns=5, nsd=nsd, seed=seed, fused=fused)
+        if mode == libntf.INPUT_MEANPOOL: e.set_skill_table(data["table"])
+        e.set_skill_csr(data["skill"]); e.set_member(data["member"]); e.load_state_dict(sd)
+        if unigram is not None: e.set_unigram(unigram)
+        ev = e.eval_step(rows); e.set_seed(seed, 0)
+        loss = e.backward(rows)
+        res.append((ev, loss, e.grads()))
+        e.close()
+    (ev_f, l_f, g_f), (ev_g, l_g, g_g) = res
+    assert abs(ev_f - ev_g) <= 2e-6 * abs(ev_g) and abs(l_f - l_g) <= 2e-6 * abs(l_g)
+    for k in g_g:
+        scale = np.abs(g_g[k]).max()
+        d = np.abs(g_f[k] - g_g[k])
+        assert (d > 2e-5 * scale).sum() <= 64 * dims[-2], k      # a handful of leaky_relu' kink flips move one expert's row each
+        assert d.max() <= 2e-2 * scale, (k, float(d.max()), float(scale))
+    return l_f
+
+
+def test_config4_uspt_full_shape_fused_equals_generic():
+    """uspt mt10.ts2 shapes: S = 213 317, M = 394 187, d = 256 table -> [256, 128, M], B = 1000"""
+    from opentf_amd import libntf
+    from opentf_amd.synth import zipf_csr
+    N, S, M = 50_000, 213_317, 394_187
+    data = {"skill": zipf_csr(N, S, 6.29, 1), "member": zipf_csr(N, M, 2.51, 2), "table": np.random.default_rng(0).standard_normal((S, 256), dtype=np.float32)}
+    loss = _fused_vs_generic([256, 128, M], libntf.INPUT_MEANPOOL, data, 1000, "uniform", 31)
+    assert 0.6 * M < loss < 0.8 * M
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 3 (multi-hot input, unigram)
+def test_config3_multihot_unigram_full_shape_fused_equals_generic():
+    """dblp mt10.ts2 with MULTI-HOT skills (D = S = 90 671: layer 0 is a CSR gather-sum), nsd = unigram (f64 table over all teams), B = 1000"""
+    from opentf_amd import libntf
+    from opentf_amd.synth import zipf_csr
+    N, S, M = 50_000, 90_671, 233_629
+    member = zipf_csr(N, M, 3.06, 2)
+    freq = np.bincount(member[1], minlength=M).astype(np.float64) / N      # member.sum(axis=0) / N  (fnn.py:82)
+    data = {"skill": zipf_csr(N, S, 8.57, 1), "member": member}
+    _fused_vs_generic([S, 128, M], libntf.INPUT_MULTIHOT, data, 1000, "unigram", 17, unigram=freq)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 5 (gith, temporal streaming)
+class Cfg(dict):
+    def __getattr__(self, k):
+        if k.startswith("__"): raise AttributeError(k)
+        return self.get(k)
+
+
+def test_config5_gith_shapes_temporal_streaming_bnn(tmp_path):
+    """gith shapes (S = 486 skills, filtered M = 39 204 experts, d = 128 table), teams sorted by year, 5 intervals + 1 test interval, Bnn:
+    tNtf streams the intervals over ONE resident engine; with lr = 0 nothing may change, so every interval's checkpoint must equal the first
+    interval's initial weights - which only holds if each interval really warm-starts from the previous one's file (a cold start would
+    draw fresh weights); with lr > 0 the chain moves and the test predictions of the last interval are produced."""
+    from opentf_amd.mdl.bnn import Bnn
+    from opentf_amd.mdl.tntf import tNtf
+    from opentf_amd.synth import zipf_csr
+    N, S, M, d = 6000, 486, 39_204, 128
+    s_ip, s_ix = zipf_csr(N, S, 1.37, 1); m_ip, m_ix = zipf_csr(N, M, 5.53, 2)
+    skill = scipy.sparse.csr_matrix((np.ones(len(s_ix), np.uint8), s_ix, s_ip), shape=(N, S))
+    member = scipy.sparse.csr_matrix((np.ones(len(m_ix), np.uint8), m_ix, m_ip), shape=(N, M))
+    table = np.random.default_rng(0).standard_normal((S, d), dtype=np.float32)
+    dense = np.asarray((skill @ table) / skill.sum(axis=1), dtype=np.float32)          # what main.py:148-153 hands over
+    tv = {"skill": dense, "original_skill": skill, "member": member, "skill_table": table}
+    year_idx = [(0, 2016), (900, 2017), (2000, 2018), (3100, 2019), (4300, 2020), (5400, 2021)]
+    sp = {"test": np.arange(5400, N), "folds": {k: {} for k in range(2)}}
+    for lr in (0.0, 0.01):
+        cfg = Cfg(b=1000, e=1, ns=5, lr=lr, es=5, h=[128], spe=0, l="bce", tpw=10, tnw=1, nsd="uniform", nmc=2)
+        inner = Bnn(str(tmp_path / f"lr{lr}"), "cuda:0", 0, cfg)
+        t = tNtf(str(tmp_path / f"lr{lr}"), "cuda:0", 0, Cfg(tfolds=2, step_ahead=1), inner, year_idx)
+        t.learn(tv, sp, None)
+        assert getattr(inner, "_resident", None) is None                                # released at the end of the stream
+        years = sorted(int(x) for x in os.listdir(t.output) if x.isdigit())
+        assert years == [2016, 2017, 2018, 2019, 2020]
+        w = [torch.load(f"{t.output}/{y}/f0.pt", map_location="cpu", weights_only=False) for y in years]
+        s17 = pickle.load(open(f"{t.output}/2017/splits.pkl", "rb"))
+        assert set(np.concatenate([s17["folds"][0]["train"], s17["folds"][0]["valid"]])) == set(range(900, 2000))
+        for a, b in zip(w[:-1], w[1:]):
+            same = all(torch.equal(a["model_state_dict"][k], b["model_state_dict"][k]) for k in a["model_state_dict"])
+            assert same == (lr == 0.0)
+            assert np.isfinite(b["t_loss"]) and np.isfinite(b["v_loss"])
+        if lr > 0:
+            assert w[-1]["t_loss"] < w[0]["t_loss"]                                     # the chain keeps learning across intervals
+            t.test(tv, sp, Cfg(per_epoch=False, on_train=False, topK=10))
+            pr = torch.load(f"{inner.output}/f1.test.pred", map_location="cpu", weights_only=False)
+            assert pr["y_pred"].is_sparse and tuple(pr["y_pred"].shape) == (600, M) and pr["y_pred"]._nnz() == 6000
+
+
+def test_config5_gith_full_shape_fused_equals_generic():
+    """unfiltered gith: M = 1 369 895 experts, S = 486, d = 128, B = 1000"""
+    from opentf_amd import libntf
+    from opentf_amd.synth import zipf_csr
+    N, S, M = 50_000, 486, 1_369_895
+    data = {"skill": zipf_csr(N, S, 1.37, 1), "member": zipf_csr(N, M, 5.53, 2), "table": np.random.default_rng(0).standard_normal((S, 128), dtype=np.float32)}
+    _fused_vs_generic([128, 128, M], libntf.INPUT_MEANPOOL, data, 1000, "uniform", 5)

@@ -196,3 +196,17 @@ def test_micro_auc_on_sparse_predictions_equals_sklearn_dense():
         assert abs(micro_auc_sparse(sp.lil_matrix(Y), S2) - ref) < 1e-12
     dense_auc, _ = calculate_auc_roc(sp.csr_matrix(Y), P)   # dense predictions keep the reference's sklearn route
     assert abs(dense_auc - ref) < 1e-12
+
+
+def test_tntf_interval_folds_match_the_reference_and_the_committed_splits():
+    """The per-interval K-fold of src/mdl/tntf.py:27-31: equal to what the reference's class wrote in its run here (g13) AND to the
+    `splits.pkl` files the reference's authors committed for their temporal Bnn run on toy dblp."""
+    from conftest import golden
+    from opentf_amd.mdl.tntf import interval_folds
+    g = golden("g13_tntf_dblp")
+    year_idx = [(int(a), int(b)) for a, b in g["i2y"]]
+    for i, (_, y) in enumerate(year_idx[:-1]):
+        for k, (tr, va) in enumerate(interval_folds(year_idx, i, 3, 0)):
+            assert np.array_equal(tr, g[f"{y}.train{k}"]) and np.array_equal(va, g[f"{y}.valid{k}"])
+            assert np.array_equal(tr, g[f"committed.{y}.train{k}"]) and np.array_equal(va, g[f"committed.{y}.valid{k}"])
+    assert np.array_equal(g["committed.2000.test"], np.arange(year_idx[-1][0], 31))
