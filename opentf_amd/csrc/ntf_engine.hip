@@ -73,7 +73,7 @@ struct ntf_engine {
     std::vector<TimeRec> recs;
     std::vector<hipEvent_t> pool;
     double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
-    int last_global_B = 0; int last_B = 0;
+    int last_global_B = 0; int last_B = 0; float last_dz_packed_scale = 0.f;
     bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
     // data-parallel pipelining: the output layer's dW kernel deferred by ntf_step_staged_deferred, launched by ntf_dw_chunk
     bool pend_valid = false; FusedDw pend; NormalSpec pend_eps_b; float pend_klw_b = 0.f; int pend_chunks = 0;
@@ -698,7 +698,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.s_out = sout_; f.s_out_inj = e->cfg.bayesian && (sout_.inj != nullptr || sin_.inj != nullptr);
             f.bf16x6 = e->cfg.mfma != NTF_MFMA_F32;   // default: bf16x6
             f.np = mfma_np(e); f.a_scale = dz_scale16(e, c.global_B); f.h_scale = kH16Scale; f.rflag = range_ptr(e);
-            if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale); }
+            f.dz_packed = f.bf16x6 && f.np == 2 && li.in == 128 && e->pl_mu != nullptr;   // the fp16x3 forward kernels (H = 128) store packed plane pairs
+            e->last_dz_packed_scale = f.dz_packed ? f.a_scale : 0.f;
+            if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale,
+                                                                                   f.dz_packed ? &sout_ : nullptr, f.s_out_inj); }
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
             if (c.defer_dw) {
                 const int tile = fused_dw_tile(), total = (M + tile - 1) / tile;
@@ -1025,7 +1028,15 @@ extern "C" int ntf_get_dlogits(ntf_engine* e, float* host, int64_t count) {
     const float* src = e->dZout;
     if (fused_ok(e)) {
         if (!e->Pbuf) DM(e, &e->Pbuf, (int64_t)e->cfg.max_batch * M);
-        launch_fused_probs_finish(e->st, B, e->layers[e->L - 1].in, M, e->fws, e->dZout, e->Pbuf, nullptr, 1.f, true);
+        // fp16x3 step: dzT holds packed plane pairs of dz * scale - unless that step fell back to the f32 kernels
+        float inv = 0.f;
+        if (e->last_dz_packed_scale > 0.f) {
+            int32_t raised = 0;
+            HIPCHK(e, hipMemcpyAsync(&raised, e->d_range, 4, hipMemcpyDeviceToHost, e->st));
+            HIPCHK(e, hipStreamSynchronize(e->st));
+            if (!raised) inv = 1.f / e->last_dz_packed_scale;
+        }
+        launch_fused_probs_finish(e->st, B, e->layers[e->L - 1].in, M, e->fws, e->dZout, e->Pbuf, nullptr, 1.f, true, inv);
         src = e->Pbuf;
     }
     HIPCHK(e, hipMemcpyAsync(host, src, (size_t)B * M * 4, hipMemcpyDeviceToHost, e->st));

@@ -52,6 +52,7 @@ struct FusedDw {
     float a_scale = 1.f, h_scale = 1.f;             // np = 2: exact power-of-two scales of dz (applied in the kernel) and of the h planes (applied by the producer)
     int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the expert tiles [wg_begin, wg_begin + wg_count) of fused_dw_tile() experts each
     int* rflag = nullptr;                           // fp16x3 range guard, see FusedOut
+    int dz_packed = 0;                              // np = 2, H = 128: dzT holds the forward kernel's packed fp16 plane pairs (see pack_planes)
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
 };
@@ -65,9 +66,12 @@ int64_t fused_planes_elems(int M, int H);   // uint16 elements of one matrix's s
 int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are padded to a multiple of it)
 // phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
-void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 3, float h_scale = 1.f);
+// s_out != null: also the transposed s_out sign words the packed fp16x3 dW kernel reads (k_sign_words_T)
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 3, float h_scale = 1.f, const SignSpec* s_out = nullptr, int s_out_inj = 0);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
 // after a probs pass: ent_rows[i] += scale * the pass's entropy terms (nullable); transpose: P [B, M] = PT^T
-void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws, const float* PT, float* P, float* ent_rows, float scale, bool transpose);
+// unpack_inv_scale > 0: PT holds packed fp16 plane pairs (the fp16x3 step's dzT): P = (hi + lo) * unpack_inv_scale
+void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws, const float* PT, float* P, float* ent_rows, float scale, bool transpose,
+                               float unpack_inv_scale = 0.f);
 
 }  // namespace ntf

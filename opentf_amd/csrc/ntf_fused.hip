@@ -16,6 +16,7 @@
 #include "ntf_fused.h"
 #include "ntf_device.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace ntf {
 
@@ -31,6 +32,15 @@ int fused_dw_tile() { return DW_TC; }
 int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 63) / 64 * 64 * H * 3; }   // rows padded to the 64-expert tile of k_out_fwd_h3w
 bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
 int fused_loss_slots(int) { return 0; }
+
+// Layout of dzT (d loss / d z of the output layer, the only dense [experts x batch] tensor of a step): tiles of DW_TC = 256 experts x 32 batch
+// rows, [expert tile][32-row K block][expert in tile][row in block].  The dW kernel consumes one K block of its expert tile per stage: one
+// contiguous 32 KiB piece, and a whole tile is a contiguous (Bpad / 32) * 32 KiB stream; the forward kernels' stores (32 rows = 128 B per expert)
+// fall in the same granules as in a plain [expert][Bpad] matrix.
+__host__ __device__ __forceinline__ int64_t dzt_index(int c, int i, int Bpad) {
+    return ((int64_t)(c >> 8) * (Bpad >> 5) + (i >> 5)) * 8192 + ((c & 255) << 5) + (i & 31);
+}
+__host__ __device__ __forceinline__ int64_t dzt_tile_base(int c0, int Bpad) { return (int64_t)(c0 >> 8) * (Bpad >> 5) * 8192 + ((c0 & 255) << 5); }   // floats
 
 struct Geom { int Bpad, NRB, T, NCG, nCB; };
 static Geom geom(int B, int M) {
@@ -48,7 +58,7 @@ static WsLayout ws_layout(int Bmax, int H, int M) {
     WsLayout w; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
     w.sbits = take((size_t)Bpad * nCB * 4);
-    w.sbitsT = take((size_t)nCB * 32 * (Bpad / 32) * 4);
+    w.sbitsT = take((size_t)rup(M, DW_TC) * (Bpad / 32) * 4);   // [expert tile of 256][K block of 32 rows][256 experts]: word = s_out signs of the 32 rows
     w.sinbits = take((size_t)Bpad * (H / 32) * 4);
     w.hs = take((size_t)Bpad * H * 4);
     w.hz = take((size_t)Bpad * H * 4);
@@ -263,9 +273,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
         uint32_t sw[2] = {0u, 0u};
         if (BAYES) { sw[0] = w2.x >> (4 * half); sw[1] = w2.y >> (4 * half); }
         // buffer descriptor over this tile's 64 rows of dzT (the tile base is wave-uniform; rows are Bpad floats)
-        const int dz_row_bytes = p.Bpad * 4;
-        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BN * dz_row_bytes, 0x00020000);
-        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
+        // this tile's experts inside their 256-expert dzT tile: base = block-uniform, the wave's 32-row K block and the lane in voffset
+        constexpr int dz_row_bytes = 128;
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
+        const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
         const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TB) + 4 * half;
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TB + 256) + 4 * half;
 
@@ -418,12 +429,15 @@ struct SpecialArgs {
     float tpw, tnw, inv_B;
     float *dzT, *dh, *row_fix;
     uint32_t so_k0, so_k1; int so_inj;
+    float dz_pack_scale;   // > 0: dzT holds packed fp16 plane pairs of dz * scale (fp16x3 step) ... unless *rflag is raised (the f32 kernels ran)
+    const int* rflag;
 };
 
 template <int H, bool BAYES, bool TRAIN, bool DH>
 __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
     constexpr int NM = (H + 63) / 64;
     const int i = blockIdx.x, lane = threadIdx.x;
+    const bool packed = p.dz_pack_scale > 0.f && !(p.rflag && *p.rflag);
     float rl = 0.f;
     for (int cg = lane; cg < p.NCG; cg += 64) rl += p.lossp[(int64_t)i * p.NCG + cg];
     rl = wave_reduce_sum(rl);
@@ -475,7 +489,10 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
         if (TRAIN) {
             const float dzt = p.tpw * (sg - y) * dact * p.inv_B;
             const float delta = dzt - p.tnw * sg * dact * p.inv_B;
-            if (lane == 0) p.dzT[(int64_t)c * p.Bpad + i] = dzt;
+            if (lane == 0) {
+                if (packed) { uint32_t pq[3]; split_pair_np<2>(dzt, 0.f, p.dz_pack_scale, pq); reinterpret_cast<uint32_t*>(p.dzT)[dzt_index(c, i, p.Bpad)] = (pq[0] & 0xFFFFu) | (pq[1] << 16); }
+                else p.dzT[dzt_index(c, i, p.Bpad)] = dzt;
+            }
             if (DH) {
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
@@ -517,6 +534,8 @@ struct DwArgs {
     float lr_over_bc1, b1, b2, eps, bc2_sqrt;
     int wg_begin;   // first expert tile of this launch (the expert range can be launched in chunks)
     int* rflag; int rmode;   // fp16x3 range guard, see OutFwdArgs
+    const uint32_t* sT;      // k_sign_words_T image (fp16x3 packed path)
+    int ablate;              // diagnostics (NTF_DW_ABLATE): 1 no epilogue memory traffic, 2 no MFMAs, 4 no DMA after the first K block, 8 no barrier waits on DMA
     const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
 };
@@ -576,7 +595,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
             const int inst = wave_u * (TA / 1024 / DW_WAVES) + n;
             const int row = inst * 8 + (lane >> 3), pch = lane & 7;
             const int q = pch ^ ((row >> 1) & 7);
-            glds16(p.dzT + (int64_t)(c0 + row) * p.Bpad + ib * KB + 4 * q, sb + inst * 1024);
+            glds16(p.dzT + ((int64_t)(c0 >> 8) * nib + ib) * 8192 + row * 32 + 4 * q, sb + inst * 1024);   // the K block of this tile: contiguous 32 KiB
         }
         constexpr int HI = TH / 1024;                           // wave-instructions per h tile (may be fewer than the waves)
 #pragma unroll
@@ -785,7 +804,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
             const int inst = wave_u * (TA / 1024 / DW_WAVES) + n;
             const int row = inst * 8 + (lane >> 3), pch = lane & 7;
             const int q = pch ^ ((row >> 1) & 7);
-            glds16(p.dzT + (int64_t)(c0 + row) * p.Bpad + ib * 32 + 4 * q, sb + inst * 1024);
+            glds16(p.dzT + ((int64_t)(c0 >> 8) * nib + ib) * 8192 + row * 32 + 4 * q, sb + inst * 1024);   // the K block of this tile: contiguous 32 KiB
         }
         const char* src = hb + (size_t)ib * TB;
         constexpr int NINST = TB / 1024;
@@ -858,18 +877,28 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
             if (hg + 1 < NHG) load_b(hg + 1, bq[(hg + 1) & 1]);
             asm volatile("" ::: "memory");   // keep the prefetch above this half-group's MFMAs
             const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
-            if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
+            if (p.ablate & 2) {   // scalar elements only: the host pass parses this body too
+                asm volatile("" :: "v"(bq[hg & 1][0][0]), "v"(bq[hg & 1][1][3]), "v"(a[ks][0][0]), "v"(a[ks][1][3]));
+                if (BAYES) asm volatile("" :: "v"(as[ks][0][0]), "v"(as[ks][1][3]));
+            }
+            else if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
             else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);   // before the first k-step-1 half-group; its vector work runs in the shadow of the following MFMAs
             // next K block: DMA issue + sign words in the middle of the MFMA phase, not in front of it — the two waves of a SIMD leave
             // every barrier in phase, and vector work bunched at the top of the iteration would meet the partner's vector work there
-            if (hg == (NP == 2 ? 0 : NHG / 2) && ib + 1 < nib) { stage(ib + 1, buf ^ 1); if (BAYES && !p.so_inj) word_next = sign_col_word(ib + 1); }   // fp16x3: the K block is short, give the DMA all of it
+            if (hg == (NP == 2 ? 0 : NHG / 2) && ib + 1 < nib) { if (!(p.ablate & 4)) stage(ib + 1, buf ^ 1); if (BAYES && !p.so_inj) word_next = sign_col_word(ib + 1); }   // fp16x3: the K block is short, give the DMA all of it
         }
         if (BAYES && p.so_inj && ib + 1 < nib) word_next = sign_col_word(ib + 1);   // injected signs (tests): a visible load, kept out of the MFMA phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next K block (DMA) has landed
         __syncthreads();
     }
 
+    if (p.ablate & 1) {   // keep the accumulators alive, touch no memory
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) { asm volatile("" :: "v"(acc1[jt][0]), "v"(acc1[jt][15])); asm volatile("" :: "v"(acc2[jt][0]), "v"(acc2[jt][15])); }
+        if (sum1 == 123.456f) p.g_b[0] = sum2;
+        return;
+    }
     // each half of the wave summed its 8 of every 16 batch rows
     sum1 += __shfl_xor(sum1, 32, 64);
     sum2 += __shfl_xor(sum2, 32, 64);
@@ -889,6 +918,190 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
                 const float w = p.wp[idx];
                 // sigma = log1p(e^rho), sigmoid(rho) = e^rho / (1 + e^rho) on the hardware exp2/log2/rcp (the library expf/log1pf cost more vector
                 // instructions here than the whole K loop); the short series keeps log1p accurate where 1 + e^rho rounds
+                const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
+                const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
+                const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
+                gm += p.klw * pm;
+                gr = (acc2[jt][r] * p.unscale) * (w * isig) * sg + p.klw * (sigma - isig) * sg;
+            } else if (ADAM) pm = p.w_mu[idx];
+            if (!ADAM) { p.g_mu[idx] = gm; if (BAYES) p.g_rho[idx] = gr; }
+            else {
+                float m = p.m_mu[idx], v = p.v_mu[idx];
+                p.w_mu[idx] = adam_update(pm, gm, m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                p.m_mu[idx] = m; p.v_mu[idx] = v;
+                if (BAYES) {
+                    float m2 = p.m_rho[idx], v2 = p.v_rho[idx];
+                    p.w_rho[idx] = adam_update(rh, gr, m2, v2, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                    p.m_rho[idx] = m2; p.v_rho[idx] = v2;
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// s_out sign words of the dW kernel: sT[expert tile of 256][K block][expert in tile], bit k = sign of (batch row 32 ib + k, expert) - the 32x32 bit
+// transposes of the row words (hash, or the packed image of injected signs), made once per step instead of once per K block inside the dW kernel
+__global__ __launch_bounds__(256) void k_sign_words_T(const uint32_t* __restrict__ sbits, int so_inj, uint32_t k0, uint32_t k1, int B, int nCB, int ncb_all, int nib,
+                                                      uint32_t* __restrict__ sT) {
+    const int lane = threadIdx.x & 63, il = lane & 31, half = lane >> 5;
+    const int cb = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half, ib = blockIdx.y;   // a half-wave per (32-expert block, K block)
+    const int i = ib * 32 + il;
+    uint32_t w = 0u;
+    if (cb < ncb_all && i < B) {
+        if (so_inj) { if (cb < nCB) w = sbits[(int64_t)i * nCB + cb]; }
+        else w = sign_word(k0, k1, (uint32_t)i, (uint32_t)cb);
+    }
+    w = transpose32(w, il);
+    const int c = cb * 32 + il;
+    if (cb < ncb_all) sT[((int64_t)(c >> 8) * nib + ib) * 256 + (c & 255)] = w;
+}
+
+// dW of the fp16x3 training step (H = 128).  Same tiling as k_out_dw_b6 (8 waves x 32 experts, K = batch in 32-row blocks, two LDS stages by LDS-DMA),
+// but the A operand arrives READY: dzT holds the two fp16 planes of dz * scale packed per element by the forward kernel, so a lane's fragment is two
+// ds_read_b128 + eight v_perm_b32 instead of an f32 split (the round-1 kernel spent a third of its time on that vector work: with MFMAs, DMA and
+// epilogue ablated it still took 0.20 of 0.63 ms); the s_out words come transposed from k_sign_words_T (one ds_read_b32 per K block instead of a
+// hash + five shuffle stages); the bias gradients are v_dot2_f32_f16 sums over the plane registers.
+template <bool BAYES, bool ADAM>
+__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = 128, NJT = 4, NP = 2;
+    constexpr int NPL = (BAYES ? 2 : 1) * NP;
+    constexpr int TA = DW_TC * 32 * 4;            // packed dz tile [256 experts][32 rows] dwords, 16-byte chunks XOR-swizzled ((row>>1)&7)
+    constexpr int PLANE = H * 64;                 // [H][32 rows] fp16
+    constexpr int TB = NPL * PLANE;
+    constexpr int TS = BAYES ? DW_TC * 4 : 0;     // s_out words of the tile's experts for this K block
+    constexpr int STAGE = TA + TB + TS;
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (range_guard_skip(p.rflag, p.rmode, false)) return;
+    const int c0 = (p.wg_begin + blockIdx.x) * DW_TC;
+    const int crow = wave * 32 + il;
+    const int c = c0 + crow;
+    const int nib = p.Bpad / 32;
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* hb = reinterpret_cast<const char*>(p.hb);
+
+    f32x16 acc1[NJT], acc2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
+    float sum1 = 0.f, sum2 = 0.f;
+    const h2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+
+    constexpr int NA = TA / 1024 / DW_WAVES, NB = (TB / 1024 + DW_WAVES - 1) / DW_WAVES;   // DMA pieces per wave: 4 of the dz tile, 2 or 4 of the planes
+    auto stage_piece = [&](int ib, int buf, int n) {      // piece n of this wave's NA + NB (+ the sign words with the last piece)
+        const uint32_t sb = smem_base + buf * STAGE;
+        if (n < NA) {
+            const float* src_a = p.dzT + ((int64_t)(c0 >> 8) * nib + ib) * 8192;   // contiguous 32 KiB
+            const int inst = wave_u * NA + n;
+            const int row = inst * 8 + (lane >> 3), pch = lane & 7;
+            const int q = pch ^ ((row >> 1) & 7);
+            glds16(src_a + row * 32 + 4 * q, sb + inst * 1024);
+        } else {
+            const char* src = hb + (size_t)ib * TB;
+            const int inst = wave_u * NB + (n - NA);
+            if (inst < TB / 1024) {
+                const int pos = inst * 1024 + lane * 16;
+                const int j = (pos % PLANE) >> 6, cd = (pos >> 4) & 3;
+                glds16(src + (pos & ~63) + 16 * (cd ^ ((j >> 2) & 3)), sb + TA + inst * 1024);
+            }
+            if (BAYES && n == NA + NB - 1 && wave_u == DW_WAVES - 1) glds16(p.sT + ((int64_t)(c0 >> 8) * nib + ib) * 256 + lane * 4, sb + TA + TB);
+        }
+    };
+    auto stage = [&](int ib, int buf) {
+#pragma unroll
+        for (int n = 0; n < NA + NB; ++n) stage_piece(ib, buf, n);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ib = 0; ib < nib; ++ib) {
+        const int buf = ib & 1;
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + TA;
+        uint32_t word = 0u;
+        if (BAYES) word = *reinterpret_cast<const uint32_t*>(sA + TA + TB + crow * 4);
+        constexpr int NHG = 2 * NJT * (BAYES ? 2 : 1);
+        const char* bbase = sB + il * 64;
+        const int swz = (il >> 2) & 3;
+        auto load_b = [&](int hg, u32x4 (&dst)[3]) {
+            const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
+            const char* bp = bbase + jt * 2048 + 16 * ((2 * ks + half) ^ swz) + which * NP * PLANE;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) dst[q] = *reinterpret_cast<const u32x4*>(bp + q * PLANE);
+        };
+        u32x4 a[2][3], as[2][3];
+        auto prep_a = [&](int ks) {      // rows 16 ks + 8 half .. + 7 of this lane's expert: 8 packed dwords -> the hi and the lo plane fragment
+            const int ch = 4 * ks + 2 * half, sw = (crow >> 1) & 7;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(sA + crow * 128 + 16 * (ch ^ sw));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(sA + crow * 128 + 16 * ((ch + 1) ^ sw));
+            const uint32_t x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const uint32_t w8 = word >> (ks * 16 + half * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t p1 = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x05040100u), p2 = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x07060302u);
+                a[ks][0][q] = p1; a[ks][1][q] = p2; a[ks][2][q] = 0u;
+                sum1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, p1), ones, sum1, false);
+                sum1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, p2), ones, sum1, false);
+                if (BAYES) {
+                    const uint32_t m = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+                    const uint32_t s1 = p1 ^ m, s2 = p2 ^ m;
+                    as[ks][0][q] = s1; as[ks][1][q] = s2; as[ks][2][q] = 0u;
+                    sum2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, s1), ones, sum2, false);
+                    sum2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, s2), ones, sum2, false);
+                }
+            }
+        };
+        u32x4 bq[2][3];
+        load_b(0, bq[0]);
+        prep_a(0);
+#pragma unroll
+        for (int hg = 0; hg < NHG; ++hg) {
+            if (hg + 1 < NHG) load_b(hg + 1, bq[(hg + 1) & 1]);
+            asm volatile("" ::: "memory");
+            const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT;
+            const int jt = g % NJT;
+            if (p.ablate & 2) {
+                asm volatile("" :: "v"(bq[hg & 1][0][0]), "v"(bq[hg & 1][1][3]), "v"(a[ks][0][0]), "v"(a[ks][1][3]));
+                if (BAYES) asm volatile("" :: "v"(as[ks][0][0]), "v"(as[ks][1][3]));
+            }
+            else if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
+            else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
+            if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);
+            // the next K block's DMA, one piece per half-group: a burst of 8-9 LDS-DMA issues in one gap stalls the wave's own MFMA stream
+            if (hg < NA + NB && ib + 1 < nib && !(p.ablate & 4)) { if (p.ablate & 16) { if (hg == 0) stage(ib + 1, buf ^ 1); } else stage_piece(ib + 1, buf ^ 1, hg); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (p.ablate & 1) {
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) { asm volatile("" :: "v"(acc1[jt][0]), "v"(acc1[jt][15])); asm volatile("" :: "v"(acc2[jt][0]), "v"(acc2[jt][15])); }
+        if (sum1 == 123.456f) p.g_b[0] = sum2;
+        return;
+    }
+
+    sum1 += __shfl_xor(sum1, 32, 64);
+    sum2 += __shfl_xor(sum2, 32, 64);
+    const float inv_a = 1.f / p.a_scale;
+    if (half == 0 && c < p.M) { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cr = c0 + wave * 32 + rowmap(r, half);
+        if (cr >= p.M) continue;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int64_t idx = (int64_t)cr * H + 32 * jt + il;
+            float gm = acc1[jt][r] * p.unscale, gr = 0.f, pm = 0.f, rh = 0.f;
+            if (BAYES) {
+                rh = ADAM ? p.w_rho[idx] : p.rho[idx];
+                pm = ADAM ? p.w_mu[idx] : p.mu[idx];
+                const float w = p.wp[idx];
                 const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
                 const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
                 const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
@@ -943,6 +1156,17 @@ struct OutFwd6Args {
     int plogit;                      // PROBS: store the logit leaky_relu(z) itself instead (ntf_logits: the quantity the 1e-4 parity bar is stated on)
     float h_scale, dz_scale, u_z, u_dh;   // fp16x3 (NP = 2): scales applied to h / dz before their split, and 1/(w scale * h scale), 1/(dz scale * w scale); 1 for bf16x6
 };
+// fp16x3 training step: dzT holds, per element, the two fp16 planes of dz * dz_scale packed in one dword (hi | lo << 16) - the split the forward
+// kernel makes anyway for its dh products - so that the dW kernel reads MFMA operands instead of splitting f32 values again
+__device__ __forceinline__ void pack_planes(uint32_t p_hi, uint32_t p_lo, uint32_t& d0, uint32_t& d1) {   // planes of an element pair -> the pair's dwords
+    d0 = __builtin_amdgcn_perm(p_lo, p_hi, 0x05040100u);
+    d1 = __builtin_amdgcn_perm(p_lo, p_hi, 0x07060302u);
+}
+__device__ __forceinline__ float unpack_planes(uint32_t d, float inv_scale) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = __builtin_bit_cast(h2_t, d);
+    return ((float)v[0] + (float)v[1]) * inv_scale;
+}
 
 // PROBS (inference, TRAIN = false): instead of the loss, the probabilities sigmoid(leaky_relu(z)) go (accumulated over the MC passes) to the
 // transposed buffer dzT [expert][batch], and lossp gets the row's entropy terms sum_c -p log(p + 1e-15) of this pass (src/mdl/fnn.py:196-208)
@@ -1059,9 +1283,9 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
 #pragma unroll
         for (int r = 0; r < 16; ++r) { X1[r] = 0.f; X2[r] = 0.f; }
         const uint32_t sbase = lds_addr(sb);
-        const int dz_row_bytes = p.Bpad * 4;
-        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BN6 * dz_row_bytes, 0x00020000);
-        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
+        constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
+        const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
         float pold[16];      // PROBS, later MC passes: the running sums of this tile, fetched under the zT products
         if (PROBS) {
 #pragma unroll
@@ -1121,13 +1345,23 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
             lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
             if (TRAIN) {
                 const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
+                if (NP != 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
                 X1[r] = dz;
             }
+        };
+        auto store_packed = [&](int r0, uint32_t p_hi, uint32_t p_lo) {   // NP == 2: registers r0, r0 + 1 as packed plane pairs
+            uint32_t d0, d1;
+            pack_planes(p_hi, p_lo, d0, d1);
+            __builtin_amdgcn_raw_buffer_store_b32(d0, dz_rsrc, dz_voff, ((r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(d1, dz_rsrc, dz_voff, (((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
         };
         if (!(TRAIN && DH)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) epilogue(r);
+            if (TRAIN && NP == 2) {
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 2) { uint32_t pq[3]; split_pair_np<2>(X1[r0], X1[r0 + 1], pp.dz_scale, pq); store_packed(r0, pq[0], pq[1]); }
+            }
         } else {
             // ---- dh += dz . mu_tile (+ (dz*s_out) . Wp_tile): the accumulator registers, split, are the A operand.  Only the first half of
             // the epilogue stands alone; the second half is spread over the MFMAs of the first k-step
@@ -1138,6 +1372,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
                     const int r0 = 8 * s2 + 2 * q;
                     split_pair_np<NP>(X1[r0], X1[r0 + 1], pp.dz_scale, pq);
                     ad[0][q] = pq[0]; ad[1][q] = pq[1]; ad[2][q] = pq[2];
+                    if (NP == 2) store_packed(r0, pq[0], pq[1]);
                     if (BAYES) {
                         const int c0r = (r0 & 3) + 8 * (r0 >> 2);   // registers r0, r0+1 are experts c0r, c0r+1 (+4*half, folded into sw)
                         const uint32_t m = (((sw << (31 - c0r)) & 0x80000000u) >> 16) | ((sw << (30 - c0r)) & 0x80000000u);
@@ -1322,9 +1557,9 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { X1[u][r] = 0.f; X2[u][r] = 0.f; }
         const uint32_t sw[2] = {w2.x >> (4 * half), w2.y >> (4 * half)};
-        const int dz_row_bytes = p.Bpad * 4;
-        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + (int64_t)c0 * p.Bpad, 0, BNT * dz_row_bytes, 0x00020000);
-        const int dz_voff = 4 * half * dz_row_bytes + 4 * i;
+        constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
+        const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
         const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
         const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
 
@@ -1360,15 +1595,17 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
             const float lc = fmaxf(l, -80.f);
             const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
             lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
-            const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
-            X1[u][r] = dz;
+            X1[u][r] = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);   // dz; stored as packed planes by split_pair_a
         };
         u32x4 ad[2][2][3];      // [u][k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
         auto split_pair_a = [&](int u, int r0) {   // registers r0, r0 + 1 (r0 even) of sub-tile u
             uint32_t pq[3];
             split_pair_np<NP>(X1[u][r0], X1[u][r0 + 1], pp.dz_scale, pq);
             ad[u][r0 >> 3][0][(r0 & 7) >> 1] = pq[0]; ad[u][r0 >> 3][1][(r0 & 7) >> 1] = pq[1];
+            uint32_t d0, d1;
+            pack_planes(pq[0], pq[1], d0, d1);
+            __builtin_amdgcn_raw_buffer_store_b32(d0, dz_rsrc, dz_voff, (32 * u + (r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(d1, dz_rsrc, dz_voff, (32 * u + ((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
         };
         auto signed_a = [&](int u, int s2, u32x4 (&o)[3]) {   // planes of dz * s_out
 #pragma unroll
@@ -1510,6 +1747,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.sbits = sbits; s.sinbits = sinbits; s.rows = f.rows; s.m_indptr = f.m_indptr; s.neg = f.neg; s.m_indices = f.m_indices;
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
+    s.dz_pack_scale = (f.train && f.bf16x6 && f.H == 128 && f.np == 2) ? f.dz_scale : 0.f; s.rflag = f.rflag;
     const int grid = g.NRB * g.NCG;
     if (f.bf16x6 && f.H == 128) {
         const int np = f.np == 2 ? 2 : 3;
@@ -1569,18 +1807,24 @@ __global__ void k_ent_slots(const float* __restrict__ lossp, int B, int NCG, flo
     for (int cg = 0; cg < NCG; ++cg) s += lossp[(int64_t)i * NCG + cg];
     ent[i] += s * scale;
 }
-__global__ __launch_bounds__(256) void k_transpose_pt(const float* __restrict__ PT, int M, int Bpad, int B, float* __restrict__ P) {
+__global__ __launch_bounds__(256) void k_transpose_pt(const float* __restrict__ PT, int M, int Bpad, int B, float* __restrict__ P, float unpack_inv_scale) {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, i0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) { const int c = c0 + r; tile[r][tx] = c < M ? PT[(int64_t)c * Bpad + i0 + tx] : 0.f; }
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        float v = 0.f;
+        if (c < M) { v = PT[dzt_index(c, i0 + tx, Bpad)]; if (unpack_inv_scale > 0.f) v = unpack_planes(__float_as_uint(v), unpack_inv_scale); }
+        tile[r][tx] = v;
+    }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) { const int i = i0 + r, c = c0 + tx; if (i < B && c < M) P[(int64_t)i * M + c] = tile[tx][r]; }
 }
-void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws_, const float* PT, float* P, float* ent_rows /*nullable: += this pass * scale*/, float scale, bool transpose) {
+void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws_, const float* PT, float* P, float* ent_rows /*nullable: += this pass * scale*/, float scale, bool transpose,
+                               float unpack_inv_scale) {
     const Geom g = geom(B, M);
     const WsLayout w = ws_layout(B, H, M);
     if (ent_rows) hipLaunchKernelGGL(k_ent_slots, dim3((B + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(static_cast<char*>(ws_) + w.lossp), B, g.NCG, scale, ent_rows);
-    if (transpose) hipLaunchKernelGGL(k_transpose_pt, dim3((M + 31) / 32, g.Bpad / 32), dim3(256), 0, st, PT, M, g.Bpad, B, P);
+    if (transpose) hipLaunchKernelGGL(k_transpose_pt, dim3((M + 31) / 32, g.Bpad / 32), dim3(256), 0, st, PT, M, g.Bpad, B, P, unpack_inv_scale);
 }
 
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
@@ -1600,8 +1844,20 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     if (grid <= 0) return;
     a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
     a.rflag = f.rflag; a.rmode = 0;
+    { static const int abl = getenv("NTF_DW_ABLATE") ? atoi(getenv("NTF_DW_ABLATE")) : 0; a.ablate = abl; }
     const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
-    if (f.bf16x6) {
+    a.sT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
+    if (f.bf16x6 && f.np == 2 && f.dz_packed) {   // fp16x3 step, H = 128: the forward kernel left packed plane pairs in dzT
+        a.a_scale = f.a_scale; a.unscale = 1.f / (f.a_scale * f.h_scale); a.rmode = guard ? 1 : 0;
+        const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0));
+#define NTF_DWP(BY, AD) do { auto kf = k_out_dw_p2<BY, AD>;                                                                    \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
+        if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
+#undef NTF_DWP
+        if (!guard) return;
+        a.rmode = 2;
+    } else if (f.bf16x6) {
         const int np = f.np == 2 ? 2 : 3;
         a.rmode = guard ? 1 : 0;
         a.a_scale = np == 2 ? f.a_scale : 1.f; a.unscale = np == 2 ? 1.f / (f.a_scale * f.h_scale) : 1.f;
@@ -1627,10 +1883,15 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
 }
 
 // bf16 split planes of the hidden activations for the dW kernel (once per step, after launch_fused_out_fwd's phase 1)
-void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws_, int np, float h_scale) {
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws_, int np, float h_scale, const SignSpec* s_out, int s_out_inj) {
     const Geom g = geom(B, M);
     const WsLayout w = ws_layout(B, H, M);
     char* ws = static_cast<char*>(ws_);
+    if (bayes && s_out) {   // packed fp16x3 path: the dW kernel's s_out words, transposed once
+        const int ncb_all = rup(M, DW_TC) / 32, nib = g.Bpad / 32;
+        hipLaunchKernelGGL(k_sign_words_T, dim3((ncb_all + 7) / 8, nib), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws + w.sbits), s_out_inj, s_out->k0, s_out->k1,
+                           B, g.nCB, ncb_all, nib, reinterpret_cast<uint32_t*>(ws + w.sbitsT));
+    }
     const int n = g.Bpad * H;
     hipLaunchKernelGGL(k_prep_planes_T, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(ws + w.hz), reinterpret_cast<const float*>(ws + w.hs),
                        bayes, g.Bpad, H, np == 2 ? 2 : 3, h_scale, reinterpret_cast<uint16_t*>(ws + w.hb));

@@ -33,3 +33,16 @@ def params_from(npz, prefix):
 def has_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+def draw_noise(sd, batch, generator=None):
+    """oracle.draw_flipout_noise for tests that INJECT the tensors into the engine.  bayesian-torch draws its signs as
+    `uniform_(-1, 1).sign()`, which is exactly 0 with probability 2^-24 per element (u = 0.5 of torch's 24-bit uniform): the perturbation
+    of that element is then dropped.  The engine's injection format is +1 / -1 (packed into bits by the fused kernels), so a drawn 0 is
+    replaced by +1 here - on both sides of the comparison, since the oracle computes with the returned tensors too."""
+    from oracle import ntf_oracle as O
+    noise = O.draw_flipout_noise(sd, batch, generator)
+    for n in noise:
+        for k in ("s_in", "s_out"):
+            n[k][n[k] == 0] = 1.0
+    return noise

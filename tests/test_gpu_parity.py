@@ -9,7 +9,7 @@ import pytest
 import scipy.sparse
 import torch
 
-from conftest import GOLDEN, golden, params_from
+from conftest import GOLDEN, golden, params_from, draw_noise
 from oracle import ntf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -124,7 +124,7 @@ def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
     rows = np.arange(B)
     opt = O.Adam(sd, 1e-3)
     for s in range(2):
-        noise = O.draw_flipout_noise(sd, B)
+        noise = draw_noise(sd, B)
         neg = O.ns_uniform(y, 5)
         inj = {"neg_idx": neg.numpy(), "eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise],
                "s_in": [n["s_in"] for n in noise], "s_out": [n["s_out"] for n in noise]}
@@ -163,7 +163,7 @@ def test_multihot_first_layer_step_vs_oracle(bayesian, S, H, M, B):
     rows = np.arange(B)
     opt = O.Adam(sd, 1e-3)
     for s in range(2):
-        noise = O.draw_flipout_noise(sd, B) if bayesian else None
+        noise = draw_noise(sd, B) if bayesian else None
         neg = O.ns_uniform(y, 5)
         inj = {"neg_idx": neg.numpy()}
         if bayesian:
@@ -233,7 +233,7 @@ def test_split_backward_equals_train_step():
     def mk():
         e = _engine([32, 32, 200], bayesian=True, max_batch=24, ns=3, nsd="uniform", fused=False)
         e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy())); return e
-    noise = O.draw_flipout_noise(sd, 24); neg = O.ns_uniform(y, 3)
+    noise = draw_noise(sd, 24); neg = O.ns_uniform(y, 3)
     def inj(sl):
         return {"neg_idx": neg.numpy()[sl], "eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise],
                 "s_in": [n["s_in"][sl] for n in noise], "s_out": [n["s_out"][sl] for n in noise]}
@@ -374,7 +374,7 @@ def test_native_flipout_matches_oracle_in_distribution():
     e = _engine([D, H, M], bayesian=True, max_batch=B, seed=11)
     e.load_state_dict(sd); e.set_dense_input(X.numpy())
     outs = np.stack([e.logits(np.arange(B)) for _ in range(400)])
-    ref = np.stack([O.bnn_forward(sd, X, O.draw_flipout_noise(sd, B)).numpy() for _ in range(400)])
+    ref = np.stack([O.bnn_forward(sd, X, draw_noise(sd, B)).numpy() for _ in range(400)])
     assert np.abs(outs.mean(0) - ref.mean(0)).max() < 6 * ref.std(0).max() / np.sqrt(400) + 1e-3
     assert abs(outs.std(0).mean() / ref.std(0).mean() - 1) < 0.1
 
@@ -384,7 +384,7 @@ def test_forward_probs_topk_and_uncertainty():
     sd, X, y = _bnn_case(32, [32], 700, 20, 4)
     e = _engine([32, 32, 700], bayesian=True, max_batch=20)
     e.load_state_dict(sd); e.set_dense_input(X.numpy())
-    noises = [O.draw_flipout_noise(sd, 20) for _ in range(3)]
+    noises = [draw_noise(sd, 20) for _ in range(3)]
     injs = [{"eps_w": [n["eps_w"] for n in nz], "eps_b": [n["eps_b"] for n in nz], "s_in": [n["s_in"] for n in nz],
              "s_out": [n["s_out"] for n in nz]} for nz in noises]
     mc = O.predict(sd, X, 3, noises).numpy()
@@ -416,7 +416,7 @@ def test_forward_probs_uncertainty_h128(bayesian, mfma):
         torch.manual_seed(2); sd = O.fnn_init(D, [128], M); nmc = 1
     e = _engine([D, 128, M], bayesian=bayesian, max_batch=B, mfma=mfma)
     e.load_state_dict(sd); e.set_dense_input(X.numpy())
-    noises = [O.draw_flipout_noise(sd, B) for _ in range(nmc)] if bayesian else None
+    noises = [draw_noise(sd, B) for _ in range(nmc)] if bayesian else None
     injs = [{"eps_w": [n["eps_w"] for n in nz], "eps_b": [n["eps_b"] for n in nz], "s_in": [n["s_in"] for n in nz],
              "s_out": [n["s_out"] for n in nz]} for nz in noises] if bayesian else None
     mc = O.predict(sd, X, nmc, noises).numpy()
