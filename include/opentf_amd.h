@@ -126,6 +126,9 @@ int ntf_eval_step(ntf_engine* e, const int64_t* rows, int32_t B, const ntf_injec
  * gradient buffer (sum over ranks = the single-process gradient); apply runs Adam. */
 int ntf_backward(ntf_engine* e, const int64_t* rows, int32_t B, int32_t global_B, const ntf_inject* inj, float* loss_out);
 int ntf_apply(ntf_engine* e);
+/* one Adam step restricted to n [lo, hi) float ranges of the flat buffers (lo_hi = 2n offsets, lo a multiple of 4): a data-parallel rank
+ * updates only the shard of the optimiser state it owns after a reduce-scatter of the gradients; parameters are then all-gathered */
+int ntf_apply_ranges(ntf_engine* e, const int64_t* lo_hi, int32_t n);
 /* whole phase without host round trips: `for batch in loader` of src/mdl/fnn.py:118 run natively.
  * order = n row ids in the order the loader yields them; mean of batch losses is returned (fnn.py:153). */
 int ntf_train_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, float* mean_loss);

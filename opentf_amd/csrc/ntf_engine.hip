@@ -817,6 +817,23 @@ static int apply_adam(ntf_engine* e) {
     return NTF_OK;
 }
 
+// Adam on the given [lo, hi) float ranges of the flat buffers only (one optimiser step: the step count advances once).  Data parallel with
+// sharded optimiser state: after a reduce-scatter every rank owns 1/G of each gradient range, updates that part, and the parameters are
+// all-gathered - the 28 B/parameter of Adam's traffic are paid once per node instead of once per GPU.
+static int apply_adam_ranges(ntf_engine* e, const int64_t* lo_hi, int n) {
+    Scope t(e, F_ADAM);
+    e->adam_t += 1;
+    e->adam_in_dw = false;
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - std::pow(b1, (double)e->adam_t), bc2 = 1.0 - std::pow(b2, (double)e->adam_t);
+    for (int k = 0; k < n; ++k) {
+        const int64_t lo = lo_hi[2 * k], hi = lo_hi[2 * k + 1];
+        if (lo < 0 || hi > e->n_params || lo > hi || (lo & 3)) FAIL(e, NTF_EINVAL, "apply_ranges: a range outside the flat buffers, reversed, or not 16-byte aligned");
+        if (hi > lo) launch_adam(e->st, e->P + lo, e->G + lo, e->M1 + lo, e->V2 + lo, hi - lo, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
+    }
+    return NTF_OK;
+}
+
 static int read_loss(ntf_engine* e, float* loss_out) {
     if (!loss_out) return NTF_OK;
     HIPCHK(e, hipMemcpyAsync(loss_out, e->d_loss, 4, hipMemcpyDeviceToHost, e->st));
@@ -864,6 +881,12 @@ extern "C" int ntf_apply(ntf_engine* e) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     return apply_adam(e);
+}
+
+extern "C" int ntf_apply_ranges(ntf_engine* e, const int64_t* lo_hi, int32_t n) {
+    if (!e || (n > 0 && !lo_hi) || n < 0) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    return apply_adam_ranges(e, lo_hi, n);
 }
 
 extern "C" int ntf_stage_order(ntf_engine* e, const int64_t* order, int64_t n) {

@@ -1,19 +1,28 @@
-"""Data parallelism over the GPUs of one node: one process per GPU, the global minibatch's rows split
-contiguously over ranks, gradient all-reduce (RCCL over xGMI through torch.distributed) per step.
+"""Data parallelism over the GPUs of one node: one process per GPU, the global minibatch's rows split contiguously over ranks,
+gradients exchanged over xGMI (RCCL through torch.distributed) once per step.
 
-The reference has no multi-GPU path (src/__config__.yaml:10 "TODO: multiple gpus"); semantics here are those of
-the single-process step on the GLOBAL minibatch (src/mdl/fnn.py:122-140): every rank's backward is scaled by
-1/global_B, so the SUM over ranks of the gradient buffers is the single-process gradient; the KL term is added
-in shares B_rank/global_B.
+The reference has no multi-GPU path (src/__config__.yaml:10 "TODO: multiple gpus"); semantics here are those of the
+single-process step on the GLOBAL minibatch (src/mdl/fnn.py:122-140): every rank's backward is scaled by 1/global_B, so the SUM
+over ranks of the gradient buffers is the single-process gradient; the KL term is added in shares B_rank/global_B.
 
-Overlap: the output layer holds >99 % of the parameters.  Its weight-gradient kernel is launched in expert chunks
-(`dw_chunk`), and the all-reduce of chunk k is issued asynchronously as soon as that chunk's kernel is queued, so
-that RCCL moves chunk k over xGMI while the GPU computes chunk k+1; the small remainder (hidden layers, biases)
-goes last.  All collectives of a step are waited for before Adam.
+Exchange, `shard_optimizer=True` (default when the engine offers `apply_ranges`):
+    reduce-scatter(gradients)  ->  Adam on the 1/G shard this rank owns  ->  all-gather(parameters)
+Every gradient range is cut into G equal parts (a remainder of < G*4 floats is all-reduced and updated by every rank).  Against
+all-reduce + replicated Adam this moves the same bytes over xGMI (reduce-scatter + all-gather = one ring all-reduce) but divides the
+optimiser's HBM traffic (28 B / parameter: 1.69 GB per step at BASELINE config 2) by G; Adam's moments of the other shards are
+never touched on this rank.  `shard_optimizer=False` keeps all-reduce + replicated Adam.
 
-The engine argument is duck-typed (`stage_order`, `step_staged`, `apply`, `grad_tensor`, `epoch_loss`, and
-optionally `step_staged_deferred` / `dw_chunks` / `dw_chunk_range` / `dw_chunk` / `rest_ranges`), which is what
-lets the world_size-2 gloo tests drive this logic on CPU with a stand-in engine.
+Overlap: the output layer holds >99 % of the parameters.  Its weight-gradient kernel is launched in expert chunks (`dw_chunk`), and
+the collective of chunk k is issued asynchronously as soon as that chunk's kernel is queued, so that RCCL moves chunk k over xGMI
+while the GPU computes chunk k+1; the small remainder (hidden layers, biases: ~1 MB) is all-reduced last and updated on every rank.
+All collectives of a step are waited for before Adam; the parameter all-gathers are waited for before the next step's first kernel.
+
+Stream contract: engine kernels and collectives are ordered through ONE stream - the caller runs under `torch.cuda.stream(s)` with
+the engine created on `s` (opentf_amd/mdl/fnn.py does); this is asserted at construction when the engine exposes its stream.
+
+The engine argument is duck-typed (`stage_order`, `step_staged`, `apply`, `grad_tensor`, `epoch_loss`, and optionally
+`step_staged_deferred` / `dw_chunks` / `dw_chunk_range` / `dw_chunk` / `rest_ranges` / `apply_ranges` / `param_tensor` /
+`skip_step`), which is what lets the world_size-2/3 gloo tests drive this logic on CPU with a stand-in engine.
 """
 from __future__ import annotations
 
@@ -23,6 +32,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+ALIGN = 4  # floats: shard boundaries stay 16-byte aligned (the Adam kernel's access width)
+
 
 def shard_bounds(global_B: int, world: int, rank: int):
     """Contiguous split of a global minibatch; sizes differ by at most one (first ranks get the extra row)."""
@@ -31,22 +42,67 @@ def shard_bounds(global_B: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_range(lo: int, hi: int, world: int):
+    """(part, tail_lo): [lo, lo + world*part) is cut into `world` equal, 16-byte aligned parts; [tail_lo, hi) is the remainder"""
+    part = ((hi - lo) // world) // ALIGN * ALIGN
+    return part, lo + world * part
+
+
+class _Done:
+    def wait(self): pass
+
+
 class DataParallel:
-    def __init__(self, engine, group=None, overlap=True):
+    def __init__(self, engine, group=None, overlap=True, shard_optimizer=None):
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._grad = engine.grad_tensor()  # flat view of the engine's gradient buffer (HBM; aliases, no copy)
-        # NTF_DP_FORCE_ALLREDUCE=1: run the collectives even at world_size 1 (exercises RCCL on the aliased buffer on a 1-GPU box)
+        # NTF_DP_FORCE_ALLREDUCE=1: run the collectives even at world_size 1 (exercises RCCL on the aliased buffers on a 1-GPU box)
         self.force_allreduce = dist.is_initialized() and os.environ.get("NTF_DP_FORCE_ALLREDUCE", "0") == "1"
         self.n_chunks = engine.dw_chunks() if (overlap and hasattr(engine, "dw_chunks")) else 0
         if self.n_chunks:
             self._chunk_ranges = [engine.dw_chunk_range(k) for k in range(self.n_chunks)]  # identical on every rank
             self._rest = engine.rest_ranges()
+        can_shard = hasattr(engine, "apply_ranges") and hasattr(engine, "param_tensor")
+        self.shard = can_shard if shard_optimizer is None else (bool(shard_optimizer) and can_shard)
+        self._param = engine.param_tensor() if self.shard else None
+        # gloo (the CPU tests) has no reduce-scatter: there it is an all-reduce of which this rank keeps its part - same result
+        self._native_rs = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._pending = []   # parameter all-gathers of the previous step
+        if self._grad.is_cuda and (self.world > 1 or self.force_allreduce) and hasattr(engine, "stream_handle"):
+            assert engine.stream_handle is not None and torch.cuda.current_stream().cuda_stream == engine.stream_handle, \
+                "DataParallel must run under torch.cuda.stream(s) with the engine created on s: kernels and collectives are ordered through that one stream"
 
-    def _reduce(self, lo, hi):
+    # ---- collectives on [lo, hi) of the flat buffers
+    def _all_reduce(self, lo, hi):
         return dist.all_reduce(self._grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _reduce_scatter(self, lo, hi, owned, works):
+        """sum over ranks of grad[lo:hi): this rank ends up with the reduced values of ITS part (and of the tail); records the part in
+        `owned`, the collectives in `works`"""
+        part, tail = shard_range(lo, hi, self.world)
+        if part:
+            mine = (lo + self.rank * part, lo + (self.rank + 1) * part)
+            if self._native_rs:
+                works.append(dist.reduce_scatter_tensor(self._grad[mine[0]:mine[1]], self._grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                works.append(self._all_reduce(lo, tail))
+            owned.append(mine)
+        if tail < hi:
+            works.append(self._all_reduce(tail, hi))
+            owned.append((tail, hi))       # every rank updates the few tail elements (replicated, identical)
+
+    def _all_gather(self, lo, hi):
+        part, tail = shard_range(lo, hi, self.world)
+        if not part:
+            return _Done()
+        mine = self._param[lo + self.rank * part: lo + (self.rank + 1) * part]
+        if self._native_rs:
+            return dist.all_gather_into_tensor(self._param[lo:tail], mine, group=self.group, async_op=True)
+        parts = [self._param[lo + r * part: lo + (r + 1) * part] for r in range(self.world)]
+        return dist.all_gather(parts, mine.clone(), group=self.group, async_op=True)
 
     def _skip(self, zero_grad=True):
         """this rank's shard of the global minibatch is empty (a last batch smaller than the world size): contribute a zero gradient and
@@ -56,10 +112,17 @@ class DataParallel:
         if hasattr(self.engine, "skip_step"):
             self.engine.skip_step()
 
+    def _finish_gathers(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
     def _train_step(self, goff, gB, lo, hi):
-        """backward of this rank's shard + gradient all-reduce + Adam for one global minibatch"""
+        """backward of this rank's shard of the batch + gradient exchange + Adam for one global minibatch"""
         e, have_rows = self.engine, hi > lo
-        works = []
+        self._finish_gathers()            # the parameters this step reads are complete
+        works, owned, gathered = [], [], []
+        reduce = (lambda a, b: self._reduce_scatter(a, b, owned, works)) if self.shard else (lambda a, b: works.append(self._all_reduce(a, b)))
         if self.n_chunks:
             if have_rows:
                 e.step_staged_deferred(goff + lo, hi - lo, goff, gB)
@@ -68,20 +131,25 @@ class DataParallel:
             for k, (ow, orr, cnt) in enumerate(self._chunk_ranges):
                 if have_rows:
                     e.dw_chunk(k)                     # queue chunk k's kernel ...
-                works.append(self._reduce(ow, ow + cnt))  # ... and let RCCL take its gradients as soon as it finishes
+                reduce(ow, ow + cnt); gathered.append((ow, ow + cnt))   # ... and let RCCL take its gradients as soon as it finishes
                 if orr >= 0:
-                    works.append(self._reduce(orr, orr + cnt))
-            for rlo, rhi in self._rest:
-                works.append(self._reduce(rlo, rhi))
+                    reduce(orr, orr + cnt); gathered.append((orr, orr + cnt))
+            for rlo, rhi in self._rest:               # hidden layers, biases: small, replicated update
+                works.append(self._all_reduce(rlo, rhi)); owned.append((rlo, rhi))
         else:
             if have_rows:
                 e.step_staged(goff + lo, hi - lo, global_offset=goff, global_B=gB, train=True, apply=False)
             else:
                 self._skip()
-            works.append(self._reduce(0, self._grad.numel()))
+            n = self._grad.numel()
+            reduce(0, n); gathered.append((0, n))
         for w in works:
             w.wait()
-        e.apply()
+        if not self.shard:
+            e.apply()
+            return
+        e.apply_ranges(sorted(owned))
+        self._pending = [self._all_gather(a, b) for a, b in gathered]
 
     def _phase(self, order, global_B, train):
         """One `for batch in loader` phase (src/mdl/fnn.py:118) over `order`; returns the mean batch loss."""
@@ -105,6 +173,7 @@ class DataParallel:
                 self.engine.step_staged(goff + lo, hi - lo, global_offset=goff, global_B=gB, train=False, apply=False)
             else:
                 self._skip(zero_grad=False)
+        self._finish_gathers()
         s, _ = self.engine.epoch_loss()  # sum over steps of this rank's share of each batch loss
         t = torch.tensor([s], dtype=torch.float64, device=self._grad.device if self._grad.is_cuda else "cpu")
         if self.world > 1:

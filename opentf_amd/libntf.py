@@ -62,6 +62,7 @@ SYMBOLS = {
     "ntf_eval_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_backward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "ntf_apply": (C.c_int, [_P]),
+    "ntf_apply_ranges": (C.c_int, [_P, _P, _I32]),
     "ntf_train_epoch": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "ntf_eval_epoch": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "ntf_epoch_loss": (C.c_int, [_P, _P, _P]),
@@ -146,6 +147,7 @@ class Engine:
         cfg.ns, cfg.nsd, cfg.tpw, cfg.tnw, cfg.lr, cfg.seed, cfg.fused = max(self.ns, 0), NSD[nsd], float(tpw), float(tnw), float(lr), int(seed) & (2**64 - 1), int(bool(fused))
         cfg.mfma = {None: 0, "default": 0, "f32": 1, "bf16x6": 2, "fp16x3": 3}[mfma] if not isinstance(mfma, int) or isinstance(mfma, bool) else int(mfma)
         cfg.fuse_adam = int(fuse_adam)  # 0: flat Adam kernel; 1: inside the dW epilogue; 2: chunked beside the dW kernel on a side stream
+        self.stream_handle = stream   # the caller's hipStream_t (int) the engine runs on, None: a stream of its own
         self._h = C.c_void_p()
         rc = lib().ntf_engine_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
@@ -302,6 +304,16 @@ class Engine:
 
     def apply(self):
         self._ck(lib().ntf_apply(self._h))
+
+    def apply_ranges(self, ranges):
+        """one Adam step on the [lo, hi) float ranges of the flat buffers only (sharded optimiser state, dp.py)"""
+        a = np.ascontiguousarray(np.asarray(ranges, dtype=np.int64).reshape(-1))
+        self._ck(lib().ntf_apply_ranges(self._h, _ptr(a), len(a) // 2))
+
+    def param_tensor(self):
+        """torch tensor aliasing the flat parameter buffer in HBM (what the sharded step all-gathers)"""
+        import torch
+        return torch.as_tensor(self.param_view(), device=f"cuda:{torch.cuda.current_device()}")
 
     def train_epoch(self, order, B):
         o = self._rows(order); loss = C.c_float()

@@ -19,15 +19,25 @@ class OracleEngine:
     """Same surface as libntf.Engine's staged API, CPU math from the oracle (test stand-in only)."""
 
     def __init__(self, sd, X, y, tpw, tnw, lr, bayesian_noise=None):
-        self.sd = OrderedDict((k, v.clone()) for k, v in sd.items())
+        # flat parameter buffer with the state_dict entries as views of it, like the engine's flat HBM buffers
+        self.keys = list(sd)
+        self.pflat = torch.cat([v.reshape(-1) for v in sd.values()]).clone()
+        self.sd, o = OrderedDict(), 0
+        for k, v in sd.items():
+            self.sd[k] = self.pflat[o:o + v.numel()].view_as(v); o += v.numel()
         self.X, self.y, self.tpw, self.tnw = X, y, tpw, tnw
-        self.opt = O.Adam(self.sd, lr)
-        self.keys = list(self.sd)
-        self.flat = torch.zeros(sum(v.numel() for v in self.sd.values()))
+        self.lr, self.t = lr, 0
+        self.m, self.v = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
+        self.flat = torch.zeros_like(self.pflat)
+        self.skipped = 0
         self.acc, self.steps, self.order = 0.0, 0, None
         self.noise = bayesian_noise  # dict global_offset -> per-layer noise for the GLOBAL batch (same eps on all ranks)
 
     def grad_tensor(self): return self.flat
+
+    def param_tensor(self): return self.pflat
+
+    def skip_step(self): self.skipped += 1
 
     def stage_order(self, order): self.order = np.asarray(order)
 
@@ -101,28 +111,36 @@ class OracleEngine:
         if orr >= 0: self.flat[orr:orr + cnt] = self._full[orr:orr + cnt]
 
     def apply(self):
-        grads, o = OrderedDict(), 0
-        for k in self.keys:
-            n = self.sd[k].numel(); grads[k] = self.flat[o:o + n].view_as(self.sd[k]).clone(); o += n
-        self.opt.step(self.sd, grads)
+        self.apply_ranges([(0, self.pflat.numel())])
+
+    def apply_ranges(self, ranges):
+        """torch.optim.Adam's update (oracle.Adam) on [lo, hi) ranges of the flat buffers; one optimiser step"""
+        self.t += 1
+        bc1, bc2 = 1 - 0.9 ** self.t, 1 - 0.999 ** self.t
+        for lo, hi in ranges:
+            assert lo % 4 == 0 and 0 <= lo <= hi <= self.pflat.numel()
+            g, m, v = self.flat[lo:hi], self.m[lo:hi], self.v[lo:hi]
+            m.mul_(0.9).add_(g, alpha=0.1)
+            v.mul_(0.999).addcmul_(g, g, value=0.001)
+            self.pflat[lo:hi].addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(1e-8), value=-self.lr / bc1)
 
 
-def _case(bayesian):
+def _case(bayesian, gB_override=None):
     torch.manual_seed(0)
     D, H, M, N = 12, [16], 40, 37
     sd = O.bnn_init(D, H, M) if bayesian else O.fnn_init(D, H, M)
     X = torch.randn(N, D)
     y = (torch.rand(N, M) < 0.1).float()
     order = torch.randperm(N).numpy()
-    gB = 10  # 37 rows -> batches of 10,10,10,7: the last one splits 4+3
+    gB = gB_override or 10  # 37 rows -> batches of 10,10,10,7: the last one splits 4+3 (gB 12: 12,12,12,1 -> an empty shard on the last batch)
     noise = None
     if bayesian:
         noise = {off: O.draw_flipout_noise(sd, min(gB, N - off)) for off in range(0, N, gB)}
     return sd, X, y, order, gB, noise
 
 
-def _single_process(bayesian):
-    sd, X, y, order, gB, noise = _case(bayesian)
+def _single_process(bayesian, gB_override=None):
+    sd, X, y, order, gB, noise = _case(bayesian, gB_override)
     sd = OrderedDict((k, v.clone()) for k, v in sd.items())
     opt = O.Adam(sd, 1e-2)
     losses = []
@@ -133,18 +151,27 @@ def _single_process(bayesian):
     return sd, float(np.mean(losses))
 
 
-def _worker(rank, world, port, bayesian, overlap, out):
+def _worker(rank, world, port, bayesian, overlap, out, shard=False, gB_override=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from opentf_amd.dp import DataParallel
-    sd, X, y, order, gB, noise = _case(bayesian)
+    sd, X, y, order, gB, noise = _case(bayesian, gB_override)
     eng = OracleEngine(sd, X, y, 10.0, 1.0, 1e-2, noise)
-    dp = DataParallel(eng, overlap=overlap)
-    assert dp.n_chunks == (OracleEngine.N_CHUNKS if overlap else 0)
+    dp = DataParallel(eng, overlap=overlap, shard_optimizer=shard)
+    assert dp.n_chunks == (OracleEngine.N_CHUNKS if overlap else 0) and dp.shard == shard
     mean_loss = dp.train_epoch(order, gB)
     eval_loss = dp.eval_epoch(order, gB)
+    if shard:   # the moments of the shards this rank does not own were never touched
+        owned = torch.zeros(eng.pflat.numel(), dtype=torch.bool)
+        owned[eng.m != 0] = True
+        frac = owned.float().mean().item()
+        assert frac < 1.0 / world + 0.35, frac
+    # every rank ends with the same, complete parameters (all-gather)
+    ref = eng.pflat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(ref, eng.pflat)
     if rank == 0:
-        out.put((mean_loss, eval_loss, {k: v.numpy() for k, v in eng.sd.items()}))
+        out.put((mean_loss, eval_loss, {k: v.numpy().copy() for k, v in eng.sd.items()}, eng.skipped))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -163,7 +190,7 @@ def test_two_rank_data_parallel_equals_single_process(bayesian, overlap):
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, bayesian, overlap, out)) for r in range(2)]
     for p in procs: p.start()
-    mean_loss, eval_loss, sd = out.get(timeout=120)
+    mean_loss, eval_loss, sd, _ = out.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -174,3 +201,31 @@ def test_two_rank_data_parallel_equals_single_process(bayesian, overlap):
     sd0, X, y, order, gB, noise = _case(bayesian)
     ev = [float(O.batch_loss(ref_sd, X[order[o:o + gB]], y[order[o:o + gB]], None, 10.0, 1.0, noise[o] if noise else None)) for o in range(0, len(order), gB)]
     assert abs(eval_loss - np.mean(ev)) <= 1e-4 * abs(np.mean(ev))
+
+
+@pytest.mark.parametrize("world,bayesian,overlap,gB", [(2, True, True, 10), (2, False, False, 10), (3, True, True, 10), (3, False, True, 12), (3, True, False, 12)])
+def test_sharded_optimizer_step_equals_single_process(world, bayesian, overlap, gB):
+    """reduce-scatter -> Adam on the owned 1/G shard -> all-gather of parameters at world sizes 2 and 3: uneven shards
+    (ranges not divisible by 3 leave a replicated tail), chunked and whole-buffer forms, and with gB = 12 a last batch of ONE row, i.e.
+    empty shards on two of three ranks (zero gradient + skip_step).  The trajectory must be the single-process one."""
+    ref_sd, ref_loss = _single_process(bayesian, gB)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bayesian, overlap, out, True, gB)) for r in range(world)]
+    for p in procs: p.start()
+    mean_loss, eval_loss, sd, skipped = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert abs(mean_loss - ref_loss) <= 1e-5 * abs(ref_loss)
+    for k in ref_sd:
+        np.testing.assert_allclose(sd[k], ref_sd[k].numpy(), rtol=2e-4, atol=1e-6)
+    assert skipped == 0   # rank 0 always has rows (the first ranks get the extra ones)
+
+
+def test_shard_range_properties():
+    from opentf_amd.dp import shard_range
+    for lo, hi, w in [(0, 100, 3), (64, 64 + 8_388_608, 8), (128, 128 + 4_738_688, 3), (0, 7, 2), (0, 0, 4), (256, 256 + 13, 5)]:
+        part, tail = shard_range(lo, hi, w)
+        assert part % 4 == 0 and tail == lo + w * part and lo <= tail <= hi and hi - tail < w * 4 + 4 * w

@@ -270,22 +270,24 @@ def test_pipelined_data_parallel_step_on_rccl_world1():
         stream = torch.cuda.Stream()
         results = []
         with torch.cuda.stream(stream):
-            for mode in ("plain", "pipelined"):
+            for mode in ("plain", "pipelined", "pipelined_allreduce"):
                 e = libntf.Engine([128, 128, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", seed=5,
                                   stream=stream.cuda_stream)
                 e.set_skill_table(table); e.set_skill_csr((s_ip, s_ix)); e.set_member((m_ip, m_ix)); e.load_state_dict(sd)
                 if mode == "plain":
                     loss = e.train_epoch(order, B)
                 else:
-                    dp = DataParallel(e)
-                    assert dp.force_allreduce and dp.n_chunks == 3 and len(dp._rest) == 3
+                    # default: reduce-scatter -> Adam on the owned shard -> all-gather of parameters; "_allreduce": all-reduce + replicated Adam
+                    dp = DataParallel(e, shard_optimizer=(mode == "pipelined"))
+                    assert dp.force_allreduce and dp.n_chunks == 3 and len(dp._rest) == 3 and dp.shard == (mode == "pipelined")
                     loss = dp.train_epoch(order, B)
                 results.append((loss, e.state_dict()))
                 e.close()
-        (la, pa), (lb, pb) = results
-        assert abs(la - lb) <= 1e-6 * abs(la)
-        for k in pa:
-            assert np.array_equal(pa[k], pb[k]), k
+        (la, pa) = results[0]
+        for lb, pb in results[1:]:
+            assert abs(la - lb) <= 1e-6 * abs(la)
+            for k in pa:
+                assert np.array_equal(pa[k], pb[k]), k
     finally:
         dist.destroy_process_group()
         os.environ.pop("NTF_DP_FORCE_ALLREDUCE", None)
