@@ -203,6 +203,24 @@ int ntf_skill_cooccurrence(int device, int64_t n_teams, int32_t n_members, int32
 int ntf_csr_result_fetch(ntf_csr_result* r, int64_t* indptr, int32_t* indices, uint8_t* data, double* device_ms);
 void ntf_csr_result_free(ntf_csr_result* r);
 
+/* ---- node2vec skill-embedding producer on the device                    src/mdl/emb/gnn.py:153-168 (model), 401-453 (_train_rw)
+ * torch_geometric.nn.Node2Vec with p = q = 1 as the reference configures it (src/mdl/emb/__config__.yaml:58-70): uniform random walks over
+ * a homogeneous CSR graph (rowptr [num_nodes+1] int64, col int32), windows of `context` nodes, negatives = start node + uniformly random
+ * nodes, loss = -mean log(sigmoid(<start, rest>) + 1e-15) - mean log(1 - sigmoid(.) + 1e-15), dense Adam on embedding.weight [num_nodes, d]
+ * (d in {64, 128, 192, 256}; init_weight = the nn.Embedding initial draw, supplied by the host so that a seed reproduces torch's).
+ * ntf_n2v_train_batch: one loader batch (gnn.py:416-419).  inj_pos / inj_neg non-NULL: the window rows [n, context] are given instead of
+ * generated (parity tests); apply = 0 leaves the gradient in place (ntf_n2v_get(what = 1)) and skips Adam.  walk_length counts NODES per
+ * walk (= cfg.wl, as Node2Vec's constructor takes it).  ntf_n2v_edge_bce: v_loss of gnn.py:420-431 before its second division. */
+typedef struct ntf_n2v ntf_n2v;
+int  ntf_n2v_create(int device, int64_t num_nodes, int32_t d, const int64_t* rowptr, const int32_t* col, const float* init_weight, uint64_t seed, ntf_n2v** out);
+void ntf_n2v_destroy(ntf_n2v* h);
+const char* ntf_n2v_last_error(const ntf_n2v* h);
+int  ntf_n2v_walks(ntf_n2v* h, const int64_t* start, int64_t n, int32_t walk_length, uint64_t step, int64_t* out_host /* [n, walk_length] */);
+int  ntf_n2v_train_batch(ntf_n2v* h, const int64_t* batch, int32_t B, int32_t walk_length, int32_t context, int32_t walks_per_node, int32_t num_neg, float lr,
+                         const int64_t* inj_pos, int64_t n_pos, const int64_t* inj_neg, int64_t n_neg, int32_t apply, float* loss_out);
+int  ntf_n2v_get(ntf_n2v* h, int what /* 0 embedding.weight, 1 gradient */, float* host /* [num_nodes, d] */);
+int  ntf_n2v_edge_bce(ntf_n2v* h, const int64_t* src, const int64_t* dst, int64_t n, float* mean_bce);
+
 /* device generators behind Flipout's eps / signs (dev_out = device pointers), for statistical tests */
 int ntf_k_fill_normal(void* stream, uint64_t seed, uint64_t step, int layer, int64_t n, float* dev_out);
 int ntf_k_fill_sign(void* stream, uint64_t seed, uint64_t step, int layer, int rows, int cols, float* dev_out);

@@ -86,6 +86,13 @@ SYMBOLS = {
     "ntf_skill_cooccurrence": (C.c_int, [C.c_int, _I64, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "ntf_csr_result_fetch": (C.c_int, [_P, _P, _P, _P, _P]),
     "ntf_csr_result_free": (None, [_P]),
+    "ntf_n2v_create": (C.c_int, [C.c_int, _I64, _I32, _P, _P, _P, _U64, C.POINTER(_P)]),
+    "ntf_n2v_destroy": (None, [_P]),
+    "ntf_n2v_last_error": (C.c_char_p, [_P]),
+    "ntf_n2v_walks": (C.c_int, [_P, _P, _I64, _I32, _U64, _P]),
+    "ntf_n2v_train_batch": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _I64, _P, _I64, _I32, _P]),
+    "ntf_n2v_get": (C.c_int, [_P, C.c_int, _P]),
+    "ntf_n2v_edge_bce": (C.c_int, [_P, _P, _P, _I64, _P]),
     "ntf_k_gemm_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
     "ntf_k_fill_normal": (C.c_int, [_P, _U64, _U64, C.c_int, _I64, _P]),
     "ntf_k_fill_sign": (C.c_int, [_P, _U64, _U64, C.c_int, C.c_int, C.c_int, _P]),
@@ -434,3 +441,62 @@ class Engine:
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); calls = (C.c_int64 * cap)()
         n = lib().ntf_kernel_times(self._h, int(enable), names, ms, calls, cap)
         return {names[i].decode(): (ms[i], calls[i]) for i in range(min(n, cap))}
+
+
+class Node2Vec:
+    """torch_geometric.nn.Node2Vec (p = q = 1) resident on one MI355X: embedding.weight [num_nodes, d] + dense Adam (include/opentf_amd.h)."""
+
+    def __init__(self, rowptr, col, init_weight, seed=0, device=0):
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int64); self.col = np.ascontiguousarray(col, dtype=np.int32)
+        w = _f32(init_weight)
+        self.num_nodes, self.d = w.shape
+        if len(self.rowptr) != self.num_nodes + 1:
+            raise NtfError("rowptr must have num_nodes + 1 entries")
+        self._h = C.c_void_p()
+        rc = lib().ntf_n2v_create(int(device), self.num_nodes, self.d, _ptr(self.rowptr), _ptr(self.col), _ptr(w), int(seed) & (2**64 - 1), C.byref(self._h))
+        if rc != 0:
+            msg = lib().ntf_n2v_last_error(None); self._h = None
+            raise NtfError(f"ntf_n2v_create failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise NtfError(f"libopentf_amd n2v error {rc}: {lib().ntf_n2v_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ntf_n2v_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+    def walks(self, start, walk_length, step=0):
+        s = np.ascontiguousarray(start, dtype=np.int64)
+        out = np.empty((len(s), int(walk_length)), dtype=np.int64)
+        self._ck(lib().ntf_n2v_walks(self._h, _ptr(s), len(s), int(walk_length), int(step), _ptr(out)))
+        return out
+
+    def train_batch(self, batch, walk_length, context, walks_per_node, num_neg, lr, apply=True, want_loss=True):
+        b = np.ascontiguousarray(batch, dtype=np.int64); loss = C.c_float()
+        self._ck(lib().ntf_n2v_train_batch(self._h, _ptr(b), len(b), int(walk_length), int(context), int(walks_per_node), int(num_neg), float(lr),
+                                           None, 0, None, 0, int(apply), C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def loss_on(self, pos_rw, neg_rw, lr=0.0, apply=False):
+        """loss (and gradient / Adam step) on GIVEN window rows [n, context]: Node2Vec.loss(pos_rw, neg_rw)"""
+        p = np.ascontiguousarray(pos_rw, dtype=np.int64); n = np.ascontiguousarray(neg_rw, dtype=np.int64); loss = C.c_float()
+        assert p.shape[1] == n.shape[1]
+        self._ck(lib().ntf_n2v_train_batch(self._h, None, 0, max(p.shape[1], 2), p.shape[1], 1, 1, float(lr), _ptr(p), len(p), _ptr(n), len(n), int(apply), C.byref(loss)))
+        return loss.value
+
+    def weight(self):
+        out = np.empty((self.num_nodes, self.d), dtype=np.float32)
+        self._ck(lib().ntf_n2v_get(self._h, 0, _ptr(out))); return out
+
+    def grad(self):
+        out = np.empty((self.num_nodes, self.d), dtype=np.float32)
+        self._ck(lib().ntf_n2v_get(self._h, 1, _ptr(out))); return out
+
+    def edge_bce(self, src, dst):
+        s = np.ascontiguousarray(src, dtype=np.int64); t = np.ascontiguousarray(dst, dtype=np.int64); out = C.c_float()
+        self._ck(lib().ntf_n2v_edge_bce(self._h, _ptr(s), _ptr(t), len(s), C.byref(out))); return out.value

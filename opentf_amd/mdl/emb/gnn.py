@@ -1,0 +1,168 @@
+"""`Gnn` with the node2vec method (`data.embedding.class_method=mdl.amd.emb.gnn.Gnn_n2v`): the reference's team2vec plugin
+(src/mdl/emb/gnn.py) for its random-walk branch, trained on the MI355X, and the bridge that puts the CSR gather of
+`get_dense_vecs` on the hot path of the UNMODIFIED caller.
+
+What the caller (src/main.py:100-153) does and what it gets here:
+  * `t2v = cls(output, acceleration, seed, cfg, method)`; `t2v.learn(teamsvecs, splits)`                       (main.py:112,122)
+      per fold: the 'stm' graph (skill - team - member) without the member-team edges of the test and of that fold's validation teams
+      (gnn.py:84-116), `torch_geometric.nn.Node2Vec` (p = q = 1) trained by `_train_rw` (gnn.py:401-453: shuffled node batches, Adam,
+      ReduceLROnPlateau on v_loss, EarlyStopping, `f{k}.pt` / `f{k}.e{e}.pt` checkpoints holding `embedding.weight`).  Here the walks,
+      the skip-gram loss, its gradient and the dense Adam run in `opentf_amd/csrc/ntf_n2v.hip`; control flow, file names and
+      checkpoint keys are the reference's.  An existing `f{k}.pt` (e.g. one the reference trained) is loaded instead, as gnn.py:402-405 does.
+  * `skill_vecs = t2v.get_dense_vecs(teamsvecs, vectype='skill')`                                                  (main.py:148)
+      the mean-pool `(skill @ E_skill) / skill.sum(1)` (gnn.py:484-486) by the gather kernel, returned as the dense [N, d] matrix the
+      caller stores in `teamsvecs['skill']` — AND `teamsvecs['skill_table'] = E_skill` is registered, so that the Fnn / Bnn plugin of this
+      package (opentf_amd/mdl/fnn.py) finds the table and runs the gather INSIDE every training step from `original_skill`
+      (which main.py:152 stores itself) instead of reading pre-pooled rows.
+
+Node ids of the homogeneous graph: [skills | members | teams].  (PyG's HeteroData orders the three blocks by Python set iteration, i.e.
+arbitrarily per process; consumers select by type, gnn.py:505-509, so the order is not part of the contract.)
+"""
+from __future__ import annotations
+
+import logging
+import os
+import re
+import time
+
+import numpy as np
+import scipy.sparse
+
+from ..earlystopping import EarlyStopping, PlateauLR
+from ..fnn import index_order, parse_devices
+from ..ntf import cfg_get, dist_rank, summary_writer
+from .t2v import T2v, gather_meanpool
+
+log = logging.getLogger(__name__)
+
+
+def _csr(mat):
+    m = scipy.sparse.csr_matrix(mat)
+    m.sort_indices()
+    return m.indptr.astype(np.int64), m.indices.astype(np.int64)
+
+
+def stm_graph(skill, member, drop_teams=()):
+    """(rowptr int64, col int32, offsets, num_nodes) of the undirected skill-team-member graph; member-team edges of `drop_teams` removed"""
+    s_ip, s_ix = _csr(skill)
+    m_ip, m_ix = _csr(member)
+    n_team, S, M = skill.shape[0], skill.shape[1], member.shape[1]
+    off = {"skill": 0, "member": S, "team": S + M}
+    n = S + M + n_team
+    team_of_s = np.repeat(np.arange(n_team, dtype=np.int64), np.diff(s_ip))
+    team_of_m = np.repeat(np.arange(n_team, dtype=np.int64), np.diff(m_ip))
+    keep = ~np.isin(team_of_m, np.asarray(list(drop_teams), dtype=np.int64))
+    src = np.concatenate([s_ix + off["skill"], m_ix[keep] + off["member"]])
+    dst = np.concatenate([team_of_s + off["team"], team_of_m[keep] + off["team"]])
+    a, b = np.concatenate([src, dst]), np.concatenate([dst, src])
+    order = np.lexsort((b, a))
+    a, b = a[order], b[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, a + 1, 1)
+    return np.cumsum(rowptr), b.astype(np.int32), off, n
+
+
+def member_team_edges(member, teams, off):
+    """homogeneous (member node, team node) pairs of the given teams, both directions (gnn.py:100-104,118-124)"""
+    sub = scipy.sparse.csr_matrix(member)[np.asarray(teams, dtype=np.int64)]
+    t = np.repeat(np.asarray(teams, dtype=np.int64), np.diff(sub.indptr)) + off["team"]
+    m = sub.indices.astype(np.int64) + off["member"]
+    return np.concatenate([m, t]), np.concatenate([t, m])
+
+
+class Gnn(T2v):
+    def __init__(self, output, device, seed, cfg, model):
+        super().__init__(output, device, seed, cfg, model)
+        if self.name != "n2v":
+            raise NotImplementedError(f"opentf_amd trains the node2vec table on the device; '{self.name}' stays the reference's mdl.emb.gnn.Gnn")
+        self.writer = summary_writer()
+        self.offsets = None
+
+    def _mcfg(self):
+        return cfg_get(self.cfg, self.name)
+
+    def _dirname(self):
+        m, g = self._mcfg(), cfg_get(self.cfg, "graph")
+        structure = cfg_get(g, "structure")
+        name = (f"/{self.name}.b{cfg_get(m, 'b')}.e{cfg_get(m, 'e')}.ns{cfg_get(m, 'ns')}.lr{cfg_get(m, 'lr')}.es{cfg_get(m, 'es')}.spe{cfg_get(m, 'spe')}"
+                f".d{cfg_get(m, 'd')}.{cfg_get(g, 'dup_edge')}.{structure[1]}")
+        name += ".pre" if cfg_get(g, "pre") else ""
+        return name + f".w{cfg_get(m, 'w')}.wl{cfg_get(m, 'wl')}.wn{cfg_get(m, 'wn')}"
+
+    def learn(self, teamsvecs, splits=None, time_indexes=None):
+        import torch
+        from ... import libntf
+        m = self._mcfg()
+        structure = cfg_get(cfg_get(self.cfg, "graph"), "structure")
+        if structure[1] != "stm":
+            raise NotImplementedError("only the skill-team-member ('stm') graph structure is built here")
+        self.output += self._dirname()
+        os.makedirs(self.output, exist_ok=True)
+        skill = teamsvecs.get("original_skill", teamsvecs["skill"]) if hasattr(teamsvecs, "get") else teamsvecs["skill"]
+        member = teamsvecs["member"]
+        d, b, lr = int(cfg_get(m, "d")), int(cfg_get(m, "b")), float(cfg_get(m, "lr"))
+        wl, ctx, wn, ns = int(cfg_get(m, "wl")), int(cfg_get(m, "w")), int(cfg_get(m, "wn")), int(cfg_get(m, "ns"))
+        spe = cfg_get(m, "spe")
+        w = None
+        for foldidx in splits["folds"].keys():
+            drop = np.concatenate([np.asarray(splits["test"]), np.asarray(splits["folds"][foldidx]["valid"])])
+            rowptr, col, off, n = stm_graph(skill, member, drop)
+            self.offsets = off
+            init = torch.nn.Embedding(n, d).weight.detach().numpy()       # the draw Node2Vec's constructor makes (gnn.py:153-160)
+            path = f"{self.output}/f{foldidx}.pt"
+            if os.path.exists(path):                                       # gnn.py:402-405: a trained table is loaded, not retrained
+                log.info(f"Loading the model {path} ...")
+                self.model = torch.load(path, map_location="cpu", weights_only=False)["model_state_dict"]["embedding.weight"].numpy()
+                continue
+            if w is None: w = self.writer(log_dir=f"{self.output}/logs4tboard/run_{int(time.time())}")
+            val_src, val_dst = member_team_edges(member, splits["folds"][foldidx]["valid"], off)
+            assert len(val_src), "Empty valid member-team edge set!"
+            net = libntf.Node2Vec(rowptr, col, init, seed=int(self.seed or 0) + 7919 * int(foldidx), device=parse_devices(self.device)[0])
+            scheduler = PlateauLR(lr, factor=0.1, patience=2)
+            earlystopping = EarlyStopping(patience=int(cfg_get(m, "es")), verbose=True, delta=0, trace_func=log.info)
+            cur_lr, e, t_loss, v_loss = lr, -1, 0.0, 0.0
+            for e in range(int(cfg_get(m, "e"))):
+                order = index_order(n, b, True)                            # DataLoader(range(num_nodes), batch_size=b, shuffle=True)
+                nb, t_loss = 0, 0.0
+                for o in range(0, n, b):
+                    t_loss += net.train_batch(order[o:o + b], wl, ctx, wn, ns, cur_lr); nb += 1
+                t_loss /= nb
+                v_loss = net.edge_bce(val_src, val_dst) / len(val_src)     # the reference divides the mean once more (gnn.py:433)
+                w.add_scalar(tag=f"{foldidx}_t_loss", scalar_value=t_loss, global_step=e)
+                w.add_scalar(tag=f"{foldidx}_v_loss", scalar_value=v_loss, global_step=e)
+                log.info(f"Fold {foldidx}/{len(splits['folds']) - 1}, Epoch {e}, Train Loss: {t_loss:.4f}, Valid Loss: {v_loss:.4f}")
+                if spe and (e == 0 or ((e + 1) % spe) == 0):
+                    self._save(net.weight(), foldidx, e, t_loss, v_loss, f"{self.output}/f{foldidx}.e{e}.pt")
+                cur_lr = scheduler.step(v_loss)
+                if earlystopping(v_loss, None).early_stop:
+                    log.info(f"Early stopping triggered at epoch: {e}")
+                    break
+            self.model = net.weight()
+            net.close()
+            self._save(self.model, foldidx, e, t_loss, v_loss, path)
+        if w is not None: w.close()
+
+    def _save(self, weight, foldidx, e, t_loss, v_loss, path):
+        import torch
+        if dist_rank() == 0:   # keys and order of gnn.py:445,453
+            torch.save({"model_state_dict": {"embedding.weight": torch.from_numpy(np.ascontiguousarray(weight))}, "cfg": self.cfg, "f": foldidx, "e": e,
+                        "t_loss": t_loss, "v_loss": v_loss}, path)
+
+    def _node_emb(self, teamsvecs, node_type):
+        if self.model is None:
+            raise RuntimeError("no trained table: call learn() first")
+        skill = teamsvecs.get("original_skill", teamsvecs["skill"]) if hasattr(teamsvecs, "get") else teamsvecs["skill"]
+        S, M = skill.shape[1], teamsvecs["member"].shape[1]
+        off = {"skill": (0, S), "member": (S, S + M), "team": (S + M, self.model.shape[0])}[node_type]
+        return self.model[off[0]:off[1]]
+
+    def get_dense_vecs(self, teamsvecs, vectype="skill"):
+        """gnn.py:484-486.  For 'skill' the table is also registered as teamsvecs['skill_table'] (see the module docstring)."""
+        if vectype not in ("skill", "member") or vectype not in teamsvecs:
+            return self._node_emb(teamsvecs, vectype)
+        table = np.ascontiguousarray(self._node_emb(teamsvecs, vectype), dtype=np.float32)
+        rows = teamsvecs.get("original_skill", teamsvecs[vectype]) if (vectype == "skill" and hasattr(teamsvecs, "get")) else teamsvecs[vectype]
+        dense = gather_meanpool(rows, table, self.device)
+        if vectype == "skill":
+            teamsvecs["skill_table"] = table
+        return dense

@@ -1,0 +1,170 @@
+"""node2vec producer on the MI355X (opentf_amd/csrc/ntf_n2v.hip through the C ABI): loss, gradient and Adam against the oracle on injected
+windows; the device walks' validity and uniformity; the whole `Gnn_n2v` plugin on toy dblp against the committed reference tables; and the
+caller sequence of src/main.py:100-177 (t2v.learn -> get_dense_vecs -> Fnn.learn) reaching the in-step CSR gather."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+import torch
+
+from conftest import golden
+from oracle import n2v_oracle as N
+
+pytestmark = pytest.mark.gpu
+
+
+class Cfg(dict):
+    def __getattr__(self, k):
+        if k.startswith("__"): raise AttributeError(k)
+        return self.get(k)
+
+
+def _toy():
+    toy = golden("toy_dblp")
+    n, S, M = [int(v) for v in toy["shape"]]
+    skill = scipy.sparse.csr_matrix((np.ones(len(toy["skill_indices"]), np.uint8), toy["skill_indices"], toy["skill_indptr"]), shape=(n, S)).tolil()
+    member = scipy.sparse.csr_matrix((np.ones(len(toy["member_indices"]), np.uint8), toy["member_indices"], toy["member_indptr"]), shape=(n, M)).tolil()
+    splits = {"test": toy["test"], "folds": {k: {"train": toy[f"train{k}"], "valid": toy[f"valid{k}"]} for k in range(3)}}
+    return toy, {"skill": skill, "member": member, "loc": None}, splits, n, S, M
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_loss_gradient_and_adam_match_the_oracle_on_injected_windows(d):
+    from opentf_amd.libntf import Node2Vec
+    toy, tv, sp, n, S, M = _toy()
+    rp, col, off, nn = N.build_graph_sized(toy["skill_indptr"], toy["skill_indices"], toy["member_indptr"], toy["member_indices"], S, M)
+    gen = torch.Generator().manual_seed(d)
+    W0 = (0.3 * torch.randn(nn, d, generator=gen))
+    pos = N.pos_sample(rp, col, torch.arange(nn), 6, 4, 4, gen)
+    neg = N.neg_sample(nn, torch.arange(nn), 6, 4, 4, 3, gen)
+    net = Node2Vec(rp, col, W0.numpy())
+    w = W0.clone().requires_grad_(True)
+    ref = N.loss(w, pos, neg); ref.backward()
+    got = net.loss_on(pos.numpy(), neg.numpy(), apply=False)
+    assert abs(got - float(ref.detach())) <= 2e-5 * abs(float(ref.detach()))
+    g = net.grad()
+    assert np.abs(g - w.grad.numpy()).max() <= 2e-5 * np.abs(w.grad.numpy()).max()
+    # three Adam steps on the same windows against torch.optim.Adam
+    emb = torch.nn.Parameter(W0.clone()); opt = torch.optim.Adam([emb], lr=0.01)
+    for _ in range(3):
+        opt.zero_grad(); N.loss(emb, pos, neg).backward(); opt.step()
+        net.loss_on(pos.numpy(), neg.numpy(), lr=0.01, apply=True)
+    np.testing.assert_allclose(net.weight(), emb.detach().numpy(), rtol=1e-4, atol=2e-5)
+    assert abs(net.edge_bce(pos[:, 0].numpy(), pos[:, 1].numpy()) - float(N.edge_bce(emb.detach(), pos[:, 0], pos[:, 1]))) < 1e-4
+
+
+def test_device_walks_follow_edges_uniformly_and_tile_the_batch():
+    from opentf_amd.libntf import Node2Vec
+    toy, tv, sp, n, S, M = _toy()
+    rp, col, off, nn = N.build_graph_sized(toy["skill_indptr"], toy["skill_indices"], toy["member_indptr"], toy["member_indices"], S, M, drop_teams=toy["test"])
+    net = Node2Vec(rp, col, np.zeros((nn, 64), np.float32), seed=3)
+    A = scipy.sparse.csr_matrix((np.ones(len(col)), col, rp), shape=(nn, nn)).toarray()
+    start = np.tile(np.arange(nn), 400)
+    rw = net.walks(start, 5, step=1)
+    assert rw.shape == (len(start), 5) and np.array_equal(rw[:, 0], start)
+    deg = np.diff(rp)
+    a, b = rw[:, :-1].ravel(), rw[:, 1:].ravel()
+    assert ((A[a, b] == 1) | ((a == b) & (deg[a] == 0))).all()            # every step is an edge; a node without neighbours stays
+    # first step from the best-connected node: uniform over its neighbours (chi-square, 400 walks x 4 steps give plenty)
+    v = int(np.argmax(deg))
+    nxt = b[a == v]
+    counts = np.array([(nxt == u).sum() for u in col[rp[v]:rp[v + 1]]])
+    exp = len(nxt) / deg[v]
+    assert len(nxt) > 50 * deg[v] and ((counts - exp) ** 2 / exp).sum() < 3 * deg[v] + 20
+    assert not np.array_equal(rw, net.walks(start, 5, step=2))             # steps are independent draws
+
+
+def test_gnn_n2v_plugin_on_toy_dblp_against_the_committed_reference_run(tmp_path):
+    """The reference's configuration of the committed tables (b1000 e100 ns5 lr0.001 es5 spe10 d128 w5 wl5 wn10, stm graph): same directory name,
+    same files and keys, and a training loss that ends at the committed level (7.06 - 7.51: N(0,1) rows of d = 128 barely move in 100 Adam steps
+    of 1e-3); the table keeps the scale of its initial draw, as the committed ones do."""
+    from opentf_amd.mdl.emb.gnn import Gnn
+    toy, tv, sp, n, S, M = _toy()
+    g = golden("g14_n2v_dblp")
+    cfg = Cfg(graph=Cfg(structure=[[["skill", "to", "team"], ["member", "to", "team"]], "stm"], dup_edge="add", pre=None),
+              n2v=Cfg(d=128, w=5, e=100, b=1000, lr=0.001, es=5, ns=5, spe=10, wl=5, wn=10, p=1.0, q=1.0))
+    t2v = Gnn(str(tmp_path), "cuda:0", 0, cfg, "n2v")
+    t2v.learn(tv, sp)
+    assert os.path.basename(t2v.output) == str(g["dirname"])
+    committed = [float(g[f"f{k}.t_loss"]) for k in range(3)]
+    ours = []
+    for k in range(3):
+        ck = torch.load(f"{t2v.output}/f{k}.pt", map_location="cpu", weights_only=False)
+        assert list(ck.keys()) == [str(x) for x in g[f"f{k}.keys"]] and list(ck["model_state_dict"].keys()) == ["embedding.weight"]
+        W = ck["model_state_dict"]["embedding.weight"].numpy()
+        assert W.shape == g[f"f{k}.embedding.weight"].shape and W.dtype == np.float32
+        assert abs(W.std() - g[f"f{k}.embedding.weight"].std()) < 0.05
+        ours.append(ck["t_loss"])
+        assert os.path.exists(f"{t2v.output}/f{k}.e0.pt") and os.path.exists(f"{t2v.output}/f{k}.e9.pt")
+    assert abs(np.mean(ours) - np.mean(committed)) < 0.6, (ours, committed)
+    # a second learn() loads the files instead of training (gnn.py:402-405)
+    stamp = os.path.getmtime(f"{t2v.output}/f0.pt")
+    t2 = Gnn(str(tmp_path), "cuda:0", 0, cfg, "n2v"); t2.learn(tv, sp)
+    assert os.path.getmtime(f"{t2v.output}/f0.pt") == stamp and np.array_equal(t2.model, t2v.model)
+
+
+def test_n2v_learns_structure_edge_reconstruction_auc():
+    """with a learning rate that lets the table move, the edges the walks traverse score far above random node pairs (AUC of <e_u, e_v>);
+    the initial table is at chance"""
+    from sklearn.metrics import roc_auc_score
+    from opentf_amd.libntf import Node2Vec
+    from opentf_amd.synth import zipf_csr
+    rng = np.random.default_rng(0)
+    n, S, M = 3000, 200, 400
+    s_ip, s_ix = zipf_csr(n, S, 3.0, 1); m_ip, m_ix = zipf_csr(n, M, 3.0, 2)
+    rp, col, off, nn = N.build_graph_sized(s_ip, s_ix, m_ip, m_ix, S, M)
+    W0 = rng.standard_normal((nn, 64)).astype(np.float32) * 0.1
+    net = Node2Vec(rp, col, W0, seed=1)
+    src = np.repeat(np.arange(nn), np.diff(rp)); pick = rng.choice(len(col), 4000, replace=False)
+    pos = np.stack([src[pick], col[pick]], 1)
+    neg = rng.integers(0, nn, (12000, 2))
+    def auc(W):
+        sc = lambda pr: np.einsum("ij,ij->i", W[pr[:, 0]], W[pr[:, 1]])
+        return roc_auc_score(np.r_[np.ones(len(pos)), np.zeros(len(neg))], np.r_[sc(pos), sc(neg)])
+    assert abs(auc(W0) - 0.5) < 0.05
+    losses = []
+    for e in range(12):
+        order = rng.permutation(nn); tot = 0.0
+        for o in range(0, nn, 1000): tot += net.train_batch(order[o:o + 1000], 5, 5, 10, 5, 0.01)
+        losses.append(tot)
+    assert losses[-1] < 0.8 * losses[0]
+    assert auc(net.weight()) > 0.85
+
+
+def test_main_py_sequence_reaches_the_in_step_gather(tmp_path):
+    """src/main.py:100-177 as the unmodified CLI runs it: t2v.learn -> skill_vecs = t2v.get_dense_vecs(teamsvecs) -> teamsvecs['original_skill'],
+    teamsvecs['skill'] = ... -> model.learn(teamsvecs, splits, None).  With Gnn_n2v of this package the Fnn plugin must end up in the
+    mean-pool (in-step CSR gather) input mode, and train exactly as from the pre-pooled dense matrix."""
+    from opentf_amd import libntf
+    from opentf_amd.mdl.emb.gnn import Gnn
+    from opentf_amd.mdl.fnn import Fnn
+    toy, teamsvecs, splits, n, S, M = _toy()
+    ecfg = Cfg(graph=Cfg(structure=[[["skill", "to", "team"], ["member", "to", "team"]], "stm"], dup_edge="add", pre=None),
+               n2v=Cfg(d=128, w=5, e=3, b=1000, lr=0.01, es=5, ns=5, spe=0, wl=5, wn=10, p=1.0, q=1.0))
+    t2v = Gnn(str(tmp_path / "split"), "cuda:0", 0, ecfg, "n2v")
+    t2v.learn(teamsvecs, splits)                                           # main.py:122
+    skill_vecs = t2v.get_dense_vecs(teamsvecs, vectype="skill")            # main.py:148
+    assert skill_vecs.shape[0] == teamsvecs["skill"].shape[0]              # main.py:149
+    teamsvecs["original_skill"] = teamsvecs["skill"]                       # main.py:152
+    teamsvecs["skill"] = skill_vecs                                        # main.py:153
+    ref = np.asarray((teamsvecs["original_skill"] @ teamsvecs["skill_table"]) / teamsvecs["original_skill"].sum(axis=1), dtype=np.float32)
+    np.testing.assert_allclose(skill_vecs, ref, rtol=1e-6, atol=1e-7)      # the reference expression, gnn.py:485
+    mcfg = Cfg(b=8, e=2, ns=0, lr=0.01, es=5, h=[32], spe=0, l="bce", tpw=10, tnw=1, nsd=None)
+    seen = {}
+    orig = libntf.Engine.__init__
+    def spy(self, dims, *a, **k):
+        seen["input_mode"] = k.get("input_mode"); seen["dims"] = list(dims)
+        return orig(self, dims, *a, **k)
+    libntf.Engine.__init__ = spy
+    try:
+        a = Fnn(t2v.output, "cuda:0", 3, mcfg); a.learn(teamsvecs, splits, None)       # main.py:172,177 (output_ = t2v.output)
+    finally:
+        libntf.Engine.__init__ = orig
+    assert seen["input_mode"] == libntf.INPUT_MEANPOOL and seen["dims"] == [128, 32, M]
+    dense_only = {k: v for k, v in teamsvecs.items() if k != "skill_table"}
+    b = Fnn(str(tmp_path / "dense"), "cuda:0", 3, mcfg); b.learn(dense_only, splits, None)
+    wa = torch.load(f"{a.output}/f1.pt", weights_only=False)["model_state_dict"]
+    wb = torch.load(f"{b.output}/f1.pt", weights_only=False)["model_state_dict"]
+    assert all(torch.equal(wa[k], wb[k]) for k in wa)

@@ -1,0 +1,69 @@
+"""node2vec producer, CPU side: the restatement of torch_geometric's Node2Vec (oracle/n2v_oracle.py) held to the tables and losses the
+reference's authors committed for toy dblp (g14), and the product's graph builder against the oracle's."""
+import numpy as np
+import pytest
+import scipy.sparse
+import torch
+
+from conftest import golden
+from oracle import n2v_oracle as N
+
+
+def _toy():
+    toy = golden("toy_dblp")
+    n, S, M = [int(v) for v in toy["shape"]]
+    return toy, n, S, M
+
+
+def test_stm_graph_matches_the_oracle_and_the_reference_node_counts():
+    from opentf_amd.mdl.emb.gnn import member_team_edges, stm_graph
+    toy, n, S, M = _toy()
+    skill = scipy.sparse.csr_matrix((np.ones(len(toy["skill_indices"])), toy["skill_indices"], toy["skill_indptr"]), shape=(n, S))
+    member = scipy.sparse.csr_matrix((np.ones(len(toy["member_indices"])), toy["member_indices"], toy["member_indptr"]), shape=(n, M))
+    drop = np.concatenate([toy["test"], toy["valid0"]])
+    rp, col, off, nn = stm_graph(skill, member, drop)
+    rp2, col2, off2, nn2 = N.build_graph_sized(toy["skill_indptr"], toy["skill_indices"], toy["member_indptr"], toy["member_indices"], S, M, drop)
+    assert nn == nn2 == golden("g14_n2v_dblp")["f0.embedding.weight"].shape[0] == S + M + n     # 54 nodes in the committed table
+    assert off == off2 and np.array_equal(rp, rp2) and np.array_equal(col, col2)
+    # undirected; no member-team edge of a dropped team; every skill-team edge kept
+    A = scipy.sparse.csr_matrix((np.ones(len(col)), col, rp), shape=(nn, nn))
+    assert (A != A.T).nnz == 0
+    for t in drop:
+        nb = col[rp[off["team"] + t]:rp[off["team"] + t + 1]]
+        assert (nb < off["member"]).all()
+    assert A[off["skill"]:off["member"]].nnz == len(toy["skill_indices"])
+    src, dst = member_team_edges(member, toy["valid0"], off)
+    assert len(src) == 2 * int(member[toy["valid0"]].nnz) and A[src, dst].sum() == 0
+
+
+def test_oracle_training_ends_at_the_committed_loss_level():
+    """The committed runs: b=1000 (one batch of all 54 nodes per epoch), 100 epochs, lr 0.001, ns 5, w 5, wl 5, wn 10, d 128 -> t_loss 7.06-7.51.
+    N(0,1) rows of d = 128 give dot products ~ N(0, 128): the loss starts near 2 * sqrt(128 / 2 pi) = 9 and 100 Adam steps of 1e-3 bring it to ~7;
+    a sum instead of a mean, a missing negative term, or walks that ignore the graph would all land elsewhere."""
+    toy, n, S, M = _toy()
+    g = golden("g14_n2v_dblp")
+    finals, firsts = [], []
+    for k in range(3):
+        drop = np.concatenate([toy["test"], toy[f"valid{k}"]])
+        rp, col, off, nn = N.build_graph_sized(toy["skill_indptr"], toy["skill_indices"], toy["member_indptr"], toy["member_indices"], S, M, drop)
+        W, hist = N.train(rp, col, nn, 128, 1000, 100, 0.001, 5, 5, 10, 5, seed=k)
+        finals.append(hist[-1]); firsts.append(hist[0])
+        # committed tables are still close to their N(0,1) draw: same scale of the rows
+        assert abs(float(W.std()) - float(g[f"f{k}.embedding.weight"].std())) < 0.05
+    committed = [float(g[f"f{k}.t_loss"]) for k in range(3)]
+    assert all(int(g[f"f{k}.e"]) == 99 for k in range(3))
+    assert abs(np.mean(finals) - np.mean(committed)) < 0.6, (finals, committed)
+    assert 8.0 < np.mean(firsts) < 10.5
+
+
+def test_oracle_sampling_shapes_and_walk_validity():
+    toy, n, S, M = _toy()
+    rp, col, off, nn = N.build_graph_sized(toy["skill_indptr"], toy["skill_indices"], toy["member_indptr"], toy["member_indices"], S, M)
+    gen = torch.Generator().manual_seed(0)
+    batch = torch.arange(nn)
+    pos = N.pos_sample(rp, col, batch, 6, 4, 3, gen)
+    neg = N.neg_sample(nn, batch, 6, 4, 3, 2, gen)
+    assert tuple(pos.shape) == (nn * 3 * 3, 4) and tuple(neg.shape) == (nn * 3 * 2 * 3, 4)       # 6 + 1 - 4 = 3 windows per walk
+    A = scipy.sparse.csr_matrix((np.ones(len(col)), col, rp), shape=(nn, nn)).toarray()
+    p = pos.numpy()
+    assert all(A[a, b] == 1 or a == b for row in p for a, b in zip(row[:-1], row[1:]))
