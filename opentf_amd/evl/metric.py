@@ -21,19 +21,22 @@ def _ptr(a):
 
 
 def _ranked_topk(Y_, k):
-    """[n, k] expert ids by decreasing score (stable: ascending id among equal scores), from a dense array or a scipy CSR."""
+    """[n, k] expert ids by decreasing score (stable: ascending id among equal scores), from a dense array or a scipy CSR.  Sparse input (the
+    top-K `.pred` files): ONE lexsort over all stored entries, no per-row Python work; only rows that store fewer than k entries (never the case
+    for files test() wrote with topK >= k) are completed one by one with the lowest-id unstored experts, which all score 0."""
     n = Y_.shape[0]
     if sp.issparse(Y_):
         Y_ = sp.csr_matrix(Y_)
+        cnt = np.diff(Y_.indptr)
+        rows = np.repeat(np.arange(n, dtype=np.int64), cnt)
+        order = np.lexsort((Y_.indices, -Y_.data, rows))                 # by row, then score descending, then expert id
+        pos = np.arange(len(order), dtype=np.int64) - np.repeat(Y_.indptr[:-1].astype(np.int64), cnt)   # rank inside the row
+        keep = pos < k
         out = np.zeros((n, k), dtype=np.int32)
-        for i in range(n):
-            cols, vals = Y_.indices[Y_.indptr[i]:Y_.indptr[i + 1]], Y_.data[Y_.indptr[i]:Y_.indptr[i + 1]]
-            order = np.lexsort((cols, -vals))[:k]
-            got = cols[order]
-            if len(got) < k:  # fewer stored entries than k: the remaining (zero-score) experts follow in id order
-                rest = np.setdiff1d(np.arange(Y_.shape[1], dtype=np.int64), cols, assume_unique=False)[: k - len(got)]
-                got = np.concatenate([got, rest])
-            out[i] = got
+        out[rows[keep], pos[keep]] = Y_.indices[order][keep]
+        for i in np.nonzero(cnt < k)[0]:
+            cols = Y_.indices[Y_.indptr[i]:Y_.indptr[i + 1]]
+            out[i, cnt[i]:] = np.setdiff1d(np.arange(Y_.shape[1], dtype=np.int64), cols)[: k - cnt[i]]
         return out
     Y_ = np.asarray(Y_)
     idx = np.argsort(-Y_, axis=1, kind="stable")[:, :k]
@@ -47,16 +50,22 @@ def _cutoffs(metrics, family):
     return []
 
 
-def calculate_metrics(Y, Y_, topK=None, per_instance=False, metrics=("P_2,5", "recall_2,5", "ndcg_cut_2,5"), device=0):
+def calculate_metrics(Y, Y_, topK=None, per_instance=False, metrics=("P_2,5", "recall_2,5", "ndcg_cut_2,5"), device=0, ranked=None):
+    """`ranked` [n, K] int32 (optional): the ranked expert ids themselves, e.g. `Engine.forward_topk`'s indices straight from the device; Y_ may
+    then be None - no prediction matrix, sparse or dense, is formed or sorted on the host."""
     import pandas as pd
     from .. import libntf
-    assert Y.shape == Y_.shape, f"Shape mismatch between truth Y {Y.shape} vs preds Y_ {Y_.shape}!"
+    assert ranked is not None or Y.shape == Y_.shape, f"Shape mismatch between truth Y {Y.shape} vs preds Y_ {Y_.shape}!"
     Y = sp.csr_matrix(Y); Y.sort_indices()
-    n, M = Y_.shape
+    n, M = Y.shape
     fams = [f for f in TREC if _cutoffs(metrics, f)]
     cuts = sorted({k for f in fams for k in _cutoffs(metrics, f)})
     kmax = min(max(cuts), min(topK, M) if topK else M)
-    top = _ranked_topk(Y_, kmax)
+    if ranked is not None:
+        top = np.ascontiguousarray(np.asarray(ranked)[:, :kmax], dtype=np.int32)
+        assert top.shape == (n, kmax), f"ranked ids {np.asarray(ranked).shape} cover fewer than the {kmax} ranks the cutoffs need"
+    else:
+        top = _ranked_topk(Y_, kmax)
     ip, ix = np.ascontiguousarray(Y.indptr, dtype=np.int64), np.ascontiguousarray(Y.indices, dtype=np.int32)
     cu = np.ascontiguousarray(cuts, dtype=np.int32)
     out = np.zeros((n, 5 * len(cuts)), dtype=np.float32)

@@ -48,3 +48,26 @@ def test_learn_test_evaluate_pipeline(tmp_path):
     agg = pd.read_csv(f"{m.output}/test.pred.eval.mean.csv", index_col=0)
     assert list(agg.columns) == ["mean", "std"]
     np.testing.assert_allclose(agg["mean"].values, pd.concat(fold_means, axis=1).mean(axis=1).values, rtol=1e-9)
+
+
+def test_device_topk_goes_straight_into_the_rank_metrics():
+    """`ntf_forward_topk`'s ranked ids fed to `ntf_rank_metrics` without a prediction matrix on the host (metric.calculate_metrics(ranked=...))
+    give the same table as the file route (sparse top-K matrix -> ranking on the host), and aucroc+ writes the curve the reference pickles."""
+    from opentf_amd import libntf
+    from opentf_amd.evl import metric
+    from opentf_amd.synth import init_params, zipf_csr
+    N, S, M, B, K = 400, 300, 5000, 256, 20
+    s_ip, s_ix = zipf_csr(N, S, 4.0, 1); m_ip, m_ix = zipf_csr(N, M, 3.0, 2)
+    e = libntf.Engine([S, 64, M], input_mode=libntf.INPUT_MULTIHOT, max_batch=B, ns=0, nsd=None)
+    e.set_skill_csr((s_ip, s_ix)); e.load_state_dict(init_params([S, 64, M], False, 1))
+    rows = np.arange(B)
+    vals, idx = e.forward_topk(rows, K)
+    Y = scipy.sparse.csr_matrix((np.ones(len(m_ix)), m_ix, m_ip), shape=(N, M))[rows]
+    names = ["P_2,5,10", "recall_2,5,10", "ndcg_cut_2,5,10", "map_cut_2,5,10", "success_2,5,10"]
+    df_a, mean_a = metric.calculate_metrics(Y, None, K, True, names, ranked=idx)
+    Y_ = scipy.sparse.csr_matrix((vals.ravel(), (np.repeat(rows, K), idx.ravel())), shape=(B, M))
+    df_b, mean_b = metric.calculate_metrics(Y, Y_, K, True, names)
+    assert np.array_equal(df_a.values, df_b.values) and np.array_equal(mean_a.values, mean_b.values)
+    auc, curve = metric.calculate_auc_roc(Y, Y_, curve=True)
+    auc2, none = metric.calculate_auc_roc(Y, Y_)
+    assert none is None and abs(auc - auc2) < 1e-12 and len(curve) == 2 and curve[0][0] == 0.0 and curve[1][-1] == 1.0
