@@ -335,6 +335,20 @@ extern "C" int ntf_set_unigram(ntf_engine* e, const double* freq, int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------ state
+// Multi-hot input: layer 0's weight-shaped segments (weight, rho_weight; parameters, gradients, Adam moments alike) live TRANSPOSED in HBM, [S, H]
+// instead of the reference's [H, S] (k_multihot_fwd / _bwd read and scatter whole rows).  Everything elementwise (Adam, Flipout operands, KL, the
+// all-reduce) is layout-blind; the host boundary transposes.
+static bool stored_transposed(const ntf_engine* e, int layer, int kind) {
+    return e->cfg.input_mode == NTF_INPUT_MULTIHOT && layer == 0 && (kind == NTF_P_WEIGHT || kind == NTF_P_RHO_WEIGHT);
+}
+static void transpose_host(const float* src, float* dst, int64_t rows, int64_t cols) {   // dst [cols, rows] = src [rows, cols]^T, blocked
+    constexpr int64_t T = 64;
+    for (int64_t r0 = 0; r0 < rows; r0 += T)
+        for (int64_t c0 = 0; c0 < cols; c0 += T)
+            for (int64_t r = r0; r < std::min(rows, r0 + T); ++r)
+                for (int64_t c = c0; c < std::min(cols, c0 + T); ++c) dst[c * rows + r] = src[r * cols + c];
+}
+
 static int param_span(ntf_engine* e, int layer, int kind, int64_t& off, int64_t& n) {
     if (layer < 0 || layer >= e->L || kind < 0 || kind > 3) FAIL(e, NTF_EINVAL, "param: bad layer/kind");
     if (kind >= 2 && !e->cfg.bayesian) FAIL(e, NTF_EINVAL, "param: rho on a non-bayesian model");
@@ -348,7 +362,20 @@ extern "C" int ntf_set_param(ntf_engine* e, int layer, int kind, const float* ho
     if (count != n) FAIL(e, NTF_EINVAL, "param: element count mismatch");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, hipStreamSynchronize(e->st));
+    if (stored_transposed(e, layer, kind)) {
+        std::vector<float> t((size_t)n);
+        transpose_host(host, t.data(), e->layers[0].out, e->layers[0].in);   // [H, S] -> [S, H]
+        HIPCHK(e, hipMemcpy(e->P + off, t.data(), n * 4, hipMemcpyHostToDevice));
+        return NTF_OK;
+    }
     HIPCHK(e, hipMemcpy(e->P + off, host, n * 4, hipMemcpyHostToDevice));
+    return NTF_OK;
+}
+static int fetch_segment(ntf_engine* e, const float* dev, int layer, int kind, float* host, int64_t n) {
+    if (!stored_transposed(e, layer, kind)) { HIPCHK(e, hipMemcpy(host, dev, n * 4, hipMemcpyDeviceToHost)); return NTF_OK; }
+    std::vector<float> t((size_t)n);
+    HIPCHK(e, hipMemcpy(t.data(), dev, n * 4, hipMemcpyDeviceToHost));
+    transpose_host(t.data(), host, e->layers[0].in, e->layers[0].out);       // [S, H] -> [H, S]
     return NTF_OK;
 }
 extern "C" int ntf_get_param(ntf_engine* e, int layer, int kind, float* host, int64_t count) {
@@ -357,8 +384,7 @@ extern "C" int ntf_get_param(ntf_engine* e, int layer, int kind, float* host, in
     if (count != n) FAIL(e, NTF_EINVAL, "param: element count mismatch");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, hipStreamSynchronize(e->st));
-    HIPCHK(e, hipMemcpy(host, e->P + off, n * 4, hipMemcpyDeviceToHost));
-    return NTF_OK;
+    return fetch_segment(e, e->P + off, layer, kind, host, n);
 }
 extern "C" int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int64_t count) {
     if (!e || !host) return NTF_EINVAL;
@@ -366,8 +392,7 @@ extern "C" int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int
     if (count != n) FAIL(e, NTF_EINVAL, "grad: element count mismatch");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, hipStreamSynchronize(e->st));
-    HIPCHK(e, hipMemcpy(host, e->G + off, n * 4, hipMemcpyDeviceToHost));
-    return NTF_OK;
+    return fetch_segment(e, e->G + off, layer, kind, host, n);
 }
 extern "C" int ntf_reset_optimizer(ntf_engine* e) {
     if (!e) return NTF_EINVAL;
@@ -478,7 +503,14 @@ static int stage_all_inj(ntf_engine* e, const StepCtx& c) {
     for (int l = 0; l < e->L; ++l) {
         const LayerInfo& li = e->layers[l];
         int r;
-        if (c.inj->eps_w[l] && (r = stage_inj(e, &e->inj_eps_w[l], c.inj->eps_w[l], li.nw()))) return r;
+        if (c.inj->eps_w[l]) {
+            if (stored_transposed(e, l, NTF_P_WEIGHT)) {   // the producer walks the stored [S, H] order: stage the injected [H, S] tensor transposed
+                std::vector<float> t((size_t)li.nw());
+                transpose_host(c.inj->eps_w[l], t.data(), li.out, li.in);
+                if ((r = stage_inj(e, &e->inj_eps_w[l], t.data(), li.nw()))) return r;
+                HIPCHK(e, hipStreamSynchronize(e->st));   // t goes out of scope
+            } else if ((r = stage_inj(e, &e->inj_eps_w[l], c.inj->eps_w[l], li.nw()))) return r;
+        }
         if (c.inj->eps_b[l] && (r = stage_inj(e, &e->inj_eps_b[l], c.inj->eps_b[l], li.out))) return r;
         if (c.inj->s_in[l]) { if (!e->inj_s_in[l]) DM(e, &e->inj_s_in[l], (int64_t)e->cfg.max_batch * li.in);
             HIPCHK(e, hipMemcpyAsync(e->inj_s_in[l], c.inj->s_in[l], (size_t)c.B * li.in * 4, hipMemcpyHostToDevice, e->st)); }

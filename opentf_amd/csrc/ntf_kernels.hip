@@ -193,7 +193,9 @@ void launch_gather_dense_rows(hipStream_t st, const float* X, int d, const int64
 }
 
 // Multi-hot input (src/mdl/ntf.py:23: the team's skill row densified to 0/1): the first layer x W^T is the SUM of the W columns
-// of the team's skills, so X is never materialised.  W is in the reference layout [H, S] (out x in); one thread per (row, h).
+// of the team's skills, so X is never materialised.  The engine keeps this layer's weight segments TRANSPOSED, [S, H] (in x out; the host boundary
+// transposes them back to the reference's [H, S]): the H threads of a team read one contiguous 4 H-byte row per skill instead of H values
+// S*4 bytes apart, and the gradient scatter below adds whole rows (the coalesced atomic form that runs at full rate).  One thread per (row, h).
 //   z = b + sum_s W[h,s]  (+ (sum_s s_in(i,s) Wp[h,s] + bp[h]) * s_out(i,h) for Flipout);   act = leaky_relu(z)
 __global__ void k_multihot_fwd(const int64_t* __restrict__ rows, int S, int H, const int64_t* __restrict__ indptr,
                                const int32_t* __restrict__ indices, const float* __restrict__ W, const float* __restrict__ b,
@@ -202,15 +204,13 @@ __global__ void k_multihot_fwd(const int64_t* __restrict__ rows, int S, int H, c
     const int i = blockIdx.x, h = blockIdx.y * blockDim.x + threadIdx.x;
     if (h >= H) return;
     const int64_t team = rows[i], p0 = indptr[team], p1 = indptr[team + 1];
-    const float* w = W + (int64_t)h * S;
     float z = b[h];
     if (Wp) {
-        const float* wp = Wp + (int64_t)h * S;
         float zp = 0.f;
-        for (int64_t p = p0; p < p1; ++p) { const int s = indices[p]; z += w[s]; zp += wp[s] * sign_at(sin, i, s); }
+        for (int64_t p = p0; p < p1; ++p) { const int64_t s = indices[p]; z += W[s * H + h]; zp += Wp[s * H + h] * sign_at(sin, i, s); }
         z += (zp + bp[h]) * sign_at(sout, i, h);
     } else {
-        for (int64_t p = p0; p < p1; ++p) z += w[indices[p]];
+        for (int64_t p = p0; p < p1; ++p) z += W[(int64_t)indices[p] * H + h];
     }
     act[(int64_t)i * H + h] = z > 0.f ? z : kLeakySlope * z;
 }
@@ -221,8 +221,8 @@ void launch_multihot_fwd(hipStream_t st, const int64_t* rows, int B, int S, int 
     hipLaunchKernelGGL(k_multihot_fwd, dim3((unsigned)B, (unsigned)((H + bs - 1) / bs)), dim3(bs), 0, st, rows, S, H, indptr, indices, W, b, Wp, bp,
                        sin, sout, act);
 }
-// its weight gradient is a scatter: gW[h,s] += dz[i,h] for every skill s of row i (gWp[h,s] += dz*s_out(i,h)*s_in(i,s)); gW/gWp zeroed by
-// the caller.  Hardware f32 atomics at L2: the per-element sums have at most (batch frequency of s) terms.
+// its weight gradient is a scatter: gW[s,h] += dz[i,h] for every skill s of row i (gWp[s,h] += dz*s_out(i,h)*s_in(i,s)), [S, H] like the weights;
+// gW/gWp zeroed by the caller.  Hardware f32 atomics: the per-element sums have at most (batch frequency of s) terms.
 __global__ void k_multihot_bwd(const int64_t* __restrict__ rows, int S, int H, const int64_t* __restrict__ indptr,
                                const int32_t* __restrict__ indices, const float* __restrict__ dZ, SignSpec sin, SignSpec sout,
                                float* __restrict__ gW, float* __restrict__ gWp) {
@@ -230,13 +230,11 @@ __global__ void k_multihot_bwd(const int64_t* __restrict__ rows, int S, int H, c
     if (h >= H) return;
     const int64_t team = rows[i], p0 = indptr[team], p1 = indptr[team + 1];
     const float dz = dZ[(int64_t)i * H + h];
-    float* g = gW + (int64_t)h * S;
     if (gWp) {
-        float* gp = gWp + (int64_t)h * S;
         const float dzs = dz * sign_at(sout, i, h);
-        for (int64_t p = p0; p < p1; ++p) { const int s = indices[p]; unsafeAtomicAdd(g + s, dz); unsafeAtomicAdd(gp + s, dzs * sign_at(sin, i, s)); }
+        for (int64_t p = p0; p < p1; ++p) { const int64_t s = indices[p]; unsafeAtomicAdd(gW + s * H + h, dz); unsafeAtomicAdd(gWp + s * H + h, dzs * sign_at(sin, i, s)); }
     } else {
-        for (int64_t p = p0; p < p1; ++p) unsafeAtomicAdd(g + indices[p], dz);
+        for (int64_t p = p0; p < p1; ++p) unsafeAtomicAdd(gW + (int64_t)indices[p] * H + h, dz);
     }
 }
 void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,

@@ -127,10 +127,10 @@ def test_n2v_learns_structure_edge_reconstruction_auc():
     losses = []
     for e in range(12):
         order = rng.permutation(nn); tot = 0.0
-        for o in range(0, nn, 1000): tot += net.train_batch(order[o:o + 1000], 5, 5, 10, 5, 0.01)
+        for o in range(0, nn, 1000): tot += net.train_batch(order[o:o + 1000], 5, 5, 10, 5, 0.05)
         losses.append(tot)
-    assert losses[-1] < 0.8 * losses[0]
-    assert auc(net.weight()) > 0.85
+    assert losses[-1] < 0.9 * losses[0]       # 5.5 -> 4.7 in the oracle's run of the same schedule (uniform negatives keep the floor high)
+    assert auc(net.weight()) > 0.95           # 0.99 there
 
 
 def test_main_py_sequence_reaches_the_in_step_gather(tmp_path):
