@@ -50,11 +50,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-bench", action="store_true", help="(default at N=1) also time the whole-dataset gather (get_dense_vecs)")
     ap.add_argument("--no-gather-bench", action="store_true")
+    ap.add_argument("--gather-only", action="store_true", help="run only the whole-dataset gather launches (the PMC passes of the gather roofline)")
+    ap.add_argument("--no-f32-line", action="store_true", help="skip the short exact-f32 (--mfma f32) measurement printed beside the default line")
     ap.add_argument("--force-dist", action="store_true", help="init RCCL and all-reduce the gradient buffer even at world_size 1 (validation)")
     return ap.parse_args()
 
 
-def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=5):
+def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
     """The oracle's reference-shaped step (dense [B, M] labels, rand_like+topk negatives, autograd, Adam) on the host."""
     import scipy.sparse
     import torch
@@ -90,7 +92,8 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=256, steps=5):
 def pmc_traffic(family, a, ds):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
     as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
-    path = os.path.join(ROOT, "profiles", {"f32": "r1_c_pmc_traffic_and_sq.json", "bf16x6": "r1_d_pmc_traffic_and_sq.json"}.get(a.mfma, "r1_e_pmc_traffic_and_sq.json"))
+    path = os.path.join(ROOT, "profiles", {"f32": "r1_c_pmc_traffic_and_sq.json", "bf16x6": "r1_d_pmc_traffic_and_sq.json"}.get(a.mfma, "r2_pmc_traffic_and_sq.json"))
+    if not os.path.exists(path): path = os.path.join(ROOT, "profiles", "r1_e_pmc_traffic_and_sq.json")
     if not (os.path.exists(path) and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
             and a.input == "meanpool" and not a.rows and not a.experts):
         return None
@@ -137,6 +140,11 @@ def main():
         e.load_state_dict(init_params(dims, bayesian, 0))
         if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
             e.set_unigram(np.bincount(ds["member"][1], minlength=ds["M"]) / ds["N"])
+        if a.gather_only:
+            for _ in range(5): e.gather_meanpool(n=ds["N"], to_host=False)
+            e.synchronize()
+            print(json.dumps({"gather_only": True, "teams": ds["N"]}), flush=True)
+            return
         dp = DataParallel(e)
         gB = a.batch * world                                   # weak scaling: B teams per GPU
         rng = np.random.default_rng(7)
@@ -168,12 +176,38 @@ def main():
             bytes_per_team = nnz * (4 * a.d + 4) + 8 + 4 * a.d
             gather = {"bound": "hbm", "achieved": bytes_per_team * n / (ms / calls * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "bytes_per_team": bytes_per_team, "teams": n, "ms": ms / calls}
+            # the roof of THIS kernel: its table rows are random reads of a 46 MB table, served on-die (MI355X_MICROARCH.md, Indexed rows: 8.6 TB/s for
+            # uniformly random rows of a 38 MB table out of the Infinity Cache); only the CSR and the output rows are compulsory HBM traffic (8 TB/s)
+            t_roof = n * nnz * 4 * a.d / 8.6e12 + (n * (4 * a.d + 8 + nnz * 4) + ds["S"] * a.d * 4) / (HBM_PEAK_GBS * 1e9)
+            gather["peak"] = bytes_per_team * n / t_roof / 1e9
+            gather["peak_def"] = "algorithmic bytes / (gathered table bytes / 8.6 TB/s on-die + (output + CSR + table once) / 8 TB/s HBM)"
             gather["frac"] = gather["achieved"] / gather["peak"]
+            pm = os.path.join(ROOT, "profiles", "r2_pmc_gather.json")
+            if os.path.exists(pm):
+                for name, v in json.load(open(pm))["kernels"].items():
+                    if "k_gather_pool" in name and "hbm_bytes" in v: gather["traffic"] = v["hbm_bytes"]
             # the algorithmic bytes count every gathered table row; the 46 MB table itself stays on-die (Infinity Cache / L2), so the compulsory
             # HBM traffic is the output rows + the CSR (+ the table once)
             comp = n * (4 * a.d + 8 + nnz * 4) + ds["S"] * a.d * 4
             gather["hbm_compulsory_gbs"] = comp / (ms / calls * 1e-3) / 1e9
-            gather["note"] = "achieved = algorithmic bytes (SURVEY 8d: nnz*(4d+4)+8+4d per team) / time; table rows are served on-die, hence > HBM peak"
+            gather["note"] = "achieved = algorithmic bytes (SURVEY 8d: nnz*(4d+4)+8+4d per team) / time; the table rows are served on-die, so the roof is not the HBM peak (peak_def)"
+
+    exact_f32 = None
+    if world == 1 and a.mfma == "default" and not a.no_f32_line and not a.no_fused:
+        # the same workload on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32, a bit-exact f32 fma chain): quoted beside the fp16x3 headline
+        with torch.cuda.stream(stream):
+            e.close()
+            e2 = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd,
+                               tpw=10.0, tnw=1.0, lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, mfma="f32")
+            if not multihot: e2.set_skill_table(ds["table"])
+            e2.set_skill_csr(ds["skill"]); e2.set_member(ds["member"]); e2.load_state_dict(init_params(dims, bayesian, 0))
+            if a.nsd == "unigram": e2.set_unigram(np.bincount(ds["member"][1], minlength=ds["M"]) / ds["N"])
+            k2 = max(5, min(20, a.steps))
+            e2.train_epoch(order[: 3 * gB], gB); e2.synchronize()
+            t1 = time.perf_counter(); e2.train_epoch(order[3 * gB: (3 + k2) * gB], gB); e2.synchronize()
+            dt2 = time.perf_counter() - t1
+            exact_f32 = {"value": k2 * gB / dt2, "unit": "teams/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2, "arithmetic": "--mfma f32: v_mfma_f32_32x32x2_f32 kernels"}
+            e2.close()
 
     if rank != 0:
         if world > 1: dist.destroy_process_group()
@@ -209,7 +243,7 @@ def main():
         "config": {"workload": f"{a.dataset} mt10.ts2 shapes N={ds['N']} S={ds['S']} M={M}; {a.model}{' (Flipout)' if bayesian else ''} on " +
                                (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
                                f"h=[{H}], b={B}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3", "global_batch": gB, "parallelism": f"dp{world}"},
-        "roofline": roof, "cpu_baseline": None, "mean_loss": mean_loss,
+        "roofline": roof, "cpu_baseline": None, "exact_f32_mfma": exact_f32, "mean_loss": mean_loss,
         "kernel_ms_per_step": {f: round(v[0] / a.steps, 4) for f, v in times.items() if v[1] > 0},
     }
     if gather: out["roofline_gather"] = gather

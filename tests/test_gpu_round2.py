@@ -336,3 +336,43 @@ def test_config5_gith_full_shape_fused_equals_generic():
     N, S, M = 50_000, 486, 1_369_895
     data = {"skill": zipf_csr(N, S, 1.37, 1), "member": zipf_csr(N, M, 5.53, 2), "table": np.random.default_rng(0).standard_normal((S, 128), dtype=np.float32)}
     _fused_vs_generic([128, 128, M], libntf.INPUT_MEANPOOL, data, 1000, "uniform", 5)
+
+
+# ------------------------------------------------------------------------------------------ the unfiltered dblp matrix (bench.py --dataset dblp_full)
+def test_dblp_full_unfiltered_shape_fused_equals_generic():
+    """`north_star`'s "full DBLP sparse matrix": M = 5 022 955 experts, S = 132 334 skills (output/dblp/dblp.v12.json/prep.teamsvecs.log:18), d = H = 128,
+    Bnn, B = 1000 - 1.29 G parameters, ~75 GB of HBM per engine.  Both engines are resident at once and are compared segment by segment, so that the
+    host never holds more than one copy of the parameters."""
+    import ctypes as C
+    import gc
+    from opentf_amd import libntf
+    from opentf_amd.synth import init_params, zipf_csr
+    N, S, M, B = 20_000, 132_334, 5_022_955, 1000
+    dims = [128, 128, M]
+    skill, member = zipf_csr(N, S, 8.57, 1), zipf_csr(N, M, 3.06, 2)
+    table = np.random.default_rng(0).standard_normal((S, 128), dtype=np.float32)
+    sd = init_params(dims, True, 0)
+    eng = []
+    for fused in (True, False):
+        e = libntf.Engine(dims, bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", seed=23, fused=fused)
+        e.set_skill_table(table); e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd)
+        eng.append(e)
+    del sd; gc.collect()
+    rows = np.random.default_rng(1).integers(0, N, B)
+    ev = [e.eval_step(rows) for e in eng]
+    for e in eng: e.set_seed(23, 0)
+    ls = [e.backward(rows) for e in eng]
+    assert abs(ev[0] - ev[1]) <= 1e-5 * abs(ev[1]) and abs(ls[0] - ls[1]) <= 1e-5 * abs(ls[1])
+    assert 0.6 * M < ls[0] < 0.8 * M
+    assert eng[0].range_fallbacks() == 0
+    for layer in (0, 1):
+        for name, kind in eng[0]._kinds():
+            shape = eng[0]._shape(layer, kind)
+            g = [np.empty(shape, np.float32) for _ in eng]
+            for e, a in zip(eng, g): e._ck(libntf.lib().ntf_get_grad(e._h, layer, kind, a.ctypes.data_as(C.c_void_p), a.size))
+            scale = float(np.abs(g[1]).max())
+            np.subtract(g[0], g[1], out=g[0]); np.abs(g[0], out=g[0])
+            assert int((g[0] > 2e-5 * scale).sum()) <= 64 * 128, (layer, name)      # leaky_relu' kink flips move one expert's row each
+            assert float(g[0].max()) <= 2e-2 * scale, (layer, name)
+            del g; gc.collect()
+    for e in eng: e.close()
