@@ -131,6 +131,17 @@ __device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// Row-loss accumulation over a column group (up to ~1.6e5 experts per lane at M = 5e6): the per-expert terms are nearly equal (softplus of a logit
+// near 0), so a plain f32 running sum rounds every add the SAME way once it is large (+0.3 % per term in one binade, -0.8 % in the next: measured
+// -335 ppm on the loss at M = 5 022 955).  Two levels: a tile's terms go to a fresh sum, the tile sums are added with compensation (Kahan).
+struct LossAcc {
+    float sum = 0.f, comp = 0.f, tile = 0.f;
+    __device__ __forceinline__ void end_tile() {
+        const float y = tile - comp, t = sum + y;
+        comp = (t - sum) - y; sum = t; tile = 0.f;
+    }
+};
+
 struct OutFwdArgs {
     int B, M, Bpad, NRB, NCG, T, nCB;
     const float *h, *hs, *mu, *mu_b, *wp, *bp;
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
     for (int j = 0; j < NJT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
-    float lsum = 0.f;
+    LossAcc lacc;
 
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
             const float l = pos ? z : z * kLeakySlope;
             const float lc = fmaxf(l, -80.f);
             const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
-            lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
+            lacc.tile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lacc.tile);
             if (TRAIN) {
                 const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
                 // dzT tile base in the buffer descriptor, lane part in voffset, register part as a scalar offset: no per-element address math
@@ -388,12 +399,14 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
         }
         // The next tile's DMA was issued before this tile's 32 dzT stores: wait until at most those stores are outstanding
         // (vmcnt counts loads, DMA and stores in issue order), not for the stores themselves, then a bare barrier.
+        lacc.end_tile();
         if (TRAIN) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
     // per-row loss partial of this column group
+    float lsum = lacc.sum;
     lsum += __shfl_xor(lsum, 32, 64);
     if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
 
@@ -539,6 +552,18 @@ struct DwArgs {
     const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
 };
+
+// N consecutive floats (N = 1, 2, 4) as one access
+template <int N> __device__ __forceinline__ void ld_vec(const float* p, float (&v)[N]) {
+    if (N == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[N > 1 ? 1 : 0] = t.y; v[N > 2 ? 2 : 0] = t.z; v[N > 3 ? 3 : 0] = t.w; }
+    else if (N == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[N > 1 ? 1 : 0] = t.y; }
+    else v[0] = p[0];
+}
+template <int N> __device__ __forceinline__ void st_vec(float* p, const float (&v)[N]) {
+    if (N == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[N > 1 ? 1 : 0], v[N > 2 ? 2 : 0], v[N > 3 ? 3 : 0]);
+    else if (N == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[N > 1 ? 1 : 0]);
+    else p[0] = v[0];
+}
 
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
     m = m + (1.f - b1) * (g - m);
@@ -757,11 +782,14 @@ __global__ void k_prep_planes_T(const float* __restrict__ hz, const float* __res
     const int r = t & 31, j = (t >> 5) % H, ib = t / (32 * H);
     const int npl = (bayes ? 2 : 1) * np;
     uint16_t* tile = hb + (size_t)ib * npl * H * 32;
+    // slot of hidden unit j in the image: column tile jt = j % NJT, lane il = j / NJT (NJT = H / 32).  The dW kernels read slot (jt, il) as the B column of
+    // lane il in tile jt, so a lane's NJT accumulators are NJT CONSECUTIVE hidden units: its epilogue moves 4 NJT-byte pieces, 32 lanes one whole row
+    const int njt = H >> 5, slot = 32 * (j % njt) + j / njt;
     for (int q = 0; q < (bayes ? 2 : 1); ++q) {
         const float x = (q ? hs : hz)[(int64_t)(ib * 32 + r) * H + j];
         uint32_t p[3];
         if (np == 3) split_pair_np<3>(x, 0.f, 1.f, p); else split_pair_np<2>(x, 0.f, scale, p);
-        for (int k = 0; k < np; ++k) tile[((q * np + k) * H + j) * 32 + r] = (uint16_t)p[k];
+        for (int k = 0; k < np; ++k) tile[((q * np + k) * H + slot) * 32 + r] = (uint16_t)p[k];
     }
 }
 
@@ -908,14 +936,19 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
     for (int r = 0; r < 16; ++r) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
         if (cr >= p.M) continue;
+        // lane il holds the NJT consecutive hidden units NJT*il .. (k_prep_planes_T's slot order): one vector access per array and row
+        float v_rho[NJT], v_mu[NJT], v_wp[NJT], o_mu[NJT], o_rho[NJT];
+        const int64_t idx0 = (int64_t)cr * H + NJT * il;
+        if (BAYES) { ld_vec<NJT>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<NJT>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<NJT>(p.wp + idx0, v_wp); }
+        else if (ADAM) ld_vec<NJT>(p.w_mu + idx0, v_mu);
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const int64_t idx = (int64_t)cr * H + 32 * jt + il;
+            const int64_t idx = idx0 + jt;
             float gm = acc1[jt][r] * p.unscale, gr = 0.f, pm = 0.f, rh = 0.f;   // unscale: 1 / (dz scale * h scale), 1 for bf16x6
             if (BAYES) {
-                rh = ADAM ? p.w_rho[idx] : p.rho[idx];
-                pm = ADAM ? p.w_mu[idx] : p.mu[idx];
-                const float w = p.wp[idx];
+                rh = v_rho[jt];
+                pm = v_mu[jt];
+                const float w = v_wp[jt];
                 // sigma = log1p(e^rho), sigmoid(rho) = e^rho / (1 + e^rho) on the hardware exp2/log2/rcp (the library expf/log1pf cost more vector
                 // instructions here than the whole K loop); the short series keeps log1p accurate where 1 + e^rho rounds
                 const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
@@ -923,9 +956,9 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
                 const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
                 gm += p.klw * pm;
                 gr = (acc2[jt][r] * p.unscale) * (w * isig) * sg + p.klw * (sigma - isig) * sg;
-            } else if (ADAM) pm = p.w_mu[idx];
-            if (!ADAM) { p.g_mu[idx] = gm; if (BAYES) p.g_rho[idx] = gr; }
-            else {
+            } else if (ADAM) pm = v_mu[jt];
+            o_mu[jt] = gm; o_rho[jt] = gr;
+            if (ADAM) {
                 float m = p.m_mu[idx], v = p.v_mu[idx];
                 p.w_mu[idx] = adam_update(pm, gm, m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
                 p.m_mu[idx] = m; p.v_mu[idx] = v;
@@ -936,6 +969,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
                 }
             }
         }
+        if (!ADAM) { st_vec<NJT>(p.g_mu + idx0, o_mu); if (BAYES) st_vec<NJT>(p.g_rho + idx0, o_rho); }
     }
 }
 
@@ -1094,22 +1128,26 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     for (int r = 0; r < 16; ++r) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
         if (cr >= p.M) continue;
+        float v_rho[NJT], v_mu[NJT], v_wp[NJT], o_mu[NJT], o_rho[NJT];      // NJT consecutive hidden units per lane, see k_out_dw_b6
+        const int64_t idx0 = (int64_t)cr * H + NJT * il;
+        if (BAYES) { ld_vec<NJT>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<NJT>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<NJT>(p.wp + idx0, v_wp); }
+        else if (ADAM) ld_vec<NJT>(p.w_mu + idx0, v_mu);
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const int64_t idx = (int64_t)cr * H + 32 * jt + il;
+            const int64_t idx = idx0 + jt;
             float gm = acc1[jt][r] * p.unscale, gr = 0.f, pm = 0.f, rh = 0.f;
             if (BAYES) {
-                rh = ADAM ? p.w_rho[idx] : p.rho[idx];
-                pm = ADAM ? p.w_mu[idx] : p.mu[idx];
-                const float w = p.wp[idx];
+                rh = v_rho[jt];
+                pm = v_mu[jt];
+                const float w = v_wp[jt];
                 const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
                 const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
                 const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
                 gm += p.klw * pm;
                 gr = (acc2[jt][r] * p.unscale) * (w * isig) * sg + p.klw * (sigma - isig) * sg;
-            } else if (ADAM) pm = p.w_mu[idx];
-            if (!ADAM) { p.g_mu[idx] = gm; if (BAYES) p.g_rho[idx] = gr; }
-            else {
+            } else if (ADAM) pm = v_mu[jt];
+            o_mu[jt] = gm; o_rho[jt] = gr;
+            if (ADAM) {
                 float m = p.m_mu[idx], v = p.v_mu[idx];
                 p.w_mu[idx] = adam_update(pm, gm, m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
                 p.m_mu[idx] = m; p.v_mu[idx] = v;
@@ -1120,6 +1158,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
                 }
             }
         }
+        if (!ADAM) { st_vec<NJT>(p.g_mu + idx0, o_mu); if (BAYES) st_vec<NJT>(p.g_rho + idx0, o_rho); }
     }
 }
 
@@ -1233,7 +1272,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
     for (int j = 0; j < NJT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
-    float lsum = 0.f;
+    LossAcc lacc;
 
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -1337,12 +1376,12 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
             const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
             if (PROBS) {
                 const float pr = __builtin_amdgcn_rcpf(tt) * rmask;       // experts past M: bias -1e30 -> tt = 1 + e^80 -> 0
-                lsum = fmaf(-pr * 0.6931471805599453f, __builtin_amdgcn_logf(pr + 1e-15f), lsum);
+                lacc.tile = fmaf(-pr * 0.6931471805599453f, __builtin_amdgcn_logf(pr + 1e-15f), lacc.tile);
                 const float o = pp.plogit ? l : fmaf(pr, pp.pscale, pold[r]);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
                 return;
             }
-            lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
+            lacc.tile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lacc.tile);
             if (TRAIN) {
                 const float dz = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
                 if (NP != 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dz_rsrc, dz_voff, cr * dz_row_bytes, 0);
@@ -1414,6 +1453,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
                 }
             }
         }
+        lacc.end_tile();
         if (TRAIN) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next tile's DMA is older than this tile's 16 dzT stores
         else if (DEEP && t + 2 < t_end) {   // tile t+1 has landed once only tile t+2's DMA (and, PROBS, this tile's 16 stores) are outstanding
             if (PROBS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + 16) : "memory");
@@ -1422,6 +1462,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
         __builtin_amdgcn_s_barrier();
     }
 
+    float lsum = lacc.sum;
     lsum += __shfl_xor(lsum, 32, 64);
     if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = PROBS ? lsum : p.tnw * lsum;
 
@@ -1509,7 +1550,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
     for (int j = 0; j < NJT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
-    float lsum = 0.f;
+    LossAcc lacc;
 
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -1594,7 +1635,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
             const float l = pos ? z : z * kLeakySlope;
             const float lc = fmaxf(l, -80.f);
             const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
-            lsum = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lsum);
+            lacc.tile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lacc.tile);
             X1[u][r] = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);   // dz; stored as packed planes by split_pair_a
         };
         u32x4 ad[2][2][3];      // [u][k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
@@ -1674,10 +1715,12 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
                 else d_mma(1, G - 2 * NHG - NGD, fb[b & 1][k]);
             }
         }
+        lacc.end_tile();
         asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // the next tile's DMA is older than this tile's 32 dzT stores
         __builtin_amdgcn_s_barrier();
     }
 
+    float lsum = lacc.sum;
     lsum += __shfl_xor(lsum, 32, 64);
     if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
 #pragma unroll

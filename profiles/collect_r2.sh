@@ -16,14 +16,14 @@ python3 $B --no-gather-bench --steps 30 --warmup 5 --input multihot --nsd unigra
 python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset uspt --d 256 > $O/bench_n1_config4_uspt_d256.json 2>> $O/bench.err
 python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset gith > $O/bench_n1_config5_gith.json 2>> $O/bench.err
 # kernel trace + stats of the default run
-rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $B --steps 20 --warmup 3 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --steps 20 --warmup 3 > $O/stats.log 2>&1
 # PMC passes (each on its own, no tracing)
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/pmc_sq -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_sq.log 2>&1
 # the whole-dataset gather launch on its own
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_gather_fetch -- python3 $B --gather-only > $O/pmc_gather_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_gather_write -- python3 $B --gather-only > $O/pmc_gather_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_gather_fetch -- python3 $B --gather-only > $O/pmc_gather_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_gather_write -- python3 $B --gather-only > $O/pmc_gather_write.log 2>&1
 # keep what is small: stats csv + counter csvs
-find $O -name "*.db" -delete 2>/dev/null
+find $O -name "*.db" -delete 2>/dev/null; find $O -name "*_agent_info.csv" -delete 2>/dev/null
 du -sh $O | tail -1
