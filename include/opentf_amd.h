@@ -173,7 +173,9 @@ int ntf_grad_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
 int ntf_param_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
 int ntf_synchronize(ntf_engine* e);
 /* HIP-event timing of the kernels launched by the engine since the last reset, by kernel family:
- * names[i] (static strings), ms[i] total, calls[i].  Returns the number of families (<= cap). */
+ * names[i] (static strings), ms[i] total, calls[i].  Returns the number of families (<= cap).
+ * enable: 0 off, 1 every family (two event records around each of ~15 scopes per step), 2 only the output layer's two MFMA kernels
+ * (what a roofline needs; keeps the timed region of a benchmark free of the other families' event records) */
 int ntf_kernel_times(ntf_engine* e, int enable, const char** names, double* ms, int64_t* calls, int cap);
 
 /* ---- stateless kernels on caller-owned device memory (used by tests and micro-benchmarks) */

@@ -69,7 +69,7 @@ struct ntf_engine {
     uint64_t seed = 0, step = 0;
     int maxhid = 0;
     // timing
-    bool timing = false;
+    int timing = 0;                   // 0 off, 1 every kernel family, 2 only the output layer's two MFMA kernels (the roofline's kernels)
     std::vector<TimeRec> recs;
     std::vector<hipEvent_t> pool;
     double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
@@ -97,14 +97,15 @@ struct ntf_engine {
 
 struct Scope {
     ntf_engine* e; int fam; hipEvent_t a = nullptr, b = nullptr;
+    bool on() const { return e->timing == 1 || (e->timing == 2 && (fam == F_OUT_FUSED_FWD || fam == F_OUT_FUSED_DW || fam == F_OUT_FWD || fam == F_OUT_BWD_DW)); }
     Scope(ntf_engine* e_, int f) : e(e_), fam(f) {
-        if (!e->timing) return;
+        if (!on()) return;
         auto get = [&]() { hipEvent_t ev; if (!e->pool.empty()) { ev = e->pool.back(); e->pool.pop_back(); } else hipEventCreate(&ev); return ev; };
         a = get(); b = get();
         hipEventRecord(a, e->st);
     }
     ~Scope() {
-        if (!e->timing) return;
+        if (!on()) return;
         hipEventRecord(b, e->st);
         e->recs.push_back({fam, a, b});
     }
@@ -1250,7 +1251,7 @@ extern "C" int ntf_kernel_times(ntf_engine* e, int enable, const char** names, d
     int n = std::min(cap, (int)F_COUNT);
     for (int i = 0; i < n; ++i) { if (names) names[i] = kFamNames[i]; if (ms) ms[i] = e->fam_ms[i]; if (calls) calls[i] = e->fam_calls[i]; }
     for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_calls[i] = 0; }
-    e->timing = enable != 0;
+    e->timing = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return F_COUNT;
 }
 

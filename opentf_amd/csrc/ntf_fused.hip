@@ -980,16 +980,19 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
 __global__ __launch_bounds__(256) void k_sign_words_T(const uint32_t* __restrict__ sbits, int so_inj, uint32_t k0, uint32_t k1, int B, int nCB, int ncb_all, int nib,
                                                       uint32_t* __restrict__ sT) {
     const int lane = threadIdx.x & 63, il = lane & 31, half = lane >> 5;
-    const int cb = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half, ib = blockIdx.y;   // a half-wave per (32-expert block, K block)
-    const int i = ib * 32 + il;
-    uint32_t w = 0u;
-    if (cb < ncb_all && i < B) {
-        if (so_inj) { if (cb < nCB) w = sbits[(int64_t)i * nCB + cb]; }
-        else w = sign_word(k0, k1, (uint32_t)i, (uint32_t)cb);
-    }
-    w = transpose32(w, il);
+    const int cb = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;   // a half-wave per 32-expert block, looping over the K blocks
+    if (cb >= ncb_all) return;                                          // (wave-uniform per half: transpose32 shuffles stay inside a half)
     const int c = cb * 32 + il;
-    if (cb < ncb_all) sT[((int64_t)(c >> 8) * nib + ib) * 256 + (c & 255)] = w;
+    uint32_t* dst = sT + (int64_t)(c >> 8) * nib * 256 + (c & 255);
+    for (int ib = 0; ib < nib; ++ib) {
+        const int i = ib * 32 + il;
+        uint32_t w = 0u;
+        if (i < B) {
+            if (so_inj) { if (cb < nCB) w = sbits[(int64_t)i * nCB + cb]; }
+            else w = sign_word(k0, k1, (uint32_t)i, (uint32_t)cb);
+        }
+        dst[(int64_t)ib * 256] = transpose32(w, il);
+    }
 }
 
 // dW of the fp16x3 training step (H = 128).  Same tiling as k_out_dw_b6 (8 waves x 32 experts, K = batch in 32-row blocks, two LDS stages by LDS-DMA),
@@ -1932,7 +1935,7 @@ void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, vo
     char* ws = static_cast<char*>(ws_);
     if (bayes && s_out) {   // packed fp16x3 path: the dW kernel's s_out words, transposed once
         const int ncb_all = rup(M, DW_TC) / 32, nib = g.Bpad / 32;
-        hipLaunchKernelGGL(k_sign_words_T, dim3((ncb_all + 7) / 8, nib), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws + w.sbits), s_out_inj, s_out->k0, s_out->k1,
+        hipLaunchKernelGGL(k_sign_words_T, dim3((ncb_all + 7) / 8), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws + w.sbits), s_out_inj, s_out->k0, s_out->k1,
                            B, g.nCB, ncb_all, nib, reinterpret_cast<uint32_t*>(ws + w.sbitsT));
     }
     const int n = g.Bpad * H;

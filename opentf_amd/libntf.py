@@ -437,6 +437,7 @@ class Engine:
         self._ck(lib().ntf_synchronize(self._h))
 
     def kernel_times(self, enable=True):
+        """enable: False / True (every kernel family) / 2 (only the output layer's forward and dW kernels)"""
         cap = 32
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); calls = (C.c_int64 * cap)()
         n = lib().ntf_kernel_times(self._h, int(enable), names, ms, calls, cap)
