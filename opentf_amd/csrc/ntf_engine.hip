@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,7 @@ struct ntf_engine {
     char* fws = nullptr;              // fused path: sign-bit images, h*s_in, loss partials
     float* gemm_slab = nullptr;       // split-K partial sums of the generic GEMM
     double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
+    int fwd_kernel = -1;
     int32_t* d_range = nullptr;       // fp16x3 range guard (lives behind d_kl[0]): [0] raised for the current step, [1] steps that fell back to the f32 kernels
     int64_t range_fallbacks_host = 0; // inference calls redone on the generic path for the same reason
     float* tk_vals = nullptr; int32_t* tk_idx = nullptr; int64_t tk_cap = 0;
@@ -167,6 +169,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->L = cfg->n_layers;
     e->lr = cfg->lr;
     e->seed = cfg->seed;
+    if (const char* fk = getenv("NTF_FWD_KERNEL")) e->fwd_kernel = atoi(fk);
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
     int64_t off = 0;
@@ -691,6 +694,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.bf16x6 = e->pl_mu != nullptr; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
         f.np = mfma_np(e); f.w_scale = kW16Scale; f.h_scale = kH16Scale; f.dz_scale = dz_scale16(e, c.global_B);
         f.rflag = range_ptr(e);
+        if (e->fwd_kernel >= 0) f.wide = e->fwd_kernel;   // A/B runs: NTF_FWD_KERNEL = 0, 1, 2 (ntf_fused.h), read when the engine is created
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }

@@ -25,7 +25,8 @@ struct FusedOut {
     int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
     int np = 3;                                     // 3: bf16x6, 2: fp16x3 (operands scaled by exact powers of two before their two-way fp16 split)
     float w_scale = 1.f, h_scale = 1.f, dz_scale = 1.f;
-    int wide = 1;                                   // np = 2 training step: the 64-expert-tile kernel (0: the 32-expert-tile kernel, for A/B runs)
+    int wide = 1;                                   // np = 2 training step: 1 the 64-expert-tile kernel (one wave per SIMD), 0 the 32-expert-tile kernel,
+                                                    // 2 (Flipout only) the role-split kernel: mu-wave / Wp-wave pairs, two waves per SIMD
     int planes_ready = 0;
     // inference (train = 0, probs = 1): dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale instead of the loss; the row entropy partials go to the workspace
     int probs = 0, pacc = 0; float pscale = 1.f;

@@ -50,7 +50,7 @@ static Geom geom(int B, int M) {
     g.nCB = rup((M + 31) / 32, 2);
     return g;
 }
-int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)NCG_MAX * BM * H; }
+int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)2 * NCG_MAX * BM * H; }   // x2: k_out_fwd_rs writes one slab set per role
 
 struct WsLayout { size_t sbits, sbitsT, sinbits, hs, hz, lossp, hb, total; };
 static WsLayout ws_layout(int Bmax, int H, int M) {
@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct SpecialArgs {
     int B, M, Bpad, NCG, nCB, ns;
+    int nslab;   // dh slabs to sum (NCG, or 2 NCG behind k_out_fwd_rs)
     const float *h, *hs, *mu, *mu_b, *wp, *bp, *slab, *lossp, *h_mask;
     const uint32_t *sbits, *sinbits;
     const int64_t *rows, *m_indptr, *neg; const int32_t* m_indices;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
         if (j < H) {
             hr[m] = p.h[(int64_t)i * H + j];
             if (BAYES) hsr[m] = p.hs[(int64_t)i * H + j];
-            if (TRAIN && DH) for (int cg = 0; cg < p.NCG; ++cg) acc[m] += p.slab[((int64_t)cg * p.Bpad + i) * H + j];
+            if (TRAIN && DH) for (int cg = 0; cg < p.nslab; ++cg) acc[m] += p.slab[((int64_t)cg * p.Bpad + i) * H + j];
         }
     }
     const int64_t team = p.rows[i];
@@ -1742,6 +1743,252 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Training forward (loss + dz + dh) of the Flipout output layer in fp16x3 with TWO WAVES PER SIMD (round 2).
+// k_out_fwd_h3w keeps one wave per SIMD at 512 registers: per 64-expert tile its 192 MFMAs (6.1 k cycles) sit beside ~1.1 k vector instructions and
+// 44 waits and the tile takes 14.9 k cycles - exposed LDS latency with nobody to cover it.  Here the two matrices are split over a wave PAIR that
+// shares 32 batch rows: wave w (role 0) multiplies by mu, wave w + 4 (role 1, the same SIMD) by Wp.  Each keeps one operand set of h planes
+// (h or h*s_in, 64 registers), one accumulator of zT (16) and one of dh (64) - under 256 registers, so both fit on the SIMD and cover each
+// other's LDS round trips.  Per 32-expert tile:
+//   S0  both: zT = W_role . hT (24 MFMAs); role 1 finishes its logit part (bias, s_out sign) and hands it over through LDS
+//   S1  role 0: z = own + partner's, leaky_relu, BCE, dz, loss; dz split into fp16 planes -> dzT (packed) and, through LDS, to the partner
+//   S2  both: dh_role += (dz | dz*s_out) . W_role (24 MFMAs)
+// The exchanges use [register][lane] images (the partners' lanes hold the same (row, expert) elements), so they are conflict-free b32 accesses.
+// MEASURED (round 2): parity-green, 228 registers, two waves per SIMD - and 9 % SLOWER than k_out_fwd_h3w (0.87 vs 0.80 ms).  Ablations: without any
+// MFMA, DMA or epilogue math the per-tile skeleton (fragment reads, the two exchanges, three barriers per 24-MFMA phase) still takes 58 % of the
+// kernel's time: on 32-expert tiles the phases are too short for their fixed LDS / barrier latencies, and 64-expert tiles do not fit beside the
+// exchange images (2 x 64.5 KB stages + 32 KB = 161 KB).  Kept as FusedOut.wide = 2 (NTF_FWD_KERNEL=2) for A/B runs; not the default.
+// ------------------------------------------------------------------------------------------------
+template <bool INJ>
+__global__ __launch_bounds__(512, 2) void k_out_fwd_rs(OutFwd6Args pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OutFwdArgs& p = pp.a;
+    constexpr int H = 128, NJT = 4, NKS = H / 16, NP = 2;
+    constexpr int PLANE = BN6 * H * 2;          // 8 KiB
+    constexpr int TM = NP * PLANE;              // one matrix of a tile
+    constexpr int STAGE = 2 * TM + 512;         // two matrices + two 64-float bias tiles
+    constexpr int XCH = 4 * 16 * 64 * 4;        // one exchange image: [pair][register][lane] dwords = 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (range_guard_skip(p.rflag, p.rmode, false)) return;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), pair = __builtin_amdgcn_readfirstlane(wave & 3);
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int cg = bid / p.NRB, rb = bid % p.NRB;
+    const int T = (p.M + BN6 - 1) / BN6;
+    const int t_beg = (int)((int64_t)cg * T / p.NCG), t_end = (int)((int64_t)(cg + 1) * T / p.NCG);
+    const int i0 = rb * BM + pair * 32;
+    const int i = i0 + il;
+    const bool row_ok = i < p.B;
+
+    // B operand of zT: this role's planes of h[i][16s + 8*half + e] (role 1: times s_in, applied once)
+    u32x4 hp[NKS][3];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
+        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        uint32_t w8 = 0u;
+        if (role == 1) {
+            const uint32_t sw_in = INJ ? p.sinbits[(int64_t)i * NJT + (s >> 1)] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)(s >> 1)) : 0u);
+            w8 = sw_in >> (16 * (s & 1) + 8 * half);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t pq[3];
+            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
+            const uint32_t m = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+            hp[s][0][q] = pq[0] ^ m; hp[s][1][q] = pq[1] ^ m; hp[s][2][q] = 0u;
+        }
+    }
+    const float rmask = row_ok ? 1.f : 0.f;
+    const float rscale = row_ok ? p.tnw * p.inv_B : 0.f;
+
+    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
+    int troff[2][NJT];
+    {
+        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int row = 8 * rr + 4 * half + q;
+                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
+            }
+    }
+
+    f32x16 Y[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y[j][r] = 0.f;
+    LossAcc lacc;
+
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float* xz = reinterpret_cast<float*>(smem + 2 * STAGE) + (pair * 16) * 64 + lane;                    // + 64 r : logit part of the partner
+    uint32_t* xd = reinterpret_cast<uint32_t*>(smem + 2 * STAGE + XCH) + (pair * 16) * 64 + lane;        // + 64 k : dz plane registers
+    auto stage_tile = [&](int t, int buf) {
+        const uint32_t sb = smem_base + buf * STAGE;
+        constexpr int PER_WAVE = TM / 1024 / 8;     // 1 KiB wave-instructions per wave per matrix
+#pragma unroll
+        for (int n = 0; n < PER_WAVE; ++n) {
+            const int inst = wave_u * PER_WAVE + n;
+            const int pos = inst * 1024 + lane * 16;
+            const int row = (pos >> 8) & 31, chp = (pos >> 4) & 15;
+            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            const size_t src = (size_t)t * TM + (pos & ~255) + 16 * ch;
+            glds16(reinterpret_cast<const char*>(pp.mu_pl) + src, sb + inst * 1024);
+            glds16(reinterpret_cast<const char*>(pp.wp_pl) + src, sb + TM + inst * 1024);
+        }
+        const int c0 = t * BN6;
+        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + 2 * TM);
+        if (wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + 2 * TM + 256);
+    };
+    if (t_beg < t_end) stage_tile(t_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        uint32_t sw = 0u;
+        if (row_ok) sw = (INJ ? p.sbits[(int64_t)i * p.nCB + t] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)t)) >> (4 * half);
+        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
+        char* sb = smem + buf * STAGE;
+        const int c0 = t * BN6;
+        if (c0 + BN6 > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
+            if (tid < BN6 && c0 + tid >= p.M) reinterpret_cast<float*>(sb + 2 * TM)[tid] = -1e30f;
+            __syncthreads();
+        }
+        f32x16 X;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[r] = 0.f;
+        const uint32_t sbase = lds_addr(sb);
+
+        // ---- S0: zT of this role's matrix: 8 k-steps of 16 hidden units, the fragments of the next k-step in flight under the MFMAs of the current one
+        {
+            auto z_load = [&](int s, u32x4 (&fr)[3]) {
+                const char* ap = sb + 256 * il + 16 * ((2 * s + half) ^ fil) + role * TM;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
+            };
+            u32x4 fr[2][3];
+            z_load(0, fr[0]);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                if (s + 1 < NKS) z_load(s + 1, fr[(s + 1) & 1]);
+                asm volatile("" ::: "memory");
+                X = mfma_np<NP>(fr[s & 1], hp[s], X);
+            }
+        }
+        const float* bias = reinterpret_cast<const float*>(sb + 2 * TM + 256 * role) + 4 * half;
+        if (role == 1) {   // the perturbation part of the logit, signed, to the partner
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                xz[64 * r] = __uint_as_float(__float_as_uint(fmaf(X[r], pp.u_z, bias[cr])) ^ ((sw << (31 - cr)) & 0x80000000u));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        // ---- S1: role 0 owns the epilogue of the tile
+        u32x4 ad[2][3];
+        if (role == 0) {
+            constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
+            const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
+            const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                const float z = fmaf(X[r], pp.u_z, bias[cr]) + xz[64 * r];
+                const bool pos = z > 0.f;
+                const float l = pos ? z : z * kLeakySlope;
+                const float lc = fmaxf(l, -80.f);
+                const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
+                lacc.tile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lacc.tile);
+                X[r] = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
+            }
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 2) {
+                uint32_t pq[3];
+                split_pair_np<NP>(X[r0], X[r0 + 1], pp.dz_scale, pq);
+                ad[r0 >> 3][0][(r0 & 7) >> 1] = pq[0]; ad[r0 >> 3][1][(r0 & 7) >> 1] = pq[1];
+                uint32_t d0, d1;
+                pack_planes(pq[0], pq[1], d0, d1);
+                __builtin_amdgcn_raw_buffer_store_b32(d0, dz_rsrc, dz_voff, ((r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(d1, dz_rsrc, dz_voff, (((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
+                xd[64 * (r0 >> 1)] = pq[0]; xd[64 * (8 + (r0 >> 1))] = pq[1];
+            }
+            ad[0][2] = ad[0][0]; ad[1][2] = ad[1][0];
+            lacc.end_tile();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (role == 1) {   // the partner's dz planes, times s_out
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r0 = 2 * k, c0r = (r0 & 3) + 8 * (r0 >> 2);   // registers r0, r0 + 1 are experts c0r, c0r + 1 (+ 4*half, folded into sw)
+                const uint32_t m = (((sw << (31 - c0r)) & 0x80000000u) >> 16) | ((sw << (30 - c0r)) & 0x80000000u);
+                ad[k >> 2][0][k & 3] = xd[64 * k] ^ m; ad[k >> 2][1][k & 3] = xd[64 * (8 + k)] ^ m;
+            }
+            ad[0][2] = ad[0][0]; ad[1][2] = ad[1][0];
+        }
+
+        // ---- S2: dh of this role's matrix: groups (k-step of 16 experts, jt) of 4 transposed reads + 3 MFMAs
+        {
+            auto tr_load = [&](int g, u32x4 (&bf)[3]) {
+                const int jt = g % NJT, s2 = g / NJT;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const uint32_t o = 4096 * s2 + q * PLANE + role * TM;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[0][jt] + o)));
+                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[1][jt] + o)));
+                    bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
+                }
+            };
+            constexpr int NG = 2 * NJT;
+            u32x4 bf[2][3];
+            tr_load(0, bf[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) tr_load(g + 1, bf[(g + 1) & 1]);
+                asm volatile("" ::: "memory");
+                Y[g % NJT] = mfma_np<NP>(ad[g / NJT], bf[g & 1], Y[g % NJT]);
+            }
+        }
+        // tile end: the next tile's DMA (older than role 0's 16 dzT stores) has landed; everybody is done with this stage and the exchange images
+        if (role == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    if (role == 0) {
+        float lsum = lacc.sum;
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+    }
+    // dh partials: role 0 -> slab cg, role 1 (times s_in) -> slab NCG + cg; k_out_special sums 2 NCG slabs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int irow = i0 + rowmap(r, half);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            float v = Y[jt][r] * pp.u_dh;
+            if (role == 1) {
+                const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
+                v = ((w >> il) & 1u) ? -v : v;
+            }
+            p.slab[((int64_t)(role * p.NCG + cg) * p.Bpad + irow) * H + 32 * jt + il] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
 static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
@@ -1789,6 +2036,8 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     a.rflag = f.rflag; a.rmode = 0;
     SpecialArgs s;
     s.B = f.B; s.M = f.M; s.Bpad = g.Bpad; s.NCG = g.NCG; s.nCB = g.nCB; s.ns = f.ns;
+    const bool role_split = f.bf16x6 && f.H == 128 && f.np == 2 && f.train && f.dh != nullptr && f.bayes && f.wide == 2;
+    s.nslab = role_split ? 2 * g.NCG : g.NCG;
     s.h = f.h; s.hs = hs; s.mu = f.mu; s.mu_b = f.mu_b; s.wp = f.wp; s.bp = f.bp; s.slab = f.dh_slab; s.lossp = lossp; s.h_mask = f.h_mask;
     s.sbits = sbits; s.sinbits = sinbits; s.rows = f.rows; s.m_indptr = f.m_indptr; s.neg = f.neg; s.m_indices = f.m_indices;
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
@@ -1815,7 +2064,14 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_L6(BY, TR, DHF, IJ, PR) do { if (np == 2) NTF_L6N(BY, TR, DHF, IJ, PR, 2); else NTF_L6N(BY, TR, DHF, IJ, PR, 3); } while (0)
 #define NTF_L6B(BY, IJ) do { if (f.probs) NTF_L6(BY, false, false, IJ, true); else if (!f.train) NTF_L6(BY, false, false, IJ, false);  \
                              else if (dh) NTF_L6(BY, true, true, IJ, false); else NTF_L6(BY, true, false, IJ, false); } while (0)
-            if (np == 2 && f.train && dh && f.wide) {    // 64-expert tiles (a.T counts them already)
+            if (role_split) {                            // two waves per SIMD, mu-wave / Wp-wave pairs on 32-expert tiles
+                const size_t ldsr = 2 * ((size_t)2 * 2 * BN6 * 128 * 2 + 512) + 2 * (4 * 16 * 64 * 4);
+#define NTF_LR(IJ) do { auto kf = k_out_fwd_rs<IJ>;                                                                               \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);   \
+                hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsr, st, a6); } while (0)
+                if (inj) NTF_LR(true); else NTF_LR(false);
+#undef NTF_LR
+            } else if (np == 2 && f.train && dh && f.wide) {    // 64-expert tiles (a.T counts them already)
                 const size_t ldsw = 2 * ((size_t)(f.bayes ? 2 : 1) * 2 * 64 * 128 * 2 + 512);
 #define NTF_LW(BY, IJ) do { auto kf = k_out_fwd_h3w<BY, IJ>;                                                                    \
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \

@@ -128,7 +128,10 @@ def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
         neg = O.ns_uniform(y, 5)
         inj = {"neg_idx": neg.numpy(), "eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise],
                "s_in": [n["s_in"] for n in noise], "s_out": [n["s_out"] for n in noise]}
-        ref_logits = O.bnn_forward(sd, X, noise).detach().numpy()
+        # the forward kernel is judged on the weights the ENGINE holds: after an Adam step those differ from the oracle's by up to the state tolerance
+        # below (a leaky_relu' kink flip moves one expert's gradient row, and Adam turns any gradient difference into a +-lr step)
+        sd_e = {k: torch.from_numpy(v) for k, v in e.state_dict().items()}
+        ref_logits = O.bnn_forward(sd_e, X, noise).detach().numpy()
         got = e.logits(rows, inject=inj)
         assert _rel(got, ref_logits) < RTOL_LOGITS
         _close(got, ref_logits, RTOL_LOGITS, 2e-6)
