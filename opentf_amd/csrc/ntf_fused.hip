@@ -447,88 +447,112 @@ struct SpecialArgs {
     const int* rflag;
 };
 
+// One wave per team.  H = 128: the wave works as FOUR quarter-waves of 16 lanes x 8 consecutive hidden units, each quarter taking every fourth
+// special entry (and every fourth dh slab): the ~8 dependent dot-product / reduction / BCE chains of a team run four abreast, rows are read as
+// 32-byte pieces (round 2: 55 -> ~20 us per step at B = 1000).  Other widths keep one entry at a time over the whole wave (NV values per lane).
 template <int H, bool BAYES, bool TRAIN, bool DH>
 __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
-    constexpr int NM = (H + 63) / 64;
+    constexpr bool QUAD = (H == 128);
+    constexpr int NQ = QUAD ? 4 : 1;                 // entries in flight
+    constexpr int NV = QUAD ? 8 : (H + 63) / 64;     // hidden units per lane
     const int i = blockIdx.x, lane = threadIdx.x;
+    const int q = QUAD ? (lane >> 4) : 0, l = QUAD ? (lane & 15) : lane;
+    auto hidx = [&](int k) { return QUAD ? 8 * l + k : l + 64 * k; };      // this lane's k-th hidden unit
     const bool packed = p.dz_pack_scale > 0.f && !(p.rflag && *p.rflag);
     float rl = 0.f;
     for (int cg = lane; cg < p.NCG; cg += 64) rl += p.lossp[(int64_t)i * p.NCG + cg];
     rl = wave_reduce_sum(rl);
-    float acc[NM], hr[NM], hsr[NM];
+    float acc[NV], hr[NV], hsr[NV];
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-        const int j = lane + 64 * m;
-        acc[m] = 0.f; hr[m] = 0.f; hsr[m] = 0.f;
-        if (j < H) {
-            hr[m] = p.h[(int64_t)i * H + j];
-            if (BAYES) hsr[m] = p.hs[(int64_t)i * H + j];
-            if (TRAIN && DH) for (int cg = 0; cg < p.nslab; ++cg) acc[m] += p.slab[((int64_t)cg * p.Bpad + i) * H + j];
+    for (int k = 0; k < NV; ++k) {
+        const int j = hidx(k);
+        acc[k] = 0.f; hr[k] = 0.f; hsr[k] = 0.f;
+        if (j < H) { hr[k] = p.h[(int64_t)i * H + j]; if (BAYES) hsr[k] = p.hs[(int64_t)i * H + j]; }
+    }
+    if (TRAIN && DH) {
+        for (int cg = q; cg < p.nslab; cg += NQ) {
+            const float* sl = p.slab + ((int64_t)cg * p.Bpad + i) * H;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const int j = hidx(k); if (j < H) acc[k] += sl[j]; }
         }
     }
+    auto group_sum = [&](float v) {    // sum over the lanes that share one entry: a quarter (16 lanes) or the whole wave
+        if (!QUAD) return wave_reduce_sum(v);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
     const int64_t team = p.rows[i];
     const int64_t pb = p.m_indptr[team];
     const int npos = (int)(p.m_indptr[team + 1] - pb);
     const int total = npos + (p.neg ? p.ns : 0);
     float fix = 0.f;
-    for (int sidx = 0; sidx < total; ++sidx) {
-        int c; float y; bool skip = false;
+    for (int s0 = 0; s0 < total; s0 += NQ) {       // wave-uniform trip count: the shuffles below need every lane
+        const int sidx = s0 + q;
+        int c = -1; float y = 0.f;
         if (sidx < npos) { c = p.m_indices[pb + sidx]; y = 1.f; }
-        else {
-            const int q = sidx - npos;
-            c = (int)p.neg[(int64_t)i * p.ns + q]; y = 0.f;
-            for (int k = 0; k < npos; ++k) if (p.m_indices[pb + k] == c) skip = true;
-            for (int k = 0; k < q; ++k) if ((int)p.neg[(int64_t)i * p.ns + k] == c) skip = true;
+        else if (sidx < total) {
+            const int qn = sidx - npos;
+            c = (int)p.neg[(int64_t)i * p.ns + qn];
+            for (int k = 0; k < npos; ++k) if (p.m_indices[pb + k] == c) c = -1;
+            for (int k = 0; k < qn; ++k) if (c >= 0 && (int)p.neg[(int64_t)i * p.ns + k] == c) c = -1;
         }
-        if (skip || c < 0 || c >= p.M) continue;
-        float d1 = 0.f, d2 = 0.f;
+        const bool live = c >= 0 && c < p.M;
+        const int cc = live ? c : 0;
+        float mu_r[NV], wp_r[NV], d1 = 0.f, d2 = 0.f;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const int j = lane + 64 * m;
-            if (j < H) { d1 += hr[m] * p.mu[(int64_t)c * H + j]; if (BAYES) d2 += hsr[m] * p.wp[(int64_t)c * H + j]; }
+        for (int k = 0; k < NV; ++k) {
+            const int j = hidx(k);
+            mu_r[k] = 0.f; wp_r[k] = 0.f;
+            if (j < H) { mu_r[k] = p.mu[(int64_t)cc * H + j]; d1 += hr[k] * mu_r[k]; if (BAYES) { wp_r[k] = p.wp[(int64_t)cc * H + j]; d2 += hsr[k] * wp_r[k]; } }
         }
-        d1 = wave_reduce_sum(d1);
-        float z = d1 + p.mu_b[c];
+        d1 = group_sum(d1);
+        float z = d1 + p.mu_b[cc];
         float so = 1.f;
         if (BAYES) {
-            d2 = wave_reduce_sum(d2);
-            const uint32_t sw_ = p.so_inj ? p.sbits[(int64_t)i * p.nCB + (c >> 5)] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(c >> 5));
-            so = ((sw_ >> (c & 31)) & 1u) ? -1.f : 1.f;
-            z += (d2 + p.bp[c]) * so;
+            d2 = group_sum(d2);
+            const uint32_t sw_ = p.so_inj ? p.sbits[(int64_t)i * p.nCB + (cc >> 5)] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(cc >> 5));
+            so = ((sw_ >> (cc & 31)) & 1u) ? -1.f : 1.f;
+            z += (d2 + p.bp[cc]) * so;
         }
         float sp, sg, dact;
         bce_terms(z, sp, sg, dact);
-        const float l = z > 0.f ? z : z * kLeakySlope;
-        fix += p.tpw * (sp - l * y) - p.tnw * sp;
-        if (TRAIN) {
+        const float lz = z > 0.f ? z : z * kLeakySlope;
+        if (live && l == 0) fix += p.tpw * (sp - lz * y) - p.tnw * sp;
+        if (TRAIN && live) {
             const float dzt = p.tpw * (sg - y) * dact * p.inv_B;
             const float delta = dzt - p.tnw * sg * dact * p.inv_B;
-            if (lane == 0) {
+            if (l == 0) {
                 if (packed) { uint32_t pq[3]; split_pair_np<2>(dzt, 0.f, p.dz_pack_scale, pq); reinterpret_cast<uint32_t*>(p.dzT)[dzt_index(c, i, p.Bpad)] = (pq[0] & 0xFFFFu) | (pq[1] << 16); }
                 else p.dzT[dzt_index(c, i, p.Bpad)] = dzt;
             }
             if (DH) {
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int j = lane + 64 * m;
+                for (int k = 0; k < NV; ++k) {
+                    const int j = hidx(k);
                     if (j < H) {
-                        acc[m] += delta * p.mu[(int64_t)c * H + j];
+                        acc[k] += delta * mu_r[k];
                         if (BAYES) {
                             const float si = ((p.sinbits[(int64_t)i * (H / 32) + (j >> 5)] >> (j & 31)) & 1u) ? -1.f : 1.f;
-                            acc[m] += delta * so * p.wp[(int64_t)c * H + j] * si;
+                            acc[k] += delta * so * wp_r[k] * si;
                         }
                     }
                 }
             }
         }
     }
-    if (lane == 0) p.row_fix[i] = rl + fix;
-    if (TRAIN && DH) {
+    if (QUAD) {   // quarters -> one
+        fix += __shfl_xor(fix, 16, 64); fix += __shfl_xor(fix, 32, 64);
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const int j = lane + 64 * m;
+        for (int k = 0; k < NV; ++k) { acc[k] += __shfl_xor(acc[k], 16, 64); acc[k] += __shfl_xor(acc[k], 32, 64); }
+    }
+    if (lane == 0) p.row_fix[i] = rl + fix;
+    if (TRAIN && DH && q == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = hidx(k);
             if (j < H) {
-                float v = acc[m];
+                float v = acc[k];
                 if (p.h_mask) v *= (p.h_mask[(int64_t)i * H + j] > 0.f) ? 1.f : kLeakySlope;
                 p.dh[(int64_t)i * H + j] = v;
             }
