@@ -966,9 +966,10 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
         const int64_t idx0 = (int64_t)cr * H + NJT * il;
         if (BAYES) { ld_vec<NJT>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<NJT>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<NJT>(p.wp + idx0, v_wp); }
         else if (ADAM) ld_vec<NJT>(p.w_mu + idx0, v_mu);
+        float a_m1[NJT], a_v1[NJT], a_m2[NJT], a_v2[NJT];
+        if (ADAM) { ld_vec<NJT>(p.m_mu + idx0, a_m1); ld_vec<NJT>(p.v_mu + idx0, a_v1); if (BAYES) { ld_vec<NJT>(p.m_rho + idx0, a_m2); ld_vec<NJT>(p.v_rho + idx0, a_v2); } }
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const int64_t idx = idx0 + jt;
             float gm = acc1[jt][r] * p.unscale, gr = 0.f, pm = 0.f, rh = 0.f;   // unscale: 1 / (dz scale * h scale), 1 for bf16x6
             if (BAYES) {
                 rh = v_rho[jt];
@@ -983,18 +984,16 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
                 gr = (acc2[jt][r] * p.unscale) * (w * isig) * sg + p.klw * (sigma - isig) * sg;
             } else if (ADAM) pm = v_mu[jt];
             o_mu[jt] = gm; o_rho[jt] = gr;
-            if (ADAM) {
-                float m = p.m_mu[idx], v = p.v_mu[idx];
-                p.w_mu[idx] = adam_update(pm, gm, m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
-                p.m_mu[idx] = m; p.v_mu[idx] = v;
-                if (BAYES) {
-                    float m2 = p.m_rho[idx], v2 = p.v_rho[idx];
-                    p.w_rho[idx] = adam_update(rh, gr, m2, v2, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
-                    p.m_rho[idx] = m2; p.v_rho[idx] = v2;
-                }
+            if (ADAM) {   // in place: the updated parameter goes where the gradient would have gone
+                o_mu[jt] = adam_update(pm, gm, a_m1[jt], a_v1[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                if (BAYES) o_rho[jt] = adam_update(rh, gr, a_m2[jt], a_v2[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
             }
         }
         if (!ADAM) { st_vec<NJT>(p.g_mu + idx0, o_mu); if (BAYES) st_vec<NJT>(p.g_rho + idx0, o_rho); }
+        else {
+            st_vec<NJT>(p.w_mu + idx0, o_mu); st_vec<NJT>(p.m_mu + idx0, a_m1); st_vec<NJT>(p.v_mu + idx0, a_v1);
+            if (BAYES) { st_vec<NJT>(p.w_rho + idx0, o_rho); st_vec<NJT>(p.m_rho + idx0, a_m2); st_vec<NJT>(p.v_rho + idx0, a_v2); }
+        }
     }
 }
 
@@ -1160,9 +1159,10 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
         const int64_t idx0 = (int64_t)cr * H + NJT * il;
         if (BAYES) { ld_vec<NJT>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<NJT>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<NJT>(p.wp + idx0, v_wp); }
         else if (ADAM) ld_vec<NJT>(p.w_mu + idx0, v_mu);
+        float a_m1[NJT], a_v1[NJT], a_m2[NJT], a_v2[NJT];
+        if (ADAM) { ld_vec<NJT>(p.m_mu + idx0, a_m1); ld_vec<NJT>(p.v_mu + idx0, a_v1); if (BAYES) { ld_vec<NJT>(p.m_rho + idx0, a_m2); ld_vec<NJT>(p.v_rho + idx0, a_v2); } }
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const int64_t idx = idx0 + jt;
             float gm = acc1[jt][r] * p.unscale, gr = 0.f, pm = 0.f, rh = 0.f;
             if (BAYES) {
                 rh = v_rho[jt];
@@ -1175,18 +1175,16 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
                 gr = (acc2[jt][r] * p.unscale) * (w * isig) * sg + p.klw * (sigma - isig) * sg;
             } else if (ADAM) pm = v_mu[jt];
             o_mu[jt] = gm; o_rho[jt] = gr;
-            if (ADAM) {
-                float m = p.m_mu[idx], v = p.v_mu[idx];
-                p.w_mu[idx] = adam_update(pm, gm, m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
-                p.m_mu[idx] = m; p.v_mu[idx] = v;
-                if (BAYES) {
-                    float m2 = p.m_rho[idx], v2 = p.v_rho[idx];
-                    p.w_rho[idx] = adam_update(rh, gr, m2, v2, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
-                    p.m_rho[idx] = m2; p.v_rho[idx] = v2;
-                }
+            if (ADAM) {   // in place: the updated parameter goes where the gradient would have gone
+                o_mu[jt] = adam_update(pm, gm, a_m1[jt], a_v1[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                if (BAYES) o_rho[jt] = adam_update(rh, gr, a_m2[jt], a_v2[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
             }
         }
         if (!ADAM) { st_vec<NJT>(p.g_mu + idx0, o_mu); if (BAYES) st_vec<NJT>(p.g_rho + idx0, o_rho); }
+        else {
+            st_vec<NJT>(p.w_mu + idx0, o_mu); st_vec<NJT>(p.m_mu + idx0, a_m1); st_vec<NJT>(p.v_mu + idx0, a_v1);
+            if (BAYES) { st_vec<NJT>(p.w_rho + idx0, o_rho); st_vec<NJT>(p.m_rho + idx0, a_m2); st_vec<NJT>(p.v_rho + idx0, a_v2); }
+        }
     }
 }
 
