@@ -113,6 +113,10 @@ def main():
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # stdout must carry exactly ONE JSON line: RCCL writes a version banner to the C-level stdout (flushed when the process exits, i.e. after
+    # the JSON line), so everything but that line is sent to stderr at the file-descriptor level
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush(); os.dup2(2, 1)
     torch.cuda.set_device(local)
     if world > 1 or a.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -143,7 +147,7 @@ def main():
         if a.gather_only:
             for _ in range(5): e.gather_meanpool(n=ds["N"], to_host=False)
             e.synchronize()
-            print(json.dumps({"gather_only": True, "teams": ds["N"]}), flush=True)
+            print(json.dumps({"gather_only": True, "teams": ds["N"]}), file=real_stdout, flush=True)
             return
         dp = DataParallel(e)
         gB = a.batch * world                                   # weak scaling: B teams per GPU
@@ -256,7 +260,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(ds, dims, bayesian, cfg)
     if world > 1: dist.destroy_process_group()   # before the JSON line: RCCL prints its version banner when the group goes away
     sys.stdout.flush(); sys.stderr.flush()
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=real_stdout, flush=True)
 
 
 if __name__ == "__main__":
