@@ -67,7 +67,15 @@ typedef struct ntf_config {
                                    three bf16 values and a product taken as six bf16 MFMA products accumulated in f32 (f32-accurate, ~2.7x the rate),
                                    NTF_MFMA_FP16X3 = each operand times an exact power of two split into two fp16 values (22 bits), three fp16 MFMA products per f32
                                    product (error against f64 ~1.2x that of the f32 MFMA, half the matrix work of BF16X6) */
-    int32_t reserved[5];
+    /* Expert-sharded output layer (every field 0 = off).  This engine owns the experts [expert_lo, expert_lo + dims[n_layers]) of an
+       output layer of `experts_global` experts that is split over `ep_world` engines (one per GPU); hidden layers are replicated.  Every engine
+       steps the WHOLE minibatch: labels (member CSR) and sampled negatives keep global expert ids, the device generators are keyed by global
+       ids, and the only exchange of a train step is the sum over engines of d(hidden) [B, h[-1]] between ntf_step_staged_ep phases 1 and 2.
+       expert_lo must be a multiple of 256; needs the fused output-layer path (h[-1] in {32, 64, 128}). */
+    int32_t expert_lo;
+    int32_t experts_global;
+    int32_t ep_world;
+    int32_t reserved[2];
 } ntf_config;
 
 /* Random tensors of one step, injected instead of generated (parity tests).  Any pointer may be NULL
@@ -151,6 +159,16 @@ int ntf_dw_chunks(ntf_engine* e, int32_t* n_chunks);
 int ntf_dw_chunk_range(ntf_engine* e, int32_t k, int64_t* off_weight, int64_t* off_rho, int64_t* count);
 int ntf_dw_chunk(ntf_engine* e, int32_t k);
 int ntf_param_segment(ntf_engine* e, int layer, int kind, int64_t* off, int64_t* count);
+
+/* expert-sharded output layer (ntf_config.expert_lo ..): one train step on the whole minibatch order[offset, offset + B) in two phases.
+ * phase 1: forward, loss, the output layer's backward on this engine's experts (its Adam included) - leaves this engine's PARTIAL d(hidden)
+ *          in the buffer ntf_dh_buffer names ([B, h[-1]] floats, row-major);
+ * (the host sums that buffer over the engines: one all-reduce of B * h[-1] floats, the only exchange of the step;)
+ * phase 2: backward through the replicated hidden layers from the summed d(hidden), Adam on them (identical on every engine).
+ * The loss accumulated for ntf_epoch_loss is this engine's share: sum over engines = the single-engine loss.  Evaluation steps need no
+ * exchange: ntf_step_staged(train = 0) as usual.  src/mdl/fnn.py:122-140 (the step this splits) */
+int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int32_t phase);
+int ntf_dh_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
 
 /* ---- inference:  Fnn.test batch body                              src/mdl/fnn.py:200-211
  * probs_host [B, M] = sigmoid(forward) (Bnn: mean over nmc stochastic forwards);

@@ -51,6 +51,7 @@ __device__ __forceinline__ void normal4(const NormalSpec& s, int64_t q, int64_t 
         for (int j = 0; j < 4; ++j) z[j] = (e0 + j < n) ? s.inj[e0 + j] : 0.f;
         return;
     }
+    q += s.qbase;
     const uint4 r = philox4x32(make_uint4((uint32_t)q, (uint32_t)(q >> 32), s.tag, s.step), make_uint2(s.k0, s.k1));
     // Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take their argument in revolutions
     const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.x)));   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)

@@ -31,6 +31,19 @@ static const char* kFamNames[F_COUNT] = {"gather", "gemm_hidden", "flipout_opera
 struct TimeRec { int fam; hipEvent_t a, b; };
 constexpr int64_t kGemmSlabFloats = 8 << 20;  // 32 MiB
 
+struct StepCtx {
+    const int64_t* rows_dev = nullptr;
+    int B = 0; int global_B = 0;
+    const ntf_inject* inj = nullptr;
+    uint64_t step = 0;
+    bool train = false;
+    uint32_t row0 = 0;       // position of this shard's first row inside its global minibatch: device generators are keyed by the
+                             // GLOBAL row position, so a sharded step draws exactly what the single-process step would draw
+    bool defer_dw = false;   // leave the output layer's dW kernel to ntf_dw_chunk (data-parallel overlap with the all-reduce)
+    bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
+    int part = 0;            // expert-sharded step: 1 = up to and including the output layer's backward, 2 = the hidden layers' backward (0 = whole step)
+};
+
 struct ntf_engine {
     ntf_config cfg{};
     hipStream_t st = nullptr;
@@ -85,6 +98,9 @@ struct ntf_engine {
     uint16_t* pl_mu = nullptr; uint16_t* pl_wp = nullptr;   // bf16 split planes of the output layer's mu / Wp (bf16x6 arithmetic)
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
+    // expert-sharded output layer (ntf_config.expert_lo ..): this engine owns experts [ep_lo, ep_lo + dims[L]) of Mg
+    bool ep = false; int ep_lo = 0, Mg = 0, ep_world = 1;
+    bool ep_open = false; StepCtx ep_ctx;   // between ntf_step_staged_ep phases 1 and 2
 };
 
 #define HIPCHK(e, call)                                                                                   \
@@ -184,6 +200,16 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
         if (l < e->L - 1) e->maxhid = std::max(e->maxhid, li.out);
     }
     e->n_params = off;
+    e->Mg = cfg->experts_global > 0 ? cfg->experts_global : cfg->dims[e->L];
+    e->ep_lo = cfg->expert_lo; e->ep_world = std::max(1, cfg->ep_world);
+    e->ep = cfg->experts_global > 0 || e->ep_lo != 0 || e->ep_world > 1;   // a shard may also be the whole layer (ep_world = 1)
+    if (e->ep) {
+        const char* bad = nullptr;
+        if (!fused_ok(e)) bad = "an expert-sharded output layer needs the fused output-layer path (fused = 1, h[-1] in {32, 64, 128})";
+        else if (e->ep_lo < 0 || (e->ep_lo & 255)) bad = "expert_lo must be a non-negative multiple of 256";
+        else if ((int64_t)e->ep_lo + cfg->dims[e->L] > e->Mg) bad = "expert_lo + dims[n_layers] exceeds experts_global";
+        if (bad) { g_create_error = bad; if (e->own_stream) hipStreamDestroy(e->st); delete e; return NTF_EINVAL; }
+    }
     const int B = cfg->max_batch, M = cfg->dims[e->L];
     int rc = NTF_OK;
     auto A = [&](int r) { if (rc == NTF_OK) rc = r; };
@@ -259,7 +285,7 @@ static int upload_csr(ntf_engine* e, const int64_t* indptr, const int32_t* indic
 }
 extern "C" int ntf_set_member_csr(ntf_engine* e, const int64_t* indptr, const int32_t* indices, int64_t n_rows) {
     if (!e) return NTF_EINVAL;
-    int r = upload_csr(e, indptr, indices, n_rows, &e->m_indptr, &e->m_indices, e->cfg.dims[e->L]);
+    int r = upload_csr(e, indptr, indices, n_rows, &e->m_indptr, &e->m_indices, e->Mg);   // labels keep GLOBAL expert ids on an expert shard
     if (r) return r;
     e->m_rows = n_rows;
     e->h_m_indptr.assign(indptr, indptr + n_rows + 1);
@@ -332,7 +358,7 @@ static int upload_alias(ntf_engine* e, const double* w, int64_t n) {
 }
 extern "C" int ntf_set_unigram(ntf_engine* e, const double* freq, int64_t n) {
     if (!e || !freq) return NTF_EINVAL;
-    if (n != e->cfg.dims[e->L]) FAIL(e, NTF_EINVAL, "unigram length != number of experts");
+    if (n != e->Mg) FAIL(e, NTF_EINVAL, "unigram length != number of experts (of the whole output layer)");
     for (int64_t i = 0; i < n; ++i) if (!(freq[i] >= 0)) FAIL(e, NTF_EINVAL, "unigram: negative or NaN weight");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     return upload_alias(e, freq, n);
@@ -420,17 +446,6 @@ extern "C" int ntf_range_fallbacks(ntf_engine* e, int64_t* steps) {
 }
 
 // ------------------------------------------------------------------------------------------ step
-struct StepCtx {
-    const int64_t* rows_dev = nullptr;
-    int B = 0; int global_B = 0;
-    const ntf_inject* inj = nullptr;
-    uint64_t step = 0;
-    bool train = false;
-    uint32_t row0 = 0;       // position of this shard's first row inside its global minibatch: device generators are keyed by the
-                             // GLOBAL row position, so a sharded step draws exactly what the single-process step would draw
-    bool defer_dw = false;   // leave the output layer's dW kernel to ntf_dw_chunk (data-parallel overlap with the all-reduce)
-    bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
-};
 
 // team ids a step may name: below the row count of EVERY resident matrix it reads (input source and, when set, the member CSR)
 static int64_t row_limit(const ntf_engine* e) {
@@ -466,6 +481,7 @@ static SignSpec sign_spec(ntf_engine* e, const StepCtx& c, int layer, int tensor
     s.inj = h ? inj : nullptr;
     make_key(e, c.step, layer, tensor, s.k0, s.k1);
     s.k0 += c.row0 * 0x9E3779B1u;  // sign_word(k0 + row0*phi, k1, r, .) == sign_word(k0, k1, r + row0, .): shifts the row index, kernels unchanged
+    if (e->ep && layer == e->L - 1 && tensor == T_S_OUT) s.k1 += (uint32_t)(e->ep_lo >> 5) * 0x85EBCA77u;   // likewise the column block: an expert shard draws the whole layer's signs
     return s;
 }
 static NormalSpec normal_spec(ntf_engine* e, const StepCtx& c, int layer, int tensor) {
@@ -475,6 +491,7 @@ static NormalSpec normal_spec(ntf_engine* e, const StepCtx& c, int layer, int te
     s.inj = h ? inj : nullptr;
     make_key(e, c.step, layer, tensor, s.k0, s.k1);
     s.tag = (uint32_t)(layer * 8 + tensor); s.step = (uint32_t)c.step;
+    if (e->ep && layer == e->L - 1) s.qbase = tensor == T_EPS_W ? (int64_t)e->ep_lo * e->layers[layer].in / 4 : e->ep_lo / 4;
     return s;
 }
 
@@ -550,10 +567,11 @@ static int forward_layers(ntf_engine* e, const StepCtx& c, bool want_logits, boo
         if (e->cfg.bayesian) {
             Scope t(e, F_FLIPOUT_OPERAND);
             const bool kl = !want_logits;  // loss steps: this layer's KL rides on the producer's pass over rho (and mu)
+            const double share = (e->ep && !last) ? 1.0 / (double)e->ep_world : 1.0;   // expert shards: a replicated layer's KL is counted once over the shards
             launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_WEIGHT], kl ? W : nullptr, li.nw(), normal_spec(e, c, l, T_EPS_W), e->Wp[l],
-                                   1.0 / (double)li.nw(), e->d_kl);
+                                   share / (double)li.nw(), e->d_kl);
             launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_BIAS], kl ? b : nullptr, li.out, normal_spec(e, c, l, T_EPS_B), e->bp[l],
-                                   1.0 / (double)li.out, e->d_kl);
+                                   share / (double)li.out, e->d_kl);
         }
         if (l == 0 && e->cfg.input_mode == NTF_INPUT_MULTIHOT) {
             Scope t(e, F_MULTIHOT);
@@ -595,7 +613,7 @@ static int sample_negatives(ntf_engine* e, const StepCtx& c) {
     if (c.inj && c.inj->neg_idx) return NTF_OK;  // staged already
     Scope t(e, F_SAMPLER);
     uint32_t k0, k1; make_key(e, c.step, 0, T_NEG, k0, k1);
-    const int M = e->cfg.dims[e->L];
+    const int M = e->Mg;   // negatives are drawn over the WHOLE output layer (an expert shard keeps the ones it owns, k_out_special)
     if (e->cfg.nsd == NTF_NSD_UNIFORM) {
         launch_ns_uniform(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
     } else if (e->cfg.nsd == NTF_NSD_UNIGRAM) {
@@ -664,13 +682,15 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const float inv_B = 1.0f / (float)c.global_B;
     const LayerInfo& lo = e->layers[e->L - 1];
     const bool fused = fused_ok(e);
+    const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
+    int nslots;
+    const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
+    if (c.part == 2) goto backward;   // expert-sharded step, second phase: the summed d(hidden) is in place
     if ((r = make_input(e, c))) return r;
     if ((r = sample_negatives(e, c))) return r;
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
     if (e->cfg.bayesian) HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 12, e->st));
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
-    const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
-    int nslots;
     if (fused) {
         if ((r = forward_layers(e, c, false, true))) return r;
         FusedOut f;
@@ -684,10 +704,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if (e->cfg.bayesian) {
             { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                     1.0 / (double)lo.nw(), e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));   // + the split planes of Wp and mu
+                                     1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));   // + the split planes of Wp and mu
               f.planes_ready = e->pl_wp != nullptr;
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
-                                     1.0 / (double)lo.out, e->d_kl); }
+                                     1.0 / out_nb, e->d_kl); }
             f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
             f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         }
@@ -696,6 +716,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.rflag = range_ptr(e);
         if (e->fwd_kernel >= 0) f.wide = e->fwd_kernel;   // A/B runs: NTF_FWD_KERNEL = 0, 1, 2 (ntf_fused.h), read when the engine is created
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
+        f.c_lo = e->ep_lo;
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
@@ -716,11 +737,13 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     }
     if (!c.train) return NTF_OK;
 
-    // ---------------- backward
+backward:
     const float kl_share = (float)B / (float)c.global_B;
     for (int l = e->L - 1; l >= 0; --l) {
         const LayerInfo& li = e->layers[l];
         const bool last = (l == e->L - 1);
+        if (c.part == 1 && !last) break;       // the hidden layers wait for the sum of d(hidden) over the expert shards
+        if (c.part == 2 && last) continue;
         const float* in = e->act[l];
         float* gW = e->G + li.off[NTF_P_WEIGHT]; float* gb = e->G + li.off[NTF_P_BIAS];
         float* gRW = e->cfg.bayesian ? e->G + li.off[NTF_P_RHO_WEIGHT] : nullptr;
@@ -739,11 +762,11 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             e->last_dz_packed_scale = f.dz_packed ? f.a_scale : 0.f;
             if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale,
                                                                                    f.dz_packed ? &sout_ : nullptr, f.s_out_inj); }
-            if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)li.nw() * (float)c.global_B); }
+            if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)out_nw * (float)c.global_B); }
             if (c.defer_dw) {
                 const int tile = fused_dw_tile(), total = (M + tile - 1) / tile;
                 e->pend = f; e->pend_valid = true; e->pend_chunks = (total + 255) / 256;
-                if (e->cfg.bayesian) { e->pend_eps_b = normal_spec(e, c, l, T_EPS_B); e->pend_klw_b = kl_share / ((float)li.out * (float)c.global_B); }
+                if (e->cfg.bayesian) { e->pend_eps_b = normal_spec(e, c, l, T_EPS_B); e->pend_klw_b = kl_share / ((float)out_nb * (float)c.global_B); }
                 continue;  // its bias-gradient finalisation follows the last chunk
             }
             if (c.fuse_adam && e->cfg.fuse_adam == 2) {
@@ -829,7 +852,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                 launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], gW, gRW, li.nw(),
                                              normal_spec(e, c, l, T_EPS_W), kl_share / ((float)li.nw() * (float)c.global_B));
             launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_BIAS], e->P + li.off[NTF_P_RHO_BIAS], gb, gRb, li.out,
-                                         normal_spec(e, c, l, T_EPS_B), kl_share / ((float)li.out * (float)c.global_B));
+                                         normal_spec(e, c, l, T_EPS_B), kl_share / ((last ? (float)out_nb : (float)li.out) * (float)c.global_B));
         }
     }
     return NTF_OK;
@@ -885,6 +908,10 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     int r;
     if ((r = check_ready(e, true))) return r;
     if (global_B < B) FAIL(e, NTF_EINVAL, "global_B < B");
+    if (train && e->ep && e->ep_world > 1)
+        FAIL(e, NTF_ESTATE, "expert-sharded engine: a train step needs the sum of d(hidden) over the shards - use ntf_step_staged_ep");
+    if (e->ep && global_B != B) FAIL(e, NTF_EINVAL, "expert-sharded engine: every shard steps the whole minibatch (global_B == B)");
+    e->ep_open = false;
     StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
     c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
     c.defer_dw = defer_dw && train && !apply && fused_ok(e);
@@ -1001,6 +1028,43 @@ extern "C" int ntf_dw_chunk(ntf_engine* e, int32_t k) {
     if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
     return NTF_OK;
 }
+// One train step of an expert-sharded engine in two phases (include/opentf_amd.h): between them the host sums d(hidden) over the shards.
+extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int32_t phase) {
+    if (!e) return NTF_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (!e->ep) FAIL(e, NTF_ESTATE, "step_staged_ep: the engine was not created as an expert shard (ntf_config.expert_lo / experts_global / ep_world)");
+    int r;
+    if (phase == 1) {
+        const int64_t n = (int64_t)e->h_order.size();
+        if (offset < 0 || B < 1 || offset + B > n) FAIL(e, NTF_EINVAL, "step_staged_ep: batch outside the staged order");
+        if ((r = check_ready(e, true))) return r;
+        StepCtx c; c.B = B; c.global_B = B; c.train = true; c.step = e->step++; c.part = 1;
+        c.fuse_adam = e->cfg.fuse_adam != 0;   // no gradient exchange for the output layer: its Adam may always ride in / beside the dW kernel
+        e->pend_valid = false; e->ep_open = false;
+        if ((r = stage_rows(e, e->d_order + offset, B, true, &c.rows_dev))) return r;
+        if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && (r = set_batch_unigram(e, e->h_order.data() + offset, B))) return r;
+        if ((r = run_step(e, c, true))) return r;
+        e->last_B = B; e->last_global_B = B;
+        e->ep_ctx = c; e->ep_open = true;
+    } else if (phase == 2) {
+        if (!e->ep_open) FAIL(e, NTF_ESTATE, "step_staged_ep: phase 2 without a pending phase 1");
+        StepCtx c = e->ep_ctx; c.part = 2;
+        e->ep_open = false;
+        if ((r = run_step(e, c, false))) return r;
+        if ((r = apply_adam(e))) return r;
+    } else FAIL(e, NTF_EINVAL, "step_staged_ep: phase must be 1 or 2");
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
+    return NTF_OK;
+}
+// where phase 1 leaves this shard's partial d(hidden) and phase 2 expects the sum: [B, h[-1]] floats (null when there is no hidden layer)
+extern "C" int ntf_dh_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats) {
+    if (!e || !dev_ptr || !n_floats) return NTF_EINVAL;
+    *dev_ptr = e->L > 1 ? e->dAct[(e->L - 1) & 1] : nullptr;
+    *n_floats = e->L > 1 ? (int64_t)e->cfg.max_batch * e->cfg.dims[e->L - 1] : 0;
+    return NTF_OK;
+}
+
 extern "C" int ntf_param_segment(ntf_engine* e, int layer, int kind, int64_t* off, int64_t* count) {
     if (!e || !off || !count) return NTF_EINVAL;
     return param_span(e, layer, kind, *off, *count);

@@ -21,6 +21,7 @@ struct FusedOut {
     // sparse fix-up
     const int64_t* rows = nullptr; const int64_t* m_indptr = nullptr; const int32_t* m_indices = nullptr;
     const int64_t* neg = nullptr; int ns = 0; float* row_fix = nullptr;
+    int c_lo = 0;                                   // expert shard of the output layer: m_indices / neg hold GLOBAL expert ids, mu .. are rows [c_lo, c_lo + M)
     // bf16x6 arithmetic (H = 128): scratch for the bf16 split planes of mu / Wp, fused_planes_elems(M, H) uint16 each
     int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
     int np = 3;                                     // 3: bf16x6, 2: fp16x3 (operands scaled by exact powers of two before their two-way fp16 split)

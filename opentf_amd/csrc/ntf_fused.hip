@@ -445,6 +445,7 @@ struct SpecialArgs {
     uint32_t so_k0, so_k1; int so_inj;
     float dz_pack_scale;   // > 0: dzT holds packed fp16 plane pairs of dz * scale (fp16x3 step) ... unless *rflag is raised (the f32 kernels ran)
     const int* rflag;
+    int c_lo;              // expert shard: labels and negatives name GLOBAL expert ids, this launch owns [c_lo, c_lo + M)
 };
 
 // One wave per team.  H = 128: the wave works as FOUR quarter-waves of 16 lanes x 8 consecutive hidden units, each quarter taking every fourth
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
             for (int k = 0; k < npos; ++k) if (p.m_indices[pb + k] == c) c = -1;
             for (int k = 0; k < qn; ++k) if (c >= 0 && (int)p.neg[(int64_t)i * p.ns + k] == c) c = -1;
         }
+        if (c >= 0) c -= p.c_lo;                   // global -> this shard's expert index (entries of other shards fall outside [0, M))
         const bool live = c >= 0 && c < p.M;
         const int cc = live ? c : 0;
         float mu_r[NV], wp_r[NV], d1 = 0.f, d2 = 0.f;
@@ -2064,7 +2066,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.sbits = sbits; s.sinbits = sinbits; s.rows = f.rows; s.m_indptr = f.m_indptr; s.neg = f.neg; s.m_indices = f.m_indices;
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
-    s.dz_pack_scale = (f.train && f.bf16x6 && f.H == 128 && f.np == 2) ? f.dz_scale : 0.f; s.rflag = f.rflag;
+    s.dz_pack_scale = (f.train && f.bf16x6 && f.H == 128 && f.np == 2) ? f.dz_scale : 0.f; s.rflag = f.rflag; s.c_lo = f.c_lo;
     const int grid = g.NRB * g.NCG;
     if (f.bf16x6 && f.H == 128) {
         const int np = f.np == 2 ? 2 : 3;

@@ -20,6 +20,7 @@ struct SignSpec {
 struct NormalSpec {
     const float* inj = nullptr;
     uint32_t k0 = 0, k1 = 0, tag = 0, step = 0;
+    int64_t qbase = 0;   // generator index of the tensor's first group of four: an expert shard of the output layer draws what the whole layer would draw
 };
 
 struct GemmArgs {

@@ -29,7 +29,8 @@ class ntf_config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p), ("n_layers", C.c_int32),
                 ("dims", C.c_int32 * (NTF_MAX_LAYERS + 1)), ("bayesian", C.c_int32), ("input_mode", C.c_int32),
                 ("max_batch", C.c_int32), ("ns", C.c_int32), ("nsd", C.c_int32), ("tpw", C.c_float), ("tnw", C.c_float),
-                ("lr", C.c_float), ("seed", C.c_uint64), ("fused", C.c_int32), ("fuse_adam", C.c_int32), ("mfma", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("lr", C.c_float), ("seed", C.c_uint64), ("fused", C.c_int32), ("fuse_adam", C.c_int32), ("mfma", C.c_int32),
+                ("expert_lo", C.c_int32), ("experts_global", C.c_int32), ("ep_world", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class ntf_inject(C.Structure):
@@ -73,6 +74,8 @@ SYMBOLS = {
     "ntf_dw_chunk_range": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "ntf_dw_chunk": (C.c_int, [_P, _I32]),
     "ntf_param_segment": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_I64), C.POINTER(_I64)]),
+    "ntf_step_staged_ep": (C.c_int, [_P, _I64, _I32, _I32]),
+    "ntf_dh_buffer": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(_I64)]),
     "ntf_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P]),
     "ntf_logits": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_forward_topk": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
@@ -135,11 +138,20 @@ class DeviceView:
 
 
 class Engine:
-    """One Fnn/Bnn model resident on one MI355X.  dims = [D, *h, M]."""
+    """One Fnn/Bnn model resident on one MI355X.  dims = [D, *h, M].
+    expert_shard = (lo, hi), ep_world = G: this engine owns the experts [lo, hi) of the output layer only (one of G such engines, one per GPU;
+    hidden layers replicated; see ntf_config.expert_lo in include/opentf_amd.h and opentf_amd/ep.py).  `dims[-1]` then is hi - lo, `experts_global` is M."""
 
     def __init__(self, dims, bayesian=False, input_mode=INPUT_DENSE, max_batch=1000, ns=5, nsd="uniform", tpw=10.0, tnw=1.0,
-                 lr=1e-3, seed=0, device=0, stream=None, fused=True, fuse_adam=False, mfma=None):
+                 lr=1e-3, seed=0, device=0, stream=None, fused=True, fuse_adam=False, mfma=None, expert_shard=None, ep_world=1):
         self.dims = [int(d) for d in dims]
+        self.experts_global = self.dims[-1]
+        self.expert_lo, self.ep_world = 0, int(ep_world)
+        if expert_shard is not None:
+            lo, hi = (int(v) for v in expert_shard)
+            if not 0 <= lo < hi <= self.experts_global:
+                raise NtfError(f"expert_shard {expert_shard} outside [0, {self.experts_global})")
+            self.expert_lo, self.dims[-1] = lo, hi - lo
         self.L = len(self.dims) - 1
         if not 1 <= self.L <= NTF_MAX_LAYERS:
             raise NtfError("between 1 and 8 layers supported")
@@ -154,6 +166,8 @@ class Engine:
         cfg.ns, cfg.nsd, cfg.tpw, cfg.tnw, cfg.lr, cfg.seed, cfg.fused = max(self.ns, 0), NSD[nsd], float(tpw), float(tnw), float(lr), int(seed) & (2**64 - 1), int(bool(fused))
         cfg.mfma = {None: 0, "default": 0, "f32": 1, "bf16x6": 2, "fp16x3": 3}[mfma] if not isinstance(mfma, int) or isinstance(mfma, bool) else int(mfma)
         cfg.fuse_adam = int(fuse_adam)  # 0: flat Adam kernel; 1: inside the dW epilogue; 2: chunked beside the dW kernel on a side stream
+        if expert_shard is not None or self.ep_world > 1:
+            cfg.expert_lo, cfg.experts_global, cfg.ep_world = self.expert_lo, self.experts_global, self.ep_world
         self.stream_handle = stream   # the caller's hipStream_t (int) the engine runs on, None: a stream of its own
         self._h = C.c_void_p()
         rc = lib().ntf_engine_create(C.byref(cfg), C.byref(self._h))
@@ -225,6 +239,8 @@ class Engine:
             for name, kind in self._kinds():
                 a = sd[f"layers.{l}.{name}"]
                 a = _f32(a.detach().cpu().numpy() if hasattr(a, "detach") else a)
+                if l == self.L - 1 and a.shape[0] == self.experts_global != self.dims[-1]:   # an expert shard takes its rows of the whole layer
+                    a = _f32(a[self.expert_lo: self.expert_lo + self.dims[-1]])
                 if a.shape != self._shape(l, kind):
                     raise NtfError(f"layers.{l}.{name}: shape {a.shape} != {self._shape(l, kind)}")
                 self._ck(lib().ntf_set_param(self._h, l, kind, _ptr(a), a.size))
@@ -342,6 +358,19 @@ class Engine:
                                        int(B if global_B is None else global_B), int(train), int(apply), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
 
+    # ---- expert-sharded output layer (see include/opentf_amd.h, opentf_amd/ep.py)
+    def step_staged_ep(self, offset, B, phase):
+        self._ck(lib().ntf_step_staged_ep(self._h, int(offset), int(B), int(phase)))
+
+    def dh_tensor(self):
+        """torch tensor aliasing the [max_batch * h[-1]] buffer of d(hidden): phase 1 leaves this shard's partial sum there, phase 2 reads the total"""
+        import torch
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(lib().ntf_dh_buffer(self._h, C.byref(p), C.byref(n)))
+        if not n.value:
+            return None
+        return torch.as_tensor(DeviceView(p.value, n.value, self), device=f"cuda:{torch.cuda.current_device()}")
+
     # ---- data-parallel pipelining (see include/opentf_amd.h)
     def step_staged_deferred(self, offset, B, global_offset, global_B):
         self._ck(lib().ntf_step_staged_deferred(self._h, int(offset), int(B), int(global_offset), int(global_B), None))
@@ -358,6 +387,12 @@ class Engine:
 
     def dw_chunk(self, k):
         self._ck(lib().ntf_dw_chunk(self._h, int(k)))
+
+    def param_segment(self, layer, kind):
+        """(offset, count) in floats of a parameter inside the flat parameter / gradient buffers"""
+        o, c = C.c_int64(), C.c_int64()
+        self._ck(lib().ntf_param_segment(self._h, int(layer), int(kind), C.byref(o), C.byref(c)))
+        return o.value, c.value
 
     def rest_ranges(self):
         """[lo, hi) float ranges of the flat gradient buffer outside the output layer's weight / rho_weight segments."""

@@ -1,0 +1,159 @@
+"""Expert-sharded output layer (opentf_amd/ep.py, ntf_step_staged_ep): G engines, each owning a contiguous range of experts, emulated on ONE
+GPU (the exchange - the sum of d(hidden) over the shards - is done with torch here, by RCCL in production).  The contract under test: with
+the NATIVE generators (keyed by global expert ids) the shards together compute the step one engine holding the whole layer computes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from opentf_amd.ep import expert_shards                      # noqa: E402
+from opentf_amd.synth import make_dataset, init_params       # noqa: E402
+
+
+def _mk(ds, dims, bayesian, B, nsd, shard=None, world=1, fuse_adam=1, multihot=False, seed=5, mfma=None):
+    from opentf_amd import libntf
+    mode = libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL
+    e = libntf.Engine(dims, bayesian=bayesian, input_mode=mode, max_batch=B, ns=5, nsd=nsd, tpw=10.0, tnw=1.0, lr=1e-3, seed=seed,
+                      fuse_adam=fuse_adam, expert_shard=shard, ep_world=world, mfma=mfma)
+    if not multihot: e.set_skill_table(ds["table"])
+    e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
+    e.load_state_dict(init_params(dims, bayesian, 0))
+    if nsd == "unigram":
+        e.set_unigram(np.bincount(ds["member"][1], minlength=ds["M"]) / ds["N"])
+    return e
+
+
+def _ep_epoch(engines, order, B, train=True):
+    import torch
+    for e in engines:
+        e.stage_order(order); e.epoch_loss()
+    H = engines[0].dims[-2]
+    for off in range(0, len(order), B):
+        b = min(B, len(order) - off)
+        if not train:
+            for e in engines: e.step_staged(off, b, train=False, apply=False)
+            continue
+        for e in engines:
+            e.step_staged_ep(off, b, 1); e.synchronize()
+        dh = [e.dh_tensor() for e in engines]
+        if dh[0] is not None:
+            tot = torch.stack([d[: b * H] for d in dh]).sum(0)
+            for d in dh: d[: b * H].copy_(tot)
+            torch.cuda.synchronize()
+        for e in engines: e.step_staged_ep(off, b, 2)
+    return sum(e.epoch_loss()[0] for e in engines)
+
+
+def _full_epoch(e, order, B, train=True):
+    e.stage_order(order); e.epoch_loss()
+    for off in range(0, len(order), B):
+        b = min(B, len(order) - off)
+        e.step_staged(off, b, train=train, apply=train)
+    return e.epoch_loss()[0]
+
+
+def _gathered(engines, exact_replicas=True):
+    sds = [e.state_dict() for e in engines]
+    last = f"layers.{engines[0].L - 1}."
+    out = {}
+    for k in sds[0]:
+        if k.startswith(last): out[k] = np.concatenate([sd[k] for sd in sds])
+        else:
+            for sd in sds[1:]:
+                if exact_replicas: assert np.array_equal(sd[k], sds[0][k]), f"replicated {k} differs between shards"
+                else: np.testing.assert_allclose(sd[k], sds[0][k], rtol=1e-5, atol=1e-6, err_msg=k)
+            out[k] = sds[0][k]
+    return out
+
+
+CASES = {
+    # name: (bayesian, dims builder, nsd, G, B, multihot)
+    "bnn_uniform_g3": (True, lambda ds: [128, 128, ds["M"]], "uniform", 3, 256, False),
+    "fnn_uniform_g2": (False, lambda ds: [128, 128, ds["M"]], "uniform", 2, 256, False),
+    "bnn_unigram_g4": (True, lambda ds: [128, 128, ds["M"]], "unigram", 4, 200, False),
+    "bnn_unigram_b_g2": (True, lambda ds: [128, 128, ds["M"]], "unigram_b", 2, 200, False),
+    "bnn_two_hidden_h64_g2": (True, lambda ds: [128, 96, 64, ds["M"]], "uniform", 2, 200, False),
+    "bnn_multihot_g2": (True, lambda ds: [ds["S"], 128, ds["M"]], "uniform", 2, 200, True),
+    "bnn_no_hidden_g2": (True, lambda ds: [128, ds["M"]], "uniform", 2, 200, False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_expert_shards_compute_the_single_engine_step(case):
+    bayesian, mkdims, nsd, G, B, multihot = CASES[case]
+    ds = make_dataset("dblp", d=128, seed=3, n_rows=1500, n_experts=3000)
+    dims = mkdims(ds)
+    order = np.random.default_rng(4).permutation(ds["N"])[: 2 * B + 77].astype(np.int64)    # two full batches and a ragged one
+    shards = expert_shards(ds["M"], G)
+    assert shards[0][0] == 0 and shards[-1][1] == ds["M"] and all(a[1] == b[0] and a[1] % 256 == 0 for a, b in zip(shards, shards[1:]))
+    full = _mk(ds, dims, bayesian, B, nsd, multihot=multihot)
+    eng = [_mk(ds, dims, bayesian, B, nsd, shard=s, world=G, multihot=multihot) for s in shards]
+
+    # --- first step: the output layer sees bit-identical operands on both sides
+    l_full = _full_epoch(full, order[:B], B); l_ep = _ep_epoch(eng, order[:B], B)
+    assert abs(l_ep - l_full) <= 2e-6 * abs(l_full), (l_ep, l_full)
+    # replicas of the hidden layers stay bit-identical (same summed d(hidden), deterministic kernels) - except behind the multi-hot first
+    # layer, whose weight gradient is a scatter-add by float atomics (ExpertParallel re-broadcasts the replicated parameters every epoch)
+    a, b = _gathered(eng, exact_replicas=not multihot), full.state_dict()
+    last = f"layers.{full.L - 1}."
+    for k in b:
+        if k.startswith(last): assert np.array_equal(a[k], b[k]), f"{k}: the shards' first update differs from the single engine's"
+        else: np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=2e-6, err_msg=k)   # d(hidden) is summed in another order
+
+    # --- a short epoch on top, then an evaluation phase
+    l_full = _full_epoch(full, order, B); l_ep = _ep_epoch(eng, order, B)
+    assert abs(l_ep - l_full) <= 1e-5 * abs(l_full), (l_ep, l_full)
+    a, b = _gathered(eng, exact_replicas=not multihot), full.state_dict()
+    for k in b:
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=2e-5, err_msg=k)
+    v_full = _full_epoch(full, order[:300], B, train=False); v_ep = _ep_epoch(eng, order[:300], B, train=False)
+    assert abs(v_ep - v_full) <= 1e-5 * abs(v_full), (v_ep, v_full)
+    for e in eng + [full]: e.close()
+
+
+def test_one_shard_of_world_one_is_the_plain_engine():
+    """expert_shard = the whole layer, ep_world = 1: both the ordinary step and the two-phase step are the plain engine's step, bit for bit"""
+    ds = make_dataset("dblp", d=128, seed=1, n_rows=600, n_experts=1000)
+    dims = [128, 128, ds["M"]]
+    order = np.arange(512, dtype=np.int64)
+    plain, one, two = _mk(ds, dims, True, 256, "uniform"), _mk(ds, dims, True, 256, "uniform", shard=(0, ds["M"])), _mk(ds, dims, True, 256, "uniform", shard=(0, ds["M"]))
+    lp, lo, lt = _full_epoch(plain, order, 256), _full_epoch(one, order, 256), _ep_epoch([two], order, 256)
+    assert lp == lo == lt
+    sp, so, st = plain.state_dict(), one.state_dict(), two.state_dict()
+    for k in sp: assert np.array_equal(sp[k], so[k]) and np.array_equal(sp[k], st[k]), k
+
+
+def test_expert_shard_contract_errors():
+    from opentf_amd import libntf
+    ds = make_dataset("dblp", d=128, seed=1, n_rows=300, n_experts=1000)
+    with pytest.raises(libntf.NtfError, match="multiple of 256"):
+        _mk(ds, [128, 128, ds["M"]], True, 64, "uniform", shard=(100, 1000), world=2)
+    with pytest.raises(libntf.NtfError, match="fused output-layer path"):
+        _mk(ds, [128, 48, ds["M"]], True, 64, "uniform", shard=(0, 512), world=2)
+    e = _mk(ds, [128, 128, ds["M"]], True, 64, "uniform", shard=(0, 512), world=2)
+    e.stage_order(np.arange(64, dtype=np.int64))
+    with pytest.raises(libntf.NtfError, match="ntf_step_staged_ep"):
+        e.step_staged(0, 64, train=True, apply=True)           # a train step of one shard alone would use a partial d(hidden)
+    with pytest.raises(libntf.NtfError, match="phase 2 without"):
+        e.step_staged_ep(0, 64, 2)
+    e.step_staged(0, 64, train=False, apply=False)              # evaluation needs no exchange
+    plain = _mk(ds, [128, 128, ds["M"]], True, 64, "uniform")
+    plain.stage_order(np.arange(64, dtype=np.int64))
+    with pytest.raises(libntf.NtfError, match="not created as an expert shard"):
+        plain.step_staged_ep(0, 64, 1)
+
+
+def test_wide_minibatch_on_a_narrow_shard():
+    """what one rank of eight runs at BASELINE config 2 in miniature: many row blocks (B = 2000) against few expert tiles; fused == generic path"""
+    ds = make_dataset("dblp", d=128, seed=2, n_rows=4000, n_experts=2048)
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(0).permutation(ds["N"])[:2000].astype(np.int64)
+    shards = expert_shards(ds["M"], 4)
+    full = _mk(ds, dims, True, 2000, "uniform")
+    eng = [_mk(ds, dims, True, 2000, "uniform", shard=s, world=4) for s in shards]
+    l_full, l_ep = _full_epoch(full, order, 2000), _ep_epoch(eng, order, 2000)
+    assert abs(l_ep - l_full) <= 2e-6 * abs(l_full)
+    a, b = _gathered(eng), full.state_dict()
+    for k in b:
+        if k.startswith("layers.1."): assert np.array_equal(a[k], b[k]), k
+        else: np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=2e-6, err_msg=k)
