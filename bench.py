@@ -53,6 +53,12 @@ def parse():
     ap.add_argument("--gather-only", action="store_true", help="run only the whole-dataset gather launches (the PMC passes of the gather roofline)")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the short exact-f32 (--mfma f32) measurement printed beside the default line")
     ap.add_argument("--force-dist", action="store_true", help="init RCCL and all-reduce the gradient buffer even at world_size 1 (validation)")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "dp"],
+                    help="N > 1: ep = expert-sharded output layer (every GPU steps the whole global minibatch on its 1/N of the experts; the only exchange is "
+                         "d(hidden), opentf_amd/ep.py); dp = rows split over GPUs, gradients reduce-scattered (opentf_amd/dp.py); auto = ep when the model shards")
+    ap.add_argument("--ep-emulate", type=int, default=0, metavar="G",
+                    help="N = 1 only: run what ONE rank of G runs under --parallel ep (its 1/G of the experts, a global minibatch of G * --batch teams, two-phase "
+                         "step, no exchange) - the per-rank compute time behind the scaling projection in DESIGN.md; not the headline")
     return ap.parse_args()
 
 
@@ -122,11 +128,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.force_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ["NTF_DP_FORCE_ALLREDUCE"] = "1"
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ["NTF_DP_FORCE_ALLREDUCE"] = "1"; os.environ["NTF_EP_FORCE_EXCHANGE"] = "1"
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
     from opentf_amd import libntf
     from opentf_amd.dp import DataParallel
+    from opentf_amd.ep import ExpertParallel, expert_shards, can_shard
     from opentf_amd.synth import make_dataset, init_params
 
     bayesian = a.model == "bnn"
@@ -134,11 +141,20 @@ def main():
     multihot = a.input == "multihot"
     dims = [ds["S"] if multihot else a.d, a.hidden, ds["M"]]
     cfg = {"ns": 5, "nsd": a.nsd, "tpw": 10.0, "tnw": 1.0, "lr": 1e-3}
+    if a.ep_emulate and world > 1: raise SystemExit("--ep-emulate is a single-GPU measurement")
+    G = a.ep_emulate if a.ep_emulate else world
+    par = "dp"
+    if (G > 1 or (a.force_dist and a.parallel == "ep")) and not a.no_fused and a.parallel != "dp":
+        if can_shard(dims, G): par = "ep"
+        elif a.parallel == "ep": raise SystemExit(f"--parallel ep: {dims} does not shard over {G} GPUs (needs h[-1] in 32/64/128 and >= {G} tiles of 256 experts)")
+    ep = par == "ep"
+    shard = expert_shards(dims[-1], G)[0 if a.ep_emulate else rank] if ep else None
+    eB = a.batch * G if ep else a.batch                     # rows one engine steps: under ep every rank steps the whole global minibatch
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
+        e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=eB, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
                           lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
-                          fuse_adam=a.fuse_adam if world == 1 else 0, mfma=a.mfma)
+                          fuse_adam=a.fuse_adam if (world == 1 or ep) else 0, mfma=a.mfma, expert_shard=shard, ep_world=G if ep else 1)
         if not multihot: e.set_skill_table(ds["table"])
         e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
         e.load_state_dict(init_params(dims, bayesian, 0))
@@ -149,8 +165,8 @@ def main():
             e.synchronize()
             print(json.dumps({"gather_only": True, "teams": ds["N"]}), file=real_stdout, flush=True)
             return
-        dp = DataParallel(e)
-        gB = a.batch * world                                   # weak scaling: B teams per GPU
+        dp = ExpertParallel(e, two_phase=bool(a.ep_emulate)) if ep else DataParallel(e)
+        gB = a.batch * G                                       # weak scaling: B teams per GPU
         rng = np.random.default_rng(7)
         total_steps = a.warmup + a.steps
         order = rng.integers(0, ds["N"], total_steps * gB).astype(np.int64)   # the loader's shuffled row order
@@ -175,7 +191,7 @@ def main():
         dt = float(t.item())
 
         gather = None
-        if (a.gather_bench or (world == 1 and not a.no_gather_bench)) and rank == 0 and not multihot:
+        if (a.gather_bench or (world == 1 and not a.no_gather_bench and not a.ep_emulate)) and rank == 0 and not multihot:
             e.kernel_times(enable=True)
             n = ds["N"]
             e.gather_meanpool(n=n, to_host=False); e.kernel_times(enable=True)
@@ -202,7 +218,7 @@ def main():
             gather["note"] = "achieved = algorithmic bytes (SURVEY 8d: nnz*(4d+4)+8+4d per team) / time; the table rows are served on-die, so the roof is not the HBM peak (peak_def)"
 
     exact_f32 = None
-    if world == 1 and a.mfma == "default" and not a.no_f32_line and not a.no_fused:
+    if world == 1 and a.mfma == "default" and not a.no_f32_line and not a.no_fused and not a.ep_emulate:
         # the same workload on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32, a bit-exact f32 fma chain): quoted beside the fp16x3 headline
         with torch.cuda.stream(stream):
             e.close()
@@ -223,7 +239,8 @@ def main():
         return
     if a.force_dist and world == 1: dist.destroy_process_group()
     B, H, M = a.batch, a.hidden, ds["M"]
-    gemm = 2.0 * B * H * M  # one [B,H]x[H,M]-sized product
+    Mloc = (shard[1] - shard[0]) if ep else M                # experts this GPU's kernels cover, over eB rows
+    gemm = 2.0 * eB * H * Mloc  # one [rows,H]x[H,experts]-sized product of a launch
     k = 2 if bayesian else 1
     # per timed scope: the unfused families launch one GEMM per Flipout half (k launches), the fused ones a single kernel
     flops_per_launch = {"out_fwd_gemm": k * gemm, "out_bwd_dw_gemm": k * gemm, "out_bwd_da_gemm": k * gemm,
@@ -251,12 +268,19 @@ def main():
         "vs_baseline": None, "dtype": {"f32": "f32", "bf16x6": "f32 (bf16x6 split products, f32 accumulate)"}.get(a.mfma, "f32 (fp16x3 split products, f32 accumulate)"), "data": "synthetic",
         "config": {"workload": f"{a.dataset} mt10.ts2 shapes N={ds['N']} S={ds['S']} M={M}; {a.model}{' (Flipout)' if bayesian else ''} on " +
                                (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
-                               f"h=[{H}], b={B}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3", "global_batch": gB, "parallelism": f"dp{world}"},
+                               f"h=[{H}], b={B}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3", "global_batch": gB,
+                   "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else f"dp{world}")},
         "roofline": roof, "cpu_baseline": None, "exact_f32_mfma": exact_f32, "mean_loss": mean_loss,
         "kernel_ms_per_step": breakdown, "kernel_ms_note": "separate pass of %d steps with events around every kernel family; the timed region carries events around the two output-layer kernels only" % k3,
     }
     if gather: out["roofline_gather"] = gather
-    if world == 1 and not a.no_cpu_baseline and not multihot:   # the CPU leg times the headline (mean-pool) configuration only
+    if a.ep_emulate:
+        # one rank of G: it processed the whole global minibatch on 1/G of the experts, i.e. 1/G of the job
+        out["metric"] += f" [one rank of {G} under --parallel ep, emulated on one GPU without the exchange]"
+        out["value"] = a.steps * a.batch / dt; out["n_gpus"] = 1
+        out["ep_emulation"] = {"G": G, "experts": [int(shard[0]), int(shard[1])], "rows_per_step": gB, "ms_per_step": dt / a.steps * 1e3,
+                               "projected_teams_per_s_at_G_gpus": a.steps * gB / dt, "note": "projection = G * this rank's rate; excludes the 4*B*h[-1]-byte all-reduce per step"}
+    if world == 1 and not a.no_cpu_baseline and not multihot and not a.ep_emulate:   # the CPU leg times the headline (mean-pool) configuration only
         out["cpu_baseline"] = cpu_baseline(ds, dims, bayesian, cfg)
     if world > 1: dist.destroy_process_group()   # before the JSON line: RCCL prints its version banner when the group goes away
     sys.stdout.flush(); sys.stderr.flush()

@@ -76,6 +76,7 @@ struct ntf_engine {
     float* gemm_slab = nullptr;       // split-K partial sums of the generic GEMM
     double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
     int fwd_kernel = -1;
+    int dw_ksplit = 0;                // 0: automatic (few expert tiles -> split the dW kernel's K range), else forced (NTF_DW_KSPLIT)
     int32_t* d_range = nullptr;       // fp16x3 range guard (lives behind d_kl[0]): [0] raised for the current step, [1] steps that fell back to the f32 kernels
     int64_t range_fallbacks_host = 0; // inference calls redone on the generic path for the same reason
     float* tk_vals = nullptr; int32_t* tk_idx = nullptr; int64_t tk_cap = 0;
@@ -186,6 +187,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->lr = cfg->lr;
     e->seed = cfg->seed;
     if (const char* fk = getenv("NTF_FWD_KERNEL")) e->fwd_kernel = atoi(fk);
+    if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
     int64_t off = 0;
@@ -760,6 +762,14 @@ backward:
             f.np = mfma_np(e); f.a_scale = dz_scale16(e, c.global_B); f.h_scale = kH16Scale; f.rflag = range_ptr(e);
             f.dz_packed = f.bf16x6 && f.np == 2 && li.in == 128 && e->pl_mu != nullptr;   // the fp16x3 forward kernels (H = 128) store packed plane pairs
             e->last_dz_packed_scale = f.dz_packed ? f.a_scale : 0.f;
+            if (f.dz_packed && !c.defer_dw && !(c.fuse_adam && e->cfg.fuse_adam == 2)) {
+                // few expert tiles (a narrow expert shard under a wide minibatch, or a small model) leave most CUs idle at one workgroup per 256 experts:
+                // split every tile's K (batch) range over several workgroups.  Scratch: the dense-logits buffer of the generic path, idle in a fused step.
+                const int tiles = (M + fused_dw_tile() - 1) / fused_dw_tile(), nib = fused_ldb(B) / 32;
+                int ks = e->dw_ksplit > 0 ? e->dw_ksplit : (tiles <= 128 ? std::min({256 / tiles, 8, std::max(1, nib / 4)}) : 1);
+                while (ks > 1 && fused_dw_part_floats(M, li.in, ks) > (int64_t)e->cfg.max_batch * M) --ks;
+                if (ks > 1) { f.ksplit = ks; f.part = e->Zout; }
+            }
             if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale,
                                                                                    f.dz_packed ? &sout_ : nullptr, f.s_out_inj); }
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)out_nw * (float)c.global_B); }

@@ -55,6 +55,8 @@ struct FusedDw {
     int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the expert tiles [wg_begin, wg_begin + wg_count) of fused_dw_tile() experts each
     int* rflag = nullptr;                           // fp16x3 range guard, see FusedOut
     int dz_packed = 0;                              // np = 2, H = 128: dzT holds the forward kernel's packed fp16 plane pairs (see pack_planes)
+    int ksplit = 1; float* part = nullptr;          // dz_packed path, whole-layer launch: split every expert tile's K (batch) range over ksplit workgroups; part = scratch
+                                                    // of fused_dw_part_floats(M, H, ksplit) floats.  For few expert tiles (a narrow expert shard under a wide minibatch).
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
 };
@@ -65,6 +67,7 @@ int64_t fused_dh_slab_floats(int B, int H, int M);
 size_t fused_workspace_bytes(int B, int H, int M);
 int fused_ldb(int B);
 int64_t fused_planes_elems(int M, int H);   // uint16 elements of one matrix's split planes
+int64_t fused_dw_part_floats(int M, int H, int ksplit);
 int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are padded to a multiple of it)
 // phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);

@@ -29,6 +29,7 @@ constexpr int DW_TC = 32 * DW_WAVES;      // experts per workgroup of the dW ker
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 int fused_ldb(int B) { return rup(B, BM); }
 int fused_dw_tile() { return DW_TC; }
+int64_t fused_dw_part_floats(int M, int H, int ksplit) { return (int64_t)ksplit * 2 * ((int64_t)rup(M, DW_TC) * (H + 1)); }
 int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 63) / 64 * 64 * H * 3; }   // rows padded to the 64-expert tile of k_out_fwd_h3w
 bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
 int fused_loss_slots(int) { return 0; }
@@ -578,6 +579,9 @@ struct DwArgs {
     int ablate;              // diagnostics (NTF_DW_ABLATE): 1 no epilogue memory traffic, 2 no MFMAs, 4 no DMA after the first K block, 8 no barrier waits on DMA
     const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
+    // split-K (k_out_dw_p2 only): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
+    // contiguous part of the K blocks into part[(split * 2 + matrix) * slab ..] (bias sums behind the slabs); k_out_dw_finish adds the parts and runs the epilogue
+    int ksplit; float* part; int64_t slab;
 };
 
 // N consecutive floats (N = 1, 2, 4) as one access
@@ -1021,6 +1025,69 @@ __global__ __launch_bounds__(256) void k_sign_words_T(const uint32_t* __restrict
     }
 }
 
+// Epilogue of the output layer's dW for N consecutive hidden units of one expert (idx0 = expert * H + first unit), from the finished sums s1 = dz^T h and
+// s2 = (dz s_out)^T (h s_in): Flipout chain rule for rho (eps recovered as Wp / sigma) + the KL terms, then either the gradients or, with ADAM, the update in place.
+template <bool BAYES, bool ADAM, int N>
+__device__ __forceinline__ void dw_finish_vec(const DwArgs& p, int64_t idx0, const float (&s1)[N], const float (&s2)[N]) {
+    float v_rho[N], v_mu[N], v_wp[N], o_mu[N], o_rho[N];
+    if (BAYES) { ld_vec<N>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<N>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<N>(p.wp + idx0, v_wp); }
+    else if (ADAM) ld_vec<N>(p.w_mu + idx0, v_mu);
+    float a_m1[N], a_v1[N], a_m2[N], a_v2[N];
+    if (ADAM) { ld_vec<N>(p.m_mu + idx0, a_m1); ld_vec<N>(p.v_mu + idx0, a_v1); if (BAYES) { ld_vec<N>(p.m_rho + idx0, a_m2); ld_vec<N>(p.v_rho + idx0, a_v2); } }
+#pragma unroll
+    for (int jt = 0; jt < N; ++jt) {
+        float gm = s1[jt], gr = 0.f, pm = 0.f, rh = 0.f;
+        if (BAYES) {
+            rh = v_rho[jt];
+            pm = v_mu[jt];
+            const float w = v_wp[jt];
+            const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
+            const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
+            const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
+            gm += p.klw * pm;
+            gr = s2[jt] * (w * isig) * sg + p.klw * (sigma - isig) * sg;
+        } else if (ADAM) pm = v_mu[jt];
+        o_mu[jt] = gm; o_rho[jt] = gr;
+        if (ADAM) {   // in place: the updated parameter goes where the gradient would have gone
+            o_mu[jt] = adam_update(pm, gm, a_m1[jt], a_v1[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+            if (BAYES) o_rho[jt] = adam_update(rh, gr, a_m2[jt], a_v2[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+        }
+    }
+    if (!ADAM) { st_vec<N>(p.g_mu + idx0, o_mu); if (BAYES) st_vec<N>(p.g_rho + idx0, o_rho); }
+    else {
+        st_vec<N>(p.w_mu + idx0, o_mu); st_vec<N>(p.m_mu + idx0, a_m1); st_vec<N>(p.v_mu + idx0, a_v1);
+        if (BAYES) { st_vec<N>(p.w_rho + idx0, o_rho); st_vec<N>(p.m_rho + idx0, a_m2); st_vec<N>(p.v_rho + idx0, a_v2); }
+    }
+}
+
+// split-K dW: sum of the K ranges' partial slabs, then the epilogue (one thread per four hidden units; the first M threads also finish the bias gradients)
+template <bool BAYES, bool ADAM>
+__global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
+    if (p.rflag && *p.rflag) return;           // an operand left the fp16 window: the exact-f32 dW kernel (unsplit, own epilogue) ran instead
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, idx0 = q * 4;
+    const int64_t Mp = p.slab / 128;
+    if (q < p.M) {
+        const float* pb = p.part + (int64_t)p.ksplit * 2 * p.slab;
+        float b1 = 0.f, b2 = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) { b1 += pb[(int64_t)(s * 2) * Mp + q]; if (BAYES) b2 += pb[(int64_t)(s * 2 + 1) * Mp + q]; }
+        p.g_b[q] = b1; if (BAYES) p.g_bp[q] = b2;
+    }
+    if (idx0 >= (int64_t)p.M * 128) return;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s) {
+        float t[4];
+        ld_vec<4>(p.part + (int64_t)(s * 2) * p.slab + idx0, t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s1[k] += t[k];
+        if (BAYES) {
+            ld_vec<4>(p.part + (int64_t)(s * 2 + 1) * p.slab + idx0, t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s2[k] += t[k];
+        }
+    }
+    dw_finish_vec<BAYES, ADAM, 4>(p, idx0, s1, s2);
+}
+
 // dW of the fp16x3 training step (H = 128).  Same tiling as k_out_dw_b6 (8 waves x 32 experts, K = batch in 32-row blocks, two LDS stages by LDS-DMA),
 // but the A operand arrives READY: dzT holds the two fp16 planes of dz * scale packed per element by the forward kernel, so a lane's fragment is two
 // ds_read_b128 + eight v_perm_b32 instead of an f32 split (the round-1 kernel spent a third of its time on that vector work: with MFMAs, DMA and
@@ -1039,10 +1106,14 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
     if (range_guard_skip(p.rflag, p.rmode, false)) return;
-    const int c0 = (p.wg_begin + blockIdx.x) * DW_TC;
+    const bool split = p.ksplit > 1;
+    const int ntile = split ? (int)gridDim.x / p.ksplit : (int)gridDim.x;
+    const int ksi = split ? (int)blockIdx.x / ntile : 0;                  // which K range (the splits of one tile sit ntile workgroups apart)
+    const int c0 = (p.wg_begin + (split ? (int)blockIdx.x % ntile : (int)blockIdx.x)) * DW_TC;
     const int crow = wave * 32 + il;
     const int c = c0 + crow;
     const int nib = p.Bpad / 32;
+    const int ib0 = split ? (int)((int64_t)ksi * nib / p.ksplit) : 0, ib1 = split ? (int)((int64_t)(ksi + 1) * nib / p.ksplit) : nib;
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char* hb = reinterpret_cast<const char*>(p.hb);
@@ -1079,11 +1150,11 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
 #pragma unroll
         for (int n = 0; n < NA + NB; ++n) stage_piece(ib, buf, n);
     };
-    stage(0, 0);
+    stage(ib0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int ib = 0; ib < nib; ++ib) {
-        const int buf = ib & 1;
+    for (int ib = ib0; ib < ib1; ++ib) {
+        const int buf = (ib - ib0) & 1;
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + TA;
         uint32_t word = 0u;
@@ -1136,7 +1207,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);
             // the next K block's DMA, one piece per half-group: a burst of 8-9 LDS-DMA issues in one gap stalls the wave's own MFMA stream
-            if (hg < NA + NB && ib + 1 < nib && !(p.ablate & 4)) { if (p.ablate & 16) { if (hg == 0) stage(ib + 1, buf ^ 1); } else stage_piece(ib + 1, buf ^ 1, hg); }
+            if (hg < NA + NB && ib + 1 < ib1 && !(p.ablate & 4)) { if (p.ablate & 16) { if (hg == 0) stage(ib + 1, buf ^ 1); } else stage_piece(ib + 1, buf ^ 1, hg); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1151,42 +1222,25 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     sum1 += __shfl_xor(sum1, 32, 64);
     sum2 += __shfl_xor(sum2, 32, 64);
     const float inv_a = 1.f / p.a_scale;
-    if (half == 0 && c < p.M) { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
+    if (half == 0 && c < p.M) {
+        if (split) {
+            float* pb = p.part + (int64_t)p.ksplit * 2 * p.slab; const int64_t Mp = p.slab / 128;
+            pb[(int64_t)(ksi * 2) * Mp + c] = sum1 * inv_a; if (BAYES) pb[(int64_t)(ksi * 2 + 1) * Mp + c] = sum2 * inv_a;
+        } else { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
+    }
 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
         if (cr >= p.M) continue;
-        float v_rho[NJT], v_mu[NJT], v_wp[NJT], o_mu[NJT], o_rho[NJT];      // NJT consecutive hidden units per lane, see k_out_dw_b6
-        const int64_t idx0 = (int64_t)cr * H + NJT * il;
-        if (BAYES) { ld_vec<NJT>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<NJT>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<NJT>(p.wp + idx0, v_wp); }
-        else if (ADAM) ld_vec<NJT>(p.w_mu + idx0, v_mu);
-        float a_m1[NJT], a_v1[NJT], a_m2[NJT], a_v2[NJT];
-        if (ADAM) { ld_vec<NJT>(p.m_mu + idx0, a_m1); ld_vec<NJT>(p.v_mu + idx0, a_v1); if (BAYES) { ld_vec<NJT>(p.m_rho + idx0, a_m2); ld_vec<NJT>(p.v_rho + idx0, a_v2); } }
+        const int64_t idx0 = (int64_t)cr * H + NJT * il;      // NJT consecutive hidden units per lane, see k_out_dw_b6
+        float s1[NJT], s2[NJT];
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            float gm = acc1[jt][r] * p.unscale, gr = 0.f, pm = 0.f, rh = 0.f;
-            if (BAYES) {
-                rh = v_rho[jt];
-                pm = v_mu[jt];
-                const float w = v_wp[jt];
-                const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
-                const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
-                const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
-                gm += p.klw * pm;
-                gr = (acc2[jt][r] * p.unscale) * (w * isig) * sg + p.klw * (sigma - isig) * sg;
-            } else if (ADAM) pm = v_mu[jt];
-            o_mu[jt] = gm; o_rho[jt] = gr;
-            if (ADAM) {   // in place: the updated parameter goes where the gradient would have gone
-                o_mu[jt] = adam_update(pm, gm, a_m1[jt], a_v1[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
-                if (BAYES) o_rho[jt] = adam_update(rh, gr, a_m2[jt], a_v2[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
-            }
-        }
-        if (!ADAM) { st_vec<NJT>(p.g_mu + idx0, o_mu); if (BAYES) st_vec<NJT>(p.g_rho + idx0, o_rho); }
-        else {
-            st_vec<NJT>(p.w_mu + idx0, o_mu); st_vec<NJT>(p.m_mu + idx0, a_m1); st_vec<NJT>(p.v_mu + idx0, a_v1);
-            if (BAYES) { st_vec<NJT>(p.w_rho + idx0, o_rho); st_vec<NJT>(p.m_rho + idx0, a_m2); st_vec<NJT>(p.v_rho + idx0, a_v2); }
-        }
+        for (int jt = 0; jt < NJT; ++jt) { s1[jt] = acc1[jt][r] * p.unscale; s2[jt] = acc2[jt][r] * p.unscale; }
+        if (split) {   // raw partial sums of this K range; k_out_dw_finish adds the ranges and finalises
+            st_vec<NJT>(p.part + (int64_t)(ksi * 2) * p.slab + idx0, s1);
+            if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + idx0, s2);
+        } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2);
     }
 }
 
@@ -2173,8 +2227,24 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     { static const int abl = getenv("NTF_DW_ABLATE") ? atoi(getenv("NTF_DW_ABLATE")) : 0; a.ablate = abl; }
     const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
     a.sT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
+    a.ksplit = 1; a.part = nullptr; a.slab = 0;
     if (f.bf16x6 && f.np == 2 && f.dz_packed) {   // fp16x3 step, H = 128: the forward kernel left packed plane pairs in dzT
         a.a_scale = f.a_scale; a.unscale = 1.f / (f.a_scale * f.h_scale); a.rmode = guard ? 1 : 0;
+        const int ks = (f.ksplit > 1 && f.part && f.wg_count <= 0) ? std::min(f.ksplit, std::max(1, g.Bpad / 32)) : 1;
+        if (ks > 1) {   // few expert tiles: every tile's K range is split over ks workgroups, k_out_dw_finish adds the parts and runs the epilogue
+            a.ksplit = ks; a.part = f.part; a.slab = (int64_t)rup(f.M, DW_TC) * 128;
+            const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0));
+            const int64_t nq = (int64_t)f.M * 128 / 4;
+#define NTF_DWS(BY, AD) do { auto kf = k_out_dw_p2<BY, false>;                                                                  \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            hipLaunchKernelGGL(kf, dim3(grid * ks), dim3(64 * DW_WAVES), lds, st, a);                                          \
+            hipLaunchKernelGGL((k_out_dw_finish<BY, AD>), dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, a); } while (0)
+            if (f.bayes) { if (f.adam) NTF_DWS(true, true); else NTF_DWS(true, false); } else { if (f.adam) NTF_DWS(false, true); else NTF_DWS(false, false); }
+#undef NTF_DWS
+            if (!guard) return;
+            a.rmode = 2; a.ksplit = 1;
+            goto exact_f32;
+        }
         const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0));
 #define NTF_DWP(BY, AD) do { auto kf = k_out_dw_p2<BY, AD>;                                                                    \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
@@ -2183,7 +2253,9 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
 #undef NTF_DWP
         if (!guard) return;
         a.rmode = 2;
-    } else if (f.bf16x6) {
+        goto exact_f32;
+    }
+    if (f.bf16x6) {
         const int np = f.np == 2 ? 2 : 3;
         a.rmode = guard ? 1 : 0;
         a.a_scale = np == 2 ? f.a_scale : 1.f; a.unscale = np == 2 ? 1.f / (f.a_scale * f.h_scale) : 1.f;
@@ -2200,6 +2272,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
         if (!guard) return;
         a.rmode = 2;   // fall through: the exact-f32 kernel, which runs only when the range flag is raised
     }
+exact_f32:
 #define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)

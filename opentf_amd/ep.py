@@ -51,7 +51,7 @@ def can_shard(dims, world: int) -> bool:
 
 
 class ExpertParallel:
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, two_phase=False):
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -59,7 +59,8 @@ class ExpertParallel:
         self._dh = engine.dh_tensor()          # flat alias of the engine's d(hidden) buffer (None: no hidden layer, nothing to exchange)
         self._H = engine.dims[-2]
         # NTF_EP_FORCE_EXCHANGE=1: run the two-phase step and the all-reduce even at world_size 1 (exercises RCCL on a 1-GPU box)
-        self.force = dist.is_initialized() and os.environ.get("NTF_EP_FORCE_EXCHANGE", "0") == "1"
+        # two_phase: the two-phase step without any process group (bench.py --ep-emulate: one rank's compute on a 1-GPU box)
+        self.force = bool(two_phase) or (dist.is_initialized() and os.environ.get("NTF_EP_FORCE_EXCHANGE", "0") == "1")
         if self._dh is not None and self._dh.is_cuda and (self.world > 1 or self.force) and hasattr(engine, "stream_handle"):
             assert engine.stream_handle is not None and torch.cuda.current_stream().cuda_stream == engine.stream_handle, \
                 "ExpertParallel must run under torch.cuda.stream(s) with the engine created on s: kernels and the all-reduce are ordered through that one stream"
@@ -78,7 +79,7 @@ class ExpertParallel:
             steps += 1
             if train and exchange:
                 e.step_staged_ep(off, B, 1)        # forward, loss, this shard's output-layer backward (+ its Adam); partial d(hidden)
-                if self._dh is not None:
+                if self._dh is not None and dist.is_initialized():
                     dist.all_reduce(self._dh[: B * self._H], op=dist.ReduceOp.SUM, group=self.group)   # stream-ordered; the host does not wait
                 e.step_staged_ep(off, B, 2)        # hidden layers' backward + Adam, identical on every rank
             else:

@@ -157,3 +157,29 @@ def test_wide_minibatch_on_a_narrow_shard():
     for k in b:
         if k.startswith("layers.1."): assert np.array_equal(a[k], b[k]), k
         else: np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("bayesian", [True, False])
+def test_split_k_weight_gradient_kernel_equals_the_unsplit_one(bayesian, monkeypatch):
+    """few expert tiles: the dW kernel's K (batch) range is split over workgroups and k_out_dw_finish runs the epilogue (gradient finalisation, fused Adam);
+    same sums in another order -> same update up to rounding, with and without the fused Adam, and the gradients themselves"""
+    ds = make_dataset("dblp", d=128, seed=6, n_rows=3000, n_experts=1300)     # 6 tiles of 256 experts, the last one ragged
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(1).permutation(ds["N"])[:1500].astype(np.int64)
+    def run(ks, fuse_adam):
+        monkeypatch.setenv("NTF_DW_KSPLIT", str(ks))
+        e = _mk(ds, dims, bayesian, 1000, "uniform", fuse_adam=fuse_adam)
+        e.stage_order(order)
+        e.step_staged(0, 1000, train=True, apply=False); g = e.grads() if not fuse_adam else None
+        if not fuse_adam: e.apply()
+        loss = _full_epoch(e, order, 1000)
+        sd = e.state_dict(); e.close()
+        return loss, sd, g
+    for fuse_adam in (0, 1):
+        (l1, p1, g1), (l5, p5, g5) = run(1, fuse_adam), run(5, fuse_adam)
+        assert abs(l1 - l5) <= 1e-6 * abs(l1)
+        for k in p1: np.testing.assert_allclose(p5[k], p1[k], rtol=1e-4, atol=2e-5, err_msg=k)
+        if g1 is not None:
+            for k in g1:
+                scale = float(np.abs(g1[k]).max())
+                assert float(np.abs(g5[k] - g1[k]).max()) <= 2e-6 * scale, k
