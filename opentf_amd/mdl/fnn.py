@@ -21,7 +21,7 @@ import numpy as np
 import scipy.sparse
 
 from .earlystopping import EarlyStopping, PlateauLR
-from .ntf import Ntf, cfg2str, cfg_get
+from .ntf import Ntf, cfg2str, cfg_get, dist_rank
 
 log = logging.getLogger(__name__)
 
@@ -68,38 +68,61 @@ def make_fnn(base):
             return self.model
 
         # ---- engine plumbing
-        def _engine(self, teamsvecs, max_batch):
+        def _engine(self, teamsvecs, max_batch, train=False):
             """The engine for this dataset.  With `self.keep_engine` set (tNtf's streaming loop does) the engine - CSR / table / dense
-            input resident in HBM - survives learn() / test() and is reused while the caller passes the same matrices."""
+            input resident in HBM - survives learn() / test() and is reused while the caller passes the same matrices.
+            train=True under torchrun may return an expert SHARD of the model (see _parallel_mode); test() always gets a whole-model engine."""
             key = (id(teamsvecs.get("skill_table")) if hasattr(teamsvecs, "get") else None, id(teamsvecs["skill"]), id(teamsvecs["member"]),
                    int(max_batch), str(self.device))
-            cached = getattr(self, "_resident", None)
+            if not hasattr(self, "_resident") or self._resident is None:
+                self._resident = {}
+            slot = "train" if train else "whole"
+            cached = self._resident.get(slot)
             if cached is not None:
                 if cached[0] == key:
                     return cached[1], cached[2]
                 cached[1].close()
-                self._resident = None
-            e, dims = self._new_engine(teamsvecs, max_batch)
+                del self._resident[slot]
+            e, dims = self._new_engine(teamsvecs, max_batch, train)
             if getattr(self, "keep_engine", False):
-                self._resident = (key, e, dims)
+                if getattr(e, "parallel_mode", None) != "ep" and train:     # an unsharded engine serves both roles
+                    slot = "whole"
+                    if slot in self._resident: self._resident[slot][1].close()
+                self._resident[slot] = (key, e, dims)
             return e, dims
 
         def _release(self, engine):
-            if getattr(self, "_resident", None) is None or self._resident[1] is not engine:
+            if not any(v[1] is engine for v in (getattr(self, "_resident", None) or {}).values()):
                 engine.close()
 
         def release_engine(self):
-            if getattr(self, "_resident", None) is not None:
-                self._resident[1].close()
-                self._resident = None
+            for v in (getattr(self, "_resident", None) or {}).values():
+                v[1].close()
+            self._resident = {}
+
+        @staticmethod
+        def _parallel_mode(dims, world):
+            """How torchrun's processes share a training step (world > 1).  "ep": the output layer is split along the expert axis - every GPU
+            steps the whole minibatch of cfg.b rows on its experts, the only exchange is d(hidden) (opentf_amd/ep.py); "dp": the rows are
+            split, the gradients reduce-scattered (opentf_amd/dp.py).  NTF_PARALLEL = ep | dp forces one; default: ep whenever the model
+            shards (h[-1] in {32, 64, 128} and at least one 256-expert tile per GPU) - it moves ~500x fewer bytes per step."""
+            from ..ep import can_shard
+            want = os.environ.get("NTF_PARALLEL", "auto").lower()
+            if world <= 1:
+                return None
+            if want != "dp" and can_shard(dims, world):
+                return "ep"
+            if want == "ep":
+                raise ValueError(f"NTF_PARALLEL=ep: a model of dims {dims} does not shard over {world} GPUs")
+            return "dp"
 
         def _barrier(self):
             """ranks other than 0 must not read files rank 0 is still writing (checkpoints feed test() and tNtf's warm start)"""
-            import torch
-            if getattr(self, "_world", 1) > 1:
-                torch.distributed.barrier()
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.barrier()
 
-        def _new_engine(self, teamsvecs, max_batch):
+        def _new_engine(self, teamsvecs, max_batch, train=False):
             from .. import libntf
             skill, member = teamsvecs["skill"], teamsvecs["member"]
             n_in, n_out = skill.shape[1], member.shape[1]
@@ -123,12 +146,19 @@ def make_fnn(base):
             torch.cuda.set_device(devs[0])
             # data parallel: engine kernels and the RCCL all-reduce must be ordered on ONE stream -> run both on a torch stream
             self._stream = torch.cuda.Stream() if self._world > 1 else None
+            mode = self._parallel_mode(dims, self._world) if train else None
+            shard = None
+            if mode == "ep":
+                from ..ep import expert_shards
+                shard = expert_shards(dims[-1], self._world)[self._rank]
             nsd = cfg_get(self.cfg, "nsd")
             e = libntf.Engine(dims, bayesian=self.is_bayesian, input_mode=mode, max_batch=max_batch, ns=int(cfg_get(self.cfg, "ns", 0) or 0),
                               nsd=nsd if nsd else None, tpw=float(cfg_get(self.cfg, "tpw", 1)), tnw=float(cfg_get(self.cfg, "tnw", 1)),
                               lr=float(cfg_get(self.cfg, "lr")), seed=int(self.seed or 0), device=devs[0],
                               stream=self._stream.cuda_stream if self._stream is not None else None,
-                              fuse_adam=1)   # single GPU: the output layer's Adam in the dW epilogue (-0.16 ms per step at config 2); ignored under data parallelism
+                              fuse_adam=1,   # the output layer's Adam in the dW epilogue (-0.16 ms per step at config 2); ignored under data parallelism
+                              expert_shard=shard, ep_world=self._world if mode == "ep" else 1)
+            e.parallel_mode = mode
             if mode == libntf.INPUT_MEANPOOL:
                 src = teamsvecs.get("original_skill", skill)
                 e.set_skill_table(np.asarray(table, dtype=np.float32)); e.set_skill_csr(src)
@@ -148,7 +178,7 @@ def make_fnn(base):
         def learn(self, teamsvecs, splits, prev_model):
             import contextlib
             import torch
-            engine, dims = self._engine(teamsvecs, int(cfg_get(self.cfg, "b")))
+            engine, dims = self._engine(teamsvecs, int(cfg_get(self.cfg, "b")), train=True)
             with (torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()):
                 self._learn(engine, dims, teamsvecs, splits, prev_model)
 
@@ -161,9 +191,14 @@ def make_fnn(base):
                 engine.set_unigram(np.asarray(member.sum(axis=0), dtype=np.float64).reshape(-1) / member.shape[0])
 
             runner = engine
-            if self._world > 1:  # data parallel over the node's GPUs: global minibatch = cfg.b rows, split over ranks (dp.py)
+            mode = getattr(engine, "parallel_mode", None)
+            if mode == "ep":    # every GPU steps the cfg.b rows on its range of experts (ep.py)
+                from ..ep import ExpertParallel
+                runner = ExpertParallel(engine)
+            elif mode == "dp":  # data parallel over the node's GPUs: global minibatch = cfg.b rows, split over ranks (dp.py)
                 from ..dp import DataParallel
                 runner = DataParallel(engine)
+            self._runner = runner
             w = self.writer(log_dir=f"{self.output}/logs4tboard/run_{int(time.time())}")
             for foldidx in splits["folds"].keys():
                 tr = np.asarray(splits["folds"][foldidx]["train"], dtype=np.int64)
@@ -199,7 +234,9 @@ def make_fnn(base):
         def _save(self, engine, foldidx, e, t_loss, v_loss, path):
             """Same keys and order as src/mdl/fnn.py:160,168; tensors are CPU f32 so `map_location` loads work anywhere."""
             import torch
-            self.model = self._to_torch(engine.state_dict())
+            # expert shards: the output layer's rows are gathered from the ranks (a collective: every rank calls _save)
+            sd = self._runner.state_dict() if getattr(engine, "parallel_mode", None) == "ep" else engine.state_dict()
+            self.model = self._to_torch(sd)
             if getattr(self, "_rank", 0) != 0:
                 return  # every rank holds the same weights; rank 0 writes the files
             torch.save({"model_state_dict": self.model, "cfg": self.cfg, "f": foldidx, "e": e, "t_loss": t_loss, "v_loss": v_loss}, path)
@@ -209,13 +246,12 @@ def make_fnn(base):
             import torch
             assert os.path.isdir(self.output), f"No folder for {self.output} exist!"
             b = int(cfg_get(self.cfg, "b"))
-            engine, dims = self._engine(teamsvecs, b)
-            if getattr(self, "_rank", 0) != 0:
+            if dist_rank() != 0:
                 # one writer: rank 0 runs the inference and writes the .pred files (the reference's test() is single-process);
                 # the others wait for it so that evaluate() finds complete files
                 self._barrier()
-                self._release(engine)
                 return
+            engine, dims = self._engine(teamsvecs, b)
             M = dims[-1]
             topK = cfg_get(testcfg, "topK")
             nmc = int(cfg_get(self.cfg, "nmc", 1) or 1)

@@ -291,3 +291,47 @@ def test_pipelined_data_parallel_step_on_rccl_world1():
     finally:
         dist.destroy_process_group()
         os.environ.pop("NTF_DP_FORCE_ALLREDUCE", None)
+
+
+def test_expert_parallel_step_on_rccl_world1():
+    """The expert-sharded step as the N-GPU bench runs it - phase 1, RCCL all-reduce of the engine-owned d(hidden) buffer on the engine's stream,
+    phase 2, the epoch-end gather of the output layer - exercised on one GPU (world_size 1: the shard is the whole layer, the collective forced):
+    it must leave exactly the parameters of the plain single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    from opentf_amd import libntf
+    from opentf_amd.ep import ExpertParallel, expert_shards
+    from opentf_amd.synth import init_params, zipf_csr
+    M, S, N, B = 70_000, 5_000, 20_000, 600
+    s_ip, s_ix = zipf_csr(N, S, 8.57, 1); m_ip, m_ix = zipf_csr(N, M, 3.06, 2)
+    table = np.random.default_rng(0).standard_normal((S, 128), dtype=np.float32)
+    sd = init_params([128, 128, M], True, 0)
+    order = np.random.default_rng(1).integers(0, N, 3 * B)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    os.environ["NTF_EP_FORCE_EXCHANGE"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        stream = torch.cuda.Stream()
+        results = []
+        with torch.cuda.stream(stream):
+            for mode in ("plain", "ep"):
+                e = libntf.Engine([128, 128, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", seed=5, fuse_adam=1,
+                                  stream=stream.cuda_stream, expert_shard=expert_shards(M, 1)[0] if mode == "ep" else None)
+                e.set_skill_table(table); e.set_skill_csr((s_ip, s_ix)); e.set_member((m_ip, m_ix)); e.load_state_dict(sd)
+                if mode == "plain":
+                    loss = e.train_epoch(order, B); full = e.state_dict()
+                else:
+                    ep = ExpertParallel(e)
+                    assert ep.force and ep._dh is not None and ep._dh.numel() == B * 128
+                    loss = ep.train_epoch(order, B); full = ep.state_dict()
+                    v = ep.eval_epoch(order[:B], B); assert np.isfinite(v)
+                results.append((loss, full))
+                e.close()
+        (la, pa), (lb, pb) = results
+        assert abs(la - lb) <= 1e-6 * abs(la)
+        for k in pa:
+            assert np.array_equal(pa[k], pb[k]), k
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("NTF_EP_FORCE_EXCHANGE", None)

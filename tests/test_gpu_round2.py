@@ -313,7 +313,7 @@ def test_config5_gith_shapes_temporal_streaming_bnn(tmp_path):
         inner = Bnn(str(tmp_path / f"lr{lr}"), "cuda:0", 0, cfg)
         t = tNtf(str(tmp_path / f"lr{lr}"), "cuda:0", 0, Cfg(tfolds=2, step_ahead=1), inner, year_idx)
         t.learn(tv, sp, None)
-        assert getattr(inner, "_resident", None) is None                                # released at the end of the stream
+        assert not getattr(inner, "_resident", None)                                    # released at the end of the stream
         years = sorted(int(x) for x in os.listdir(t.output) if x.isdigit())
         assert years == [2016, 2017, 2018, 2019, 2020]
         w = [torch.load(f"{t.output}/{y}/f0.pt", map_location="cpu", weights_only=False) for y in years]
