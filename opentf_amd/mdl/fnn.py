@@ -108,8 +108,8 @@ def make_fnn(base):
             shards (h[-1] in {32, 64, 128} and at least one 256-expert tile per GPU) - it moves ~500x fewer bytes per step."""
             from ..ep import can_shard
             want = os.environ.get("NTF_PARALLEL", "auto").lower()
-            if world <= 1:
-                return None
+            if world <= 1:   # NTF_PARALLEL=ep with NTF_EP_FORCE_EXCHANGE=1: the sharded code path on one GPU (validation; the shard is the whole layer)
+                return "ep" if (want == "ep" and os.environ.get("NTF_EP_FORCE_EXCHANGE", "0") == "1" and can_shard(dims, 1)) else None
             if want != "dp" and can_shard(dims, world):
                 return "ep"
             if want == "ep":
@@ -145,10 +145,10 @@ def make_fnn(base):
                 devs = [devs[local % len(devs)] if len(devs) > 1 else local]
             torch.cuda.set_device(devs[0])
             # data parallel: engine kernels and the RCCL all-reduce must be ordered on ONE stream -> run both on a torch stream
-            self._stream = torch.cuda.Stream() if self._world > 1 else None
-            mode = self._parallel_mode(dims, self._world) if train else None
+            pmode = self._parallel_mode(dims, self._world) if train else None
+            self._stream = torch.cuda.Stream() if (self._world > 1 or pmode) else None
             shard = None
-            if mode == "ep":
+            if pmode == "ep":
                 from ..ep import expert_shards
                 shard = expert_shards(dims[-1], self._world)[self._rank]
             nsd = cfg_get(self.cfg, "nsd")
@@ -157,8 +157,9 @@ def make_fnn(base):
                               lr=float(cfg_get(self.cfg, "lr")), seed=int(self.seed or 0), device=devs[0],
                               stream=self._stream.cuda_stream if self._stream is not None else None,
                               fuse_adam=1,   # the output layer's Adam in the dW epilogue (-0.16 ms per step at config 2); ignored under data parallelism
-                              expert_shard=shard, ep_world=self._world if mode == "ep" else 1)
-            e.parallel_mode = mode
+                              expert_shard=shard, ep_world=self._world if pmode == "ep" else 1)
+            e.parallel_mode = pmode
+            e.torch_stream = self._stream      # learn() runs under THIS engine's stream (a cached engine may be older than self._stream)
             if mode == libntf.INPUT_MEANPOOL:
                 src = teamsvecs.get("original_skill", skill)
                 e.set_skill_table(np.asarray(table, dtype=np.float32)); e.set_skill_csr(src)
@@ -179,7 +180,8 @@ def make_fnn(base):
             import contextlib
             import torch
             engine, dims = self._engine(teamsvecs, int(cfg_get(self.cfg, "b")), train=True)
-            with (torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()):
+            stream = getattr(engine, "torch_stream", None)
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
                 self._learn(engine, dims, teamsvecs, splits, prev_model)
 
         def _learn(self, engine, dims, teamsvecs, splits, prev_model):

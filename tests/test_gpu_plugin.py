@@ -335,3 +335,35 @@ def test_expert_parallel_step_on_rccl_world1():
     finally:
         dist.destroy_process_group()
         os.environ.pop("NTF_EP_FORCE_EXCHANGE", None)
+
+
+def test_plugin_trains_expert_sharded_under_torch_distributed(tmp_path, monkeypatch):
+    """Bnn.learn / test through the expert-sharded branch of the plugin (what `torchrun ... main.py` takes on a multi-GPU node), forced on one GPU:
+    sharded engine for learn(), ExpertParallel as the runner, the gathered state_dict in the checkpoints, a whole-model engine for test().
+    Same files, and - the shard being the whole layer - bit-identical weights to the plain single-GPU run."""
+    import socket
+    import torch.distributed as dist
+    from opentf_amd.mdl.bnn import Bnn
+    tv, splits = _toy("dblp")
+    cfg = Cfg(b=6, e=2, ns=3, lr=0.01, es=5, h=[128], spe=0, l="bce", tpw=10, tnw=1, nsd="uniform", nmc=2)
+    plain = Bnn(str(tmp_path / "plain"), "cuda:0", 0, cfg); plain.learn(tv, splits, None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    monkeypatch.setenv("NTF_PARALLEL", "ep"); monkeypatch.setenv("NTF_EP_FORCE_EXCHANGE", "1")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        m = Bnn(str(tmp_path / "ep"), "cuda:0", 0, cfg)
+        m.learn(tv, splits, None)
+        assert type(m._runner).__name__ == "ExpertParallel"
+        m.test(tv, splits, Cfg(per_epoch=False, on_train=False, topK=None))
+    finally:
+        dist.destroy_process_group()
+    for k in range(3):
+        a = torch.load(f"{plain.output}/f{k}.pt", map_location="cpu", weights_only=False)
+        b = torch.load(f"{m.output}/f{k}.pt", map_location="cpu", weights_only=False)
+        assert list(a.keys()) == list(b.keys()) and a["e"] == b["e"]
+        assert abs(a["t_loss"] - b["t_loss"]) <= 1e-6 * abs(a["t_loss"]) and abs(a["v_loss"] - b["v_loss"]) <= 1e-6 * abs(a["v_loss"])   # f32 mean vs f64 mean of the same batch losses
+        for name in a["model_state_dict"]:
+            assert torch.equal(a["model_state_dict"][name], b["model_state_dict"][name]), name
+        pr = torch.load(f"{m.output}/f{k}.test.pred", map_location="cpu", weights_only=False)
+        assert tuple(pr["y_pred"].shape) == (len(splits["test"]), tv["member"].shape[1])
