@@ -340,7 +340,7 @@ def test_expert_parallel_step_on_rccl_world1():
 def test_plugin_trains_expert_sharded_under_torch_distributed(tmp_path, monkeypatch):
     """Bnn.learn / test through the expert-sharded branch of the plugin (what `torchrun ... main.py` takes on a multi-GPU node), forced on one GPU:
     sharded engine for learn(), ExpertParallel as the runner, the gathered state_dict in the checkpoints, a whole-model engine for test().
-    Same files, and - the shard being the whole layer - bit-identical weights to the plain single-GPU run."""
+    Same files and - the shard being the whole layer - the weights of the plain single-GPU run."""
     import socket
     import torch.distributed as dist
     from opentf_amd.mdl.bnn import Bnn
@@ -364,6 +364,7 @@ def test_plugin_trains_expert_sharded_under_torch_distributed(tmp_path, monkeypa
         assert list(a.keys()) == list(b.keys()) and a["e"] == b["e"]
         assert abs(a["t_loss"] - b["t_loss"]) <= 1e-6 * abs(a["t_loss"]) and abs(a["v_loss"] - b["v_loss"]) <= 1e-6 * abs(a["v_loss"])   # f32 mean vs f64 mean of the same batch losses
         for name in a["model_state_dict"]:
-            assert torch.equal(a["model_state_dict"][name], b["model_state_dict"][name]), name
+            # toy dblp's skill rows are multi-hot: the first layer's weight gradient is a scatter-add by float atomics, so two runs agree to rounding only
+            assert torch.allclose(a["model_state_dict"][name], b["model_state_dict"][name], rtol=1e-4, atol=1e-6), name
         pr = torch.load(f"{m.output}/f{k}.test.pred", map_location="cpu", weights_only=False)
         assert tuple(pr["y_pred"].shape) == (len(splits["test"]), tv["member"].shape[1])
