@@ -816,7 +816,7 @@ backward:
         dw_done:;
         } else {
             const float* dZ = last ? e->dZout : e->dAct[(l + 1) & 1];
-            { Scope t(e, F_BIAS_GRAD); launch_bias_grad(e->st, dZ, li.out, B, li.out, sout_, gb, gRb); }
+            { Scope t(e, F_BIAS_GRAD); launch_bias_grad(e->st, dZ, li.out, B, li.out, sout_, gb, gRb, e->gemm_slab, kGemmSlabFloats); }
             if (l == 0 && e->cfg.input_mode == NTF_INPUT_MULTIHOT) {
                 Scope t(e, F_MULTIHOT);
                 HIPCHK(e, hipMemsetAsync(gW, 0, (size_t)li.nw() * 4, e->st));
@@ -830,7 +830,7 @@ backward:
                 g.B = in; g.sbk = li.in; g.sbn = 1;
                 g.C = gW; g.ldc = li.in;
                 const int wtiles = ((li.out + 63) / 64) * ((li.in + 63) / 64);
-                if (wtiles < 64 && B >= 256) { g.ksplit = std::max(1, std::min({16, B / 64, (int)(kGemmSlabFloats / ((int64_t)li.out * li.in))})); g.slab = e->gemm_slab; }
+                if (wtiles < 64 && B >= 256) { g.ksplit = std::max(1, std::min({B >= 2048 ? 64 : 16, B / 64, (int)(kGemmSlabFloats / ((int64_t)li.out * li.in))})); g.slab = e->gemm_slab; }
                 if (g.ksplit <= 1) { g.ksplit = 1; g.slab = nullptr; }
                 launch_gemm(e->st, g);
                 if (e->cfg.bayesian) { g.sa = sout_; g.sa_t = 1; g.sb = sin_; g.sb_t = 0; g.C = gRW; launch_gemm(e->st, g); }

@@ -1007,6 +1007,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
 // ------------------------------------------------------------------------------------------------
 // s_out sign words of the dW kernel: sT[expert tile of 256][K block][expert in tile], bit k = sign of (batch row 32 ib + k, expert) - the 32x32 bit
 // transposes of the row words (hash, or the packed image of injected signs), made once per step instead of once per K block inside the dW kernel
+constexpr int SWT_IB = 16;
 __global__ __launch_bounds__(256) void k_sign_words_T(const uint32_t* __restrict__ sbits, int so_inj, uint32_t k0, uint32_t k1, int B, int nCB, int ncb_all, int nib,
                                                       uint32_t* __restrict__ sT) {
     const int lane = threadIdx.x & 63, il = lane & 31, half = lane >> 5;
@@ -1014,7 +1015,8 @@ __global__ __launch_bounds__(256) void k_sign_words_T(const uint32_t* __restrict
     if (cb >= ncb_all) return;                                          // (wave-uniform per half: transpose32 shuffles stay inside a half)
     const int c = cb * 32 + il;
     uint32_t* dst = sT + (int64_t)(c >> 8) * nib * 256 + (c & 255);
-    for (int ib = 0; ib < nib; ++ib) {
+    const int ib_end = min(nib, (int)(blockIdx.y + 1) * SWT_IB);      // grid.y: chunks of SWT_IB K blocks (a wide minibatch over few expert blocks still fills the chip)
+    for (int ib = blockIdx.y * SWT_IB; ib < ib_end; ++ib) {
         const int i = ib * 32 + il;
         uint32_t w = 0u;
         if (i < B) {
@@ -2288,7 +2290,7 @@ void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, vo
     char* ws = static_cast<char*>(ws_);
     if (bayes && s_out) {   // packed fp16x3 path: the dW kernel's s_out words, transposed once
         const int ncb_all = rup(M, DW_TC) / 32, nib = g.Bpad / 32;
-        hipLaunchKernelGGL(k_sign_words_T, dim3((ncb_all + 7) / 8), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws + w.sbits), s_out_inj, s_out->k0, s_out->k1,
+        hipLaunchKernelGGL(k_sign_words_T, dim3((ncb_all + 7) / 8, (nib + SWT_IB - 1) / SWT_IB), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws + w.sbits), s_out_inj, s_out->k0, s_out->k1,
                            B, g.nCB, ncb_all, nib, reinterpret_cast<uint32_t*>(ws + w.sbitsT));
     }
     const int n = g.Bpad * H;

@@ -79,7 +79,7 @@ void launch_loss_finalize(hipStream_t st, const float* partial, int nchunk, cons
                           const double* kl, double kl_scale, float* out, double* acc, int64_t* acc_steps);
 
 // bias gradients: g_b[n] = sum_b dZ[b,n];  g_rho_b[n] = (sum_b dZ[b,n]*s_out(b,n)) * eps_b[n] * sigmoid(rho_b[n])
-void launch_bias_grad(hipStream_t st, const float* dZ, int64_t ld, int B, int N, SignSpec sout, float* g_b, float* g_pert /*nullable*/);
+void launch_bias_grad(hipStream_t st, const float* dZ, int64_t ld, int B, int N, SignSpec sout, float* g_b, float* g_pert /*nullable*/, float* scratch = nullptr, int64_t scratch_floats = 0);
 
 // uniform negatives: ns distinct columns per row among the row's non-members (src/mdl/fnn.py:48-56)
 void launch_ns_uniform(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr,

@@ -462,7 +462,46 @@ __global__ __launch_bounds__(256) void k_bias_grad_wave(const float* __restrict_
     s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2);
     if (lane == 0) { g_b[n] = s1; if (g_pert) g_pert[n] = s2; }
 }
-void launch_bias_grad(hipStream_t st, const float* dZ, int64_t ld, int B, int N, SignSpec sout, float* g_b, float* g_pert) {
+// narrow layers under a wide minibatch (an expert shard steps G x b rows): row chunks of 32 read coalesced, one partial row per chunk, then a
+// fixed-order sum over the chunks (the one-wave-per-column form above reads a column with a stride of ld floats: 64 bytes fetched per element used)
+__global__ __launch_bounds__(256) void k_bias_grad_rows(const float* __restrict__ dZ, int64_t ld, int B, int N, SignSpec sout, float* __restrict__ part, int has_pert) {
+    const int b0 = blockIdx.x * 32, b1 = min(B, b0 + 32);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) {
+            const float v = dZ[(int64_t)b * ld + n];
+            s1 += v;
+            if (has_pert) s2 += v * sign_at(sout, b, n);
+        }
+        part[((int64_t)blockIdx.x * 2) * N + n] = s1;
+        if (has_pert) part[((int64_t)blockIdx.x * 2 + 1) * N + n] = s2;
+    }
+}
+__global__ __launch_bounds__(256) void k_bias_grad_sum(const float* __restrict__ part, int nchunk, int N, float* __restrict__ g_b, float* __restrict__ g_pert) {
+    // 64 columns per workgroup, four waves each summing every fourth chunk (independent loads), then a fixed-order sum of the four
+    __shared__ float sh[2][4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    float s1 = 0.f, s2 = 0.f;
+    if (n < N) {
+#pragma unroll 8
+        for (int c = sub; c < nchunk; c += 4) { s1 += part[((int64_t)c * 2) * N + n]; if (g_pert) s2 += part[((int64_t)c * 2 + 1) * N + n]; }
+    }
+    sh[0][sub][threadIdx.x & 63] = s1; sh[1][sub][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (sub == 0 && n < N) {
+        const int t = threadIdx.x;
+        g_b[n] = ((sh[0][0][t] + sh[0][1][t]) + sh[0][2][t]) + sh[0][3][t];
+        if (g_pert) g_pert[n] = ((sh[1][0][t] + sh[1][1][t]) + sh[1][2][t]) + sh[1][3][t];
+    }
+}
+void launch_bias_grad(hipStream_t st, const float* dZ, int64_t ld, int B, int N, SignSpec sout, float* g_b, float* g_pert, float* scratch, int64_t scratch_floats) {
+    const int nchunk = (B + 31) / 32;
+    if (scratch && B >= 1024 && N <= 4096 && (int64_t)nchunk * 2 * N <= scratch_floats) {
+        hipLaunchKernelGGL(k_bias_grad_rows, dim3(nchunk), dim3(256), 0, st, dZ, ld, B, N, sout, scratch, g_pert ? 1 : 0);
+        hipLaunchKernelGGL(k_bias_grad_sum, dim3((N + 63) / 64), dim3(256), 0, st, scratch, nchunk, N, g_b, g_pert);
+        return;
+    }
     if (N <= 4096) hipLaunchKernelGGL(k_bias_grad_wave, dim3((N + 3) / 4), dim3(256), 0, st, dZ, ld, B, N, sout, g_b, g_pert);
     else hipLaunchKernelGGL(k_bias_grad, dim3((N + 255) / 256), dim3(256), 0, st, dZ, ld, B, N, sout, g_b, g_pert);
 }

@@ -183,3 +183,19 @@ def test_split_k_weight_gradient_kernel_equals_the_unsplit_one(bayesian, monkeyp
             for k in g1:
                 scale = float(np.abs(g1[k]).max())
                 assert float(np.abs(g5[k] - g1[k]).max()) <= 2e-6 * scale, k
+
+
+def test_wide_minibatch_hidden_bias_gradients():
+    """B >= 1024 takes the row-chunked bias-gradient kernels: the gradients of one 1536-row step equal the sum of two 768-row shards' (one-wave-per-column kernel)"""
+    ds = make_dataset("dblp", d=128, seed=8, n_rows=2000, n_experts=1500)
+    dims = [128, 96, 128, ds["M"]]
+    order = np.random.default_rng(3).permutation(ds["N"])[:1536].astype(np.int64)
+    full, a, b = (_mk(ds, dims, True, 1536, "uniform", fuse_adam=0) for _ in range(3))
+    for e in (full, a, b): e.stage_order(order)
+    full.step_staged(0, 1536, 0, 1536, train=True, apply=False)
+    a.step_staged(0, 768, 0, 1536, train=True, apply=False); b.step_staged(768, 768, 0, 1536, train=True, apply=False)
+    gf, ga, gb = full.grads(), a.grads(), b.grads()
+    for k in gf:
+        if "bias" not in k: continue
+        s = ga[k] + gb[k]
+        assert float(np.abs(s - gf[k]).max()) <= 2e-5 * float(np.abs(gf[k]).max()) + 1e-9, k
