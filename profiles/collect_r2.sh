@@ -15,6 +15,10 @@ python3 $B --no-gather-bench --steps 20 --warmup 3 --dataset dblp_full --rows 20
 python3 $B --no-gather-bench --steps 30 --warmup 5 --input multihot --nsd unigram > $O/bench_n1_config3_multihot_unigram.json 2>> $O/bench.err
 python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset uspt --d 256 > $O/bench_n1_config4_uspt_d256.json 2>> $O/bench.err
 python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset gith > $O/bench_n1_config5_gith.json 2>> $O/bench.err
+# expert-sharded multi-GPU path: what ONE rank of G runs (its 1/G of the experts, G x 1000 rows, two-phase step, no exchange), emulated
+# on this GPU, and the sharded step through RCCL at world size 1
+for G in 2 4 8; do python3 $R/bench.py --steps 20 --warmup 4 --ep-emulate $G > $O/bench_ep_rank_of_$G.json 2>> $O/bench.err; done
+python3 $B --no-gather-bench --steps 20 --warmup 4 --parallel ep --force-dist > $O/bench_ep_world1_rccl.json 2>> $O/bench.err
 # kernel trace + stats of the default run
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --steps 20 --warmup 3 > $O/stats.log 2>&1
 # PMC passes (each on its own, no tracing)
