@@ -70,7 +70,7 @@ typedef struct ntf_config {
     /* Expert-sharded output layer (every field 0 = off).  This engine owns the experts [expert_lo, expert_lo + dims[n_layers]) of an
        output layer of `experts_global` experts that is split over `ep_world` engines (one per GPU); hidden layers are replicated.  Every engine
        steps the WHOLE minibatch: labels (member CSR) and sampled negatives keep global expert ids, the device generators are keyed by global
-       ids, and the only exchange of a train step is the sum over engines of d(hidden) [B, h[-1]] between ntf_step_staged_ep phases 1 and 2.
+       ids, and the only exchange of a train step is the sum over engines of d(hidden) [B, h[-1]] between ntf_step_staged_ep phases 1 and 3.
        expert_lo must be a multiple of 256; needs the fused output-layer path (h[-1] in {32, 64, 128}). */
     int32_t expert_lo;
     int32_t experts_global;
@@ -160,11 +160,12 @@ int ntf_dw_chunk_range(ntf_engine* e, int32_t k, int64_t* off_weight, int64_t* o
 int ntf_dw_chunk(ntf_engine* e, int32_t k);
 int ntf_param_segment(ntf_engine* e, int layer, int kind, int64_t* off, int64_t* count);
 
-/* expert-sharded output layer (ntf_config.expert_lo ..): one train step on the whole minibatch order[offset, offset + B) in two phases.
- * phase 1: forward, loss, the output layer's backward on this engine's experts (its Adam included) - leaves this engine's PARTIAL d(hidden)
- *          in the buffer ntf_dh_buffer names ([B, h[-1]] floats, row-major);
- * (the host sums that buffer over the engines: one all-reduce of B * h[-1] floats, the only exchange of the step;)
- * phase 2: backward through the replicated hidden layers from the summed d(hidden), Adam on them (identical on every engine).
+/* expert-sharded output layer (ntf_config.expert_lo ..): one train step on the whole minibatch order[offset, offset + B) in three phases.
+ * phase 1: forward, loss, sparse fix-up - leaves this engine's PARTIAL d(hidden) in the buffer ntf_dh_buffer names ([B, h[-1]] floats, row-major);
+ * (the host starts the sum of that buffer over the engines: one all-reduce of B * h[-1] floats, the only exchange of the step;)
+ * phase 2: the output layer's backward on this engine's experts, its Adam included - independent of the exchange, which it hides;
+ * (the host makes the engine's stream wait for the all-reduce;)
+ * phase 3: backward through the replicated hidden layers from the summed d(hidden), Adam on them (identical on every engine).
  * The loss accumulated for ntf_epoch_loss is this engine's share: sum over engines = the single-engine loss.  Evaluation steps need no
  * exchange: ntf_step_staged(train = 0) as usual.  src/mdl/fnn.py:122-140 (the step this splits) */
 int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int32_t phase);

@@ -41,7 +41,7 @@ struct StepCtx {
                              // GLOBAL row position, so a sharded step draws exactly what the single-process step would draw
     bool defer_dw = false;   // leave the output layer's dW kernel to ntf_dw_chunk (data-parallel overlap with the all-reduce)
     bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
-    int part = 0;            // expert-sharded step: 1 = up to and including the output layer's backward, 2 = the hidden layers' backward (0 = whole step)
+    int part = 0;            // expert-sharded step: 1 = forward + loss (leaves the partial d(hidden)), 2 = the output layer's backward, 3 = the hidden layers' backward (0 = whole step)
 };
 
 struct ntf_engine {
@@ -99,9 +99,12 @@ struct ntf_engine {
     uint16_t* pl_mu = nullptr; uint16_t* pl_wp = nullptr;   // bf16 split planes of the output layer's mu / Wp (bf16x6 arithmetic)
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
+    hipStream_t st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the hidden layers' backward runs beside the output layer's dW kernel
+    int side_bwd = 1;                 // NTF_SIDE_BWD=0 keeps the whole backward on one stream (A/B runs)
     // expert-sharded output layer (ntf_config.expert_lo ..): this engine owns experts [ep_lo, ep_lo + dims[L]) of Mg
     bool ep = false; int ep_lo = 0, Mg = 0, ep_world = 1;
-    bool ep_open = false; StepCtx ep_ctx;   // between ntf_step_staged_ep phases 1 and 2
+    bool ep_side = false;                   // this step's phase 2 runs on the side stream
+    int ep_open = 0; StepCtx ep_ctx;        // the ntf_step_staged_ep phase that ran last (0: none pending)
 };
 
 #define HIPCHK(e, call)                                                                                   \
@@ -187,7 +190,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->lr = cfg->lr;
     e->seed = cfg->seed;
     if (const char* fk = getenv("NTF_FWD_KERNEL")) e->fwd_kernel = atoi(fk);
-    if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
+    if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
+    if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
     int64_t off = 0;
@@ -265,6 +269,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
     for (int k = 0; k < 2; ++k) { if (e->ub_host[k]) hipHostFree(e->ub_host[k]); if (e->ub_dev[k]) hipFree(e->ub_dev[k]); if (e->ub_ev[k]) hipEventDestroy(e->ub_ev[k]); }
+    if (e->st3) { hipStreamSynchronize(e->st3); hipStreamDestroy(e->st3); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); }
     if (e->st2) { hipStreamSynchronize(e->st2); hipStreamDestroy(e->st2); hipEventDestroy(e->ev_chunk); hipEventDestroy(e->ev_side); }
     if (e->own_stream && e->st) hipStreamDestroy(e->st);
     delete e;
@@ -677,6 +682,11 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
     return NTF_OK;
 }
 
+static int side_stream(ntf_engine* e) {
+    if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
+    return NTF_OK;
+}
+
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
 static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     int r;
@@ -687,7 +697,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
     int nslots;
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
-    if (c.part == 2) goto backward;   // expert-sharded step, second phase: the summed d(hidden) is in place
+    if (c.part >= 2) goto backward;   // expert-sharded step, later phases
     if ((r = make_input(e, c))) return r;
     if ((r = sample_negatives(e, c))) return r;
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
@@ -737,15 +747,24 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         launch_loss_finalize(e->st, e->partial, nslots, e->row_fix, B, inv_B, e->cfg.bayesian ? e->d_kl : nullptr, kl_scale, e->d_loss,
                              accumulate_epoch ? e->d_acc : nullptr, e->d_acc_steps);
     }
-    if (!c.train) return NTF_OK;
+    if (!c.train || c.part == 1) return NTF_OK;
 
 backward:
     const float kl_share = (float)B / (float)c.global_B;
+    // Whole step on one GPU: the hidden layers' backward (a chain of small kernels, ~0.1 ms) needs d(hidden) only, not the output layer's dW kernel (0.4-0.6 ms,
+    // whose last round leaves CUs idle): it runs on a side stream beside it; both are joined before Adam.
+    const bool side = fused && e->cfg.bayesian && e->L > 1 && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
+    struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } } restore{e, e->st};
+    if (side) {
+        if ((r = side_stream(e))) return r;
+        HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
+    }
     for (int l = e->L - 1; l >= 0; --l) {
         const LayerInfo& li = e->layers[l];
         const bool last = (l == e->L - 1);
-        if (c.part == 1 && !last) break;       // the hidden layers wait for the sum of d(hidden) over the expert shards
-        if (c.part == 2 && last) continue;
+        if (c.part == 2 && !last) break;       // the hidden layers wait for the sum of d(hidden) over the expert shards
+        if (c.part == 3 && last) continue;
+        if (side && l == e->L - 2) { HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0)); e->st = e->st3; }   // from here on: launches and timing scopes on the side stream
         const float* in = e->act[l];
         float* gW = e->G + li.off[NTF_P_WEIGHT]; float* gb = e->G + li.off[NTF_P_BIAS];
         float* gRW = e->cfg.bayesian ? e->G + li.off[NTF_P_RHO_WEIGHT] : nullptr;
@@ -865,6 +884,11 @@ backward:
                                          normal_spec(e, c, l, T_EPS_B), kl_share / ((last ? (float)out_nb : (float)li.out) * (float)c.global_B));
         }
     }
+    if (side) {
+        HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
+        e->st = restore.main;
+        HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
+    }
     return NTF_OK;
 }
 
@@ -921,7 +945,8 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     if (train && e->ep && e->ep_world > 1)
         FAIL(e, NTF_ESTATE, "expert-sharded engine: a train step needs the sum of d(hidden) over the shards - use ntf_step_staged_ep");
     if (e->ep && global_B != B) FAIL(e, NTF_EINVAL, "expert-sharded engine: every shard steps the whole minibatch (global_B == B)");
-    e->ep_open = false;
+    if (e->ep_open == 2 && e->ep_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
+    e->ep_open = 0;
     StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
     c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
     c.defer_dw = defer_dw && train && !apply && fused_ok(e);
@@ -1038,7 +1063,8 @@ extern "C" int ntf_dw_chunk(ntf_engine* e, int32_t k) {
     if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
     return NTF_OK;
 }
-// One train step of an expert-sharded engine in two phases (include/opentf_amd.h): between them the host sums d(hidden) over the shards.
+// One train step of an expert-sharded engine in three phases (include/opentf_amd.h): the host sums d(hidden) over the shards between phases 1 and 3,
+// while phase 2 (this shard's output-layer backward, the longest kernel after the forward) runs.
 extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int32_t phase) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
@@ -1050,24 +1076,40 @@ extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int3
         if ((r = check_ready(e, true))) return r;
         StepCtx c; c.B = B; c.global_B = B; c.train = true; c.step = e->step++; c.part = 1;
         c.fuse_adam = e->cfg.fuse_adam != 0;   // no gradient exchange for the output layer: its Adam may always ride in / beside the dW kernel
-        e->pend_valid = false; e->ep_open = false;
+        if (e->ep_open == 2 && e->ep_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));   // an abandoned step's side-stream kernel still orders before this one
+        e->pend_valid = false; e->ep_open = 0;
         if ((r = stage_rows(e, e->d_order + offset, B, true, &c.rows_dev))) return r;
         if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && (r = set_batch_unigram(e, e->h_order.data() + offset, B))) return r;
         if ((r = run_step(e, c, true))) return r;
         e->last_B = B; e->last_global_B = B;
-        e->ep_ctx = c; e->ep_open = true;
-    } else if (phase == 2) {
-        if (!e->ep_open) FAIL(e, NTF_ESTATE, "step_staged_ep: phase 2 without a pending phase 1");
-        StepCtx c = e->ep_ctx; c.part = 2;
-        e->ep_open = false;
-        if ((r = run_step(e, c, false))) return r;
-        if ((r = apply_adam(e))) return r;
-    } else FAIL(e, NTF_EINVAL, "step_staged_ep: phase must be 1 or 2");
+        e->ep_ctx = c; e->ep_open = 1;
+        // measured: no gain for a shard (its split-K dW launch has no idle tail to fill, and the asynchronous exchange already runs beside dW on RCCL's
+        // stream) - kept behind NTF_SIDE_BWD=2 for A/B runs
+        e->ep_side = e->side_bwd >= 2 && e->L > 1 && e->cfg.fuse_adam != 2;
+        if (e->ep_side) { if ((r = side_stream(e))) return r; HIPCHK(e, hipEventRecord(e->ev_fork, e->st)); }
+    } else if (phase == 2 || phase == 3) {
+        if (e->ep_open != phase - 1) FAIL(e, NTF_ESTATE, phase == 2 ? "step_staged_ep: phase 2 without a pending phase 1" : "step_staged_ep: phase 3 without a pending phase 2");
+        StepCtx c = e->ep_ctx; c.part = phase;
+        e->ep_open = phase == 2 ? 2 : 0;
+        if (phase == 2 && e->ep_side) {
+            // the output layer's backward goes to the side stream: the main stream is about to wait for the d(hidden) exchange and then runs phase 3,
+            // neither of which this kernel needs or feeds - it runs beside both and is joined before Adam
+            struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } } restore{e, e->st};
+            HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
+            e->st = e->st3;
+            if ((r = run_step(e, c, false))) return r;
+            HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
+        } else if ((r = run_step(e, c, false))) return r;
+        if (phase == 3) {
+            if (e->ep_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
+            if ((r = apply_adam(e))) return r;
+        }
+    } else FAIL(e, NTF_EINVAL, "step_staged_ep: phase must be 1, 2 or 3");
     hipError_t s = hipGetLastError();
     if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
     return NTF_OK;
 }
-// where phase 1 leaves this shard's partial d(hidden) and phase 2 expects the sum: [B, h[-1]] floats (null when there is no hidden layer)
+// where phase 1 leaves this shard's partial d(hidden) and phase 3 expects the sum: [B, h[-1]] floats (null when there is no hidden layer)
 extern "C" int ntf_dh_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats) {
     if (!e || !dev_ptr || !n_floats) return NTF_EINVAL;
     *dev_ptr = e->L > 1 ? e->dAct[(e->L - 1) & 1] : nullptr;

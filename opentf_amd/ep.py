@@ -5,8 +5,8 @@ Why: the output layer holds > 99 % of the parameters (60.3 M of them at BASELINE
 gradients over xGMI every step (241 MB reduce-scatter + all-gather) and repeats the Flipout operand producer, the KL term and - unless
 sharded - Adam on every GPU.  Split along the expert axis, nothing of the output layer is exchanged or repeated: each GPU draws the
 noise, runs the forward / loss / backward kernels and Adam for its own experts only, and the one exchange of a step is the sum over
-GPUs of d(hidden) - [B, h[-1]] floats, 0.5 MB at B = 1000 - between the output layer's backward and the (replicated, tiny) hidden
-layers' backward.  The reference has no multi-GPU path (src/__config__.yaml:10 "TODO: multiple gpus"); the semantics are those of its
+GPUs of d(hidden) - [B, h[-1]] floats, 0.5 MB at B = 1000 - issued before the output layer's backward, which hides it, and waited for
+before the (replicated, tiny) hidden layers' backward.  The reference has no multi-GPU path (src/__config__.yaml:10 "TODO: multiple gpus"); the semantics are those of its
 single-process step on the same minibatch (src/mdl/fnn.py:122-140): labels and sampled negatives keep global expert ids, and the
 device generators are keyed by global ids, so G shards draw exactly what one engine holding the whole layer draws.
 
@@ -78,10 +78,14 @@ class ExpertParallel:
             B = min(global_B, n - off)
             steps += 1
             if train and exchange:
-                e.step_staged_ep(off, B, 1)        # forward, loss, this shard's output-layer backward (+ its Adam); partial d(hidden)
-                if self._dh is not None and dist.is_initialized():
-                    dist.all_reduce(self._dh[: B * self._H], op=dist.ReduceOp.SUM, group=self.group)   # stream-ordered; the host does not wait
-                e.step_staged_ep(off, B, 2)        # hidden layers' backward + Adam, identical on every rank
+                e.step_staged_ep(off, B, 1)        # forward, loss, fix-up: this shard's partial d(hidden)
+                work = None
+                if self._dh is not None and dist.is_initialized():   # the one exchange; RCCL moves it on its own stream ...
+                    work = dist.all_reduce(self._dh[: B * self._H], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                e.step_staged_ep(off, B, 2)        # ... while this shard's output-layer backward (+ its Adam) runs
+                if work is not None:
+                    work.wait()                    # stream-ordered: the engine's stream waits, the host does not
+                e.step_staged_ep(off, B, 3)        # hidden layers' backward + Adam, identical on every rank
             else:
                 e.step_staged(off, B, train=train, apply=train)   # evaluation needs no exchange: the loss shares are summed below
         if train and self.world > 1:

@@ -40,7 +40,8 @@ def _ep_epoch(engines, order, B, train=True):
             tot = torch.stack([d[: b * H] for d in dh]).sum(0)
             for d in dh: d[: b * H].copy_(tot)
             torch.cuda.synchronize()
-        for e in engines: e.step_staged_ep(off, b, 2)
+        for e in engines:
+            e.step_staged_ep(off, b, 2); e.step_staged_ep(off, b, 3)
     return sum(e.epoch_loss()[0] for e in engines)
 
 
@@ -136,6 +137,8 @@ def test_expert_shard_contract_errors():
         e.step_staged(0, 64, train=True, apply=True)           # a train step of one shard alone would use a partial d(hidden)
     with pytest.raises(libntf.NtfError, match="phase 2 without"):
         e.step_staged_ep(0, 64, 2)
+    with pytest.raises(libntf.NtfError, match="phase 3 without"):
+        e.step_staged_ep(0, 64, 3)
     e.step_staged(0, 64, train=False, apply=False)              # evaluation needs no exchange
     plain = _mk(ds, [128, 128, ds["M"]], True, 64, "uniform")
     plain.stage_order(np.arange(64, dtype=np.int64))
