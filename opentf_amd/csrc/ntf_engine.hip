@@ -682,6 +682,7 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
     return NTF_OK;
 }
 
+struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } };   // launches and timing scopes follow e->st
 static int side_stream(ntf_engine* e) {
     if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
     return NTF_OK;
@@ -697,12 +698,32 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
     int nslots;
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
+    bool prod_side = false;
     if (c.part >= 2) goto backward;   // expert-sharded step, later phases
-    if ((r = make_input(e, c))) return r;
-    if ((r = sample_negatives(e, c))) return r;
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
     if (e->cfg.bayesian) HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 12, e->st));
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
+    if (fused && e->cfg.bayesian && e->side_bwd) {
+        // The output layer's operand producer (eps, sigma, Wp, split planes, KL: one HBM-bound pass over 2 x M x H floats, 0.13 ms at config 2) reads
+        // parameters only: it runs on the side stream beside the step's small latency-bound head (gather, sampler, hidden layers, operand preparation)
+        // and is joined before the forward kernel.
+        if ((r = side_stream(e))) return r;
+        HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
+        HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
+        {
+            StreamRestore guard{e, e->st};
+            e->st = e->st3;
+            Scope t(e, F_FLIPOUT_OPERAND);
+            launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], e->P + lo.off[NTF_P_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
+                                   1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, e->P + lo.off[NTF_P_WEIGHT], lo.in, mfma_np(e), kW16Scale, range_ptr(e));
+            launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], e->P + lo.off[NTF_P_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
+                                   1.0 / out_nb, e->d_kl);
+        }
+        HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
+        prod_side = true;
+    }
+    if ((r = make_input(e, c))) return r;
+    if ((r = sample_negatives(e, c))) return r;
     if (fused) {
         if ((r = forward_layers(e, c, false, true))) return r;
         FusedOut f;
@@ -714,12 +735,12 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.dh = e->L > 1 ? e->dAct[(e->L - 1) & 1] : nullptr;
         f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
         if (e->cfg.bayesian) {
-            { Scope t(e, F_FLIPOUT_OPERAND);
+            if (!prod_side) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
                                      1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));   // + the split planes of Wp and mu
-              f.planes_ready = e->pl_wp != nullptr;
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                      1.0 / out_nb, e->d_kl); }
+            f.planes_ready = e->pl_wp != nullptr;
             f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
             f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         }
@@ -730,6 +751,15 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
         f.c_lo = e->ep_lo;
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
+        if (c.train && e->cfg.mfma != NTF_MFMA_F32) {
+            // operands of the dW kernel that depend on h and on the sign keys only (split planes of h / h*s_in, transposed s_out words): prepared here, in the
+            // step's head (beside the side-stream producer), not between the forward and the dW kernel
+            Scope t(e, F_OUT_FUSED_AUX);
+            const bool dz_packed = f.np == 2 && lo.in == 128 && e->pl_mu != nullptr;
+            const bool so_inj = e->cfg.bayesian && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
+            launch_fused_prep_planes(e->st, B, lo.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale, dz_packed ? &f.s_out : nullptr, so_inj);
+        }
+        if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
         nslots = fused_loss_slots(M);
@@ -754,7 +784,7 @@ backward:
     // Whole step on one GPU: the hidden layers' backward (a chain of small kernels, ~0.1 ms) needs d(hidden) only, not the output layer's dW kernel (0.4-0.6 ms,
     // whose last round leaves CUs idle): it runs on a side stream beside it; both are joined before Adam.
     const bool side = fused && e->cfg.bayesian && e->L > 1 && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
-    struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } } restore{e, e->st};
+    StreamRestore restore{e, e->st};
     if (side) {
         if ((r = side_stream(e))) return r;
         HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
@@ -789,8 +819,7 @@ backward:
                 while (ks > 1 && fused_dw_part_floats(M, li.in, ks) > (int64_t)e->cfg.max_batch * M) --ks;
                 if (ks > 1) { f.ksplit = ks; f.part = e->Zout; }
             }
-            if (f.bf16x6) { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, B, li.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale,
-                                                                                   f.dz_packed ? &sout_ : nullptr, f.s_out_inj); }
+            // (launch_fused_prep_planes - the h planes and the transposed s_out words this kernel reads - ran in the step's head)
             if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)out_nw * (float)c.global_B); }
             if (c.defer_dw) {
                 const int tile = fused_dw_tile(), total = (M + tile - 1) / tile;
@@ -1094,7 +1123,7 @@ extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int3
         if (phase == 2 && e->ep_side) {
             // the output layer's backward goes to the side stream: the main stream is about to wait for the d(hidden) exchange and then runs phase 3,
             // neither of which this kernel needs or feeds - it runs beside both and is joined before Adam
-            struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } } restore{e, e->st};
+            StreamRestore restore{e, e->st};
             HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
             e->st = e->st3;
             if ((r = run_step(e, c, false))) return r;
