@@ -1112,9 +1112,9 @@ extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int3
         if ((r = run_step(e, c, true))) return r;
         e->last_B = B; e->last_global_B = B;
         e->ep_ctx = c; e->ep_open = 1;
-        // measured: no gain for a shard (its split-K dW launch has no idle tail to fill, and the asynchronous exchange already runs beside dW on RCCL's
-        // stream) - kept behind NTF_SIDE_BWD=2 for A/B runs
-        e->ep_side = e->side_bwd >= 2 && e->L > 1 && e->cfg.fuse_adam != 2;
+        // phase 2 (this shard's dW kernel) on the side stream, beside the exchange and phase 3: one rank of 2 runs 1.684 -> 1.626 ms, of 4 1.605 -> 1.584, of 8
+        // unchanged (its split-K dW launch is a single round: no idle tail to fill)
+        e->ep_side = e->side_bwd >= 1 && e->L > 1 && e->cfg.fuse_adam != 2;
         if (e->ep_side) { if ((r = side_stream(e))) return r; HIPCHK(e, hipEventRecord(e->ev_fork, e->st)); }
     } else if (phase == 2 || phase == 3) {
         if (e->ep_open != phase - 1) FAIL(e, NTF_ESTATE, phase == 2 ? "step_staged_ep: phase 2 without a pending phase 1" : "step_staged_ep: phase 3 without a pending phase 2");
