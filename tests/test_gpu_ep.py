@@ -202,3 +202,22 @@ def test_wide_minibatch_hidden_bias_gradients():
         if "bias" not in k: continue
         s = ga[k] + gb[k]
         assert float(np.abs(s - gf[k]).max()) <= 2e-5 * float(np.abs(gf[k]).max()) + 1e-9, k
+
+
+@pytest.mark.parametrize("bayesian", [True, False])
+def test_two_stream_step_equals_the_one_stream_step(bayesian, monkeypatch):
+    """NTF_SIDE_BWD (default 1) moves the operand producer and the hidden layers' backward to a side stream beside the big kernels: the same kernels on the
+    same data - parameters bit-identical to the one-stream step's, losses equal up to the order of the KL atomics"""
+    ds = make_dataset("dblp", d=128, seed=9, n_rows=3000, n_experts=70_000)      # 274 expert tiles: several rounds of the dW kernel, no split-K
+    dims = [128, 64, 128, ds["M"]]
+    order = np.random.default_rng(2).permutation(ds["N"])[:2500].astype(np.int64)
+    out = []
+    for side in ("0", "1"):
+        monkeypatch.setenv("NTF_SIDE_BWD", side)
+        e = _mk(ds, dims, bayesian, 1000, "uniform")
+        loss = _full_epoch(e, order, 1000)
+        v = _full_epoch(e, order[:1000], 1000, train=False)
+        out.append((loss, v, e.state_dict())); e.close()
+    (l0, v0, p0), (l1, v1, p1) = out
+    assert abs(l0 - l1) <= 1e-9 * abs(l0) and abs(v0 - v1) <= 1e-9 * abs(v0)
+    for k in p0: assert np.array_equal(p0[k], p1[k]), k
