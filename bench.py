@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--gather-only", action="store_true", help="run only the whole-dataset gather launches (the PMC passes of the gather roofline)")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the short exact-f32 (--mfma f32) measurement printed beside the default line")
     ap.add_argument("--force-dist", action="store_true", help="init RCCL and all-reduce the gradient buffer even at world_size 1 (validation)")
+    ap.add_argument("--validate-on-one-gpu", action="store_true",
+                    help="N > 1 launch whose ranks ALL drive cuda:0 and talk over gloo (RCCL refuses two ranks on one device): exercises the multi-rank code path of this "
+                         "script on a 1-GPU box; the number it prints is not a measurement")
     ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "dp"],
                     help="N > 1: ep = expert-sharded output layer (every GPU steps the whole global minibatch on its 1/N of the experts; the only exchange is "
                          "d(hidden), opentf_amd/ep.py); dp = rows split over GPUs, gradients reduce-scattered (opentf_amd/dp.py); auto = ep when the model shards")
@@ -123,13 +126,15 @@ def main():
     # the JSON line), so everything but that line is sent to stderr at the file-descriptor level
     real_stdout = os.fdopen(os.dup(1), "w")
     sys.stdout.flush(); os.dup2(2, 1)
+    if a.validate_on_one_gpu: local = 0
     torch.cuda.set_device(local)
     if world > 1 or a.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.force_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ["NTF_DP_FORCE_ALLREDUCE"] = "1"; os.environ["NTF_EP_FORCE_EXCHANGE"] = "1"
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if a.validate_on_one_gpu: dist.init_process_group("gloo")
+        else: dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
     from opentf_amd import libntf
     from opentf_amd.dp import DataParallel
@@ -274,6 +279,7 @@ def main():
         "kernel_ms_per_step": breakdown, "kernel_ms_note": "separate pass of %d steps with events around every kernel family; the timed region carries events around the two output-layer kernels only" % k3,
     }
     if gather: out["roofline_gather"] = gather
+    if a.validate_on_one_gpu: out["validation_only"] = "all ranks on cuda:0 over gloo: code-path check, not a measurement"
     if a.ep_emulate:
         # one rank of G: it processed the whole global minibatch on 1/G of the experts, i.e. 1/G of the job
         out["metric"] += f" [one rank of {G} under --parallel ep, emulated on one GPU without the exchange]"

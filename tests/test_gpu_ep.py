@@ -1,6 +1,8 @@
 """Expert-sharded output layer (opentf_amd/ep.py, ntf_step_staged_ep): G engines, each owning a contiguous range of experts, emulated on ONE
 GPU (the exchange - the sum of d(hidden) over the shards - is done with torch here, by RCCL in production).  The contract under test: with
 the NATIVE generators (keyed by global expert ids) the shards together compute the step one engine holding the whole layer computes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -221,3 +223,30 @@ def test_two_stream_step_equals_the_one_stream_step(bayesian, monkeypatch):
     (l0, v0, p0), (l1, v1, p1) = out
     assert abs(l0 - l1) <= 1e-9 * abs(l0) and abs(v0 - v1) <= 1e-9 * abs(v0)
     for k in p0: assert np.array_equal(p0[k], p1[k]), k
+
+
+def test_two_processes_one_gpu(tmp_path):
+    """world size 2 for real: two processes, each with its own engine on this GPU, ExpertParallel over gloo (which moves CUDA tensors; RCCL refuses two ranks
+    on one device).  Exercises what the emulations above cannot: the asynchronous all-reduce between the phases, the loss all-reduce, the gather of the
+    state_dict, the epoch-end broadcast of the replicated layers - against the single-engine run."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ep_two_process_check.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    got = np.load(tmp_path / "ep2.npz")
+    ds = make_dataset("dblp", d=128, seed=3, n_rows=1500, n_experts=3000)
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(4).permutation(ds["N"])[:577].astype(np.int64)
+    full = _mk(ds, dims, True, 256, "uniform")
+    t_loss = _full_epoch(full, order, 256) / 3
+    v_loss = _full_epoch(full, order[:300], 256, train=False) / 2
+    assert abs(float(got["t_loss"]) - t_loss) <= 1e-5 * abs(t_loss) and abs(float(got["v_loss"]) - v_loss) <= 1e-5 * abs(v_loss)
+    ref = full.state_dict()
+    for k in ref:
+        assert got[k].shape == ref[k].shape, k
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, atol=2e-5, err_msg=k)

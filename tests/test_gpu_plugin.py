@@ -368,3 +368,58 @@ def test_plugin_trains_expert_sharded_under_torch_distributed(tmp_path, monkeypa
             assert torch.allclose(a["model_state_dict"][name], b["model_state_dict"][name], rtol=1e-4, atol=1e-6), name
         pr = torch.load(f"{m.output}/f{k}.test.pred", map_location="cpu", weights_only=False)
         assert tuple(pr["y_pred"].shape) == (len(splits["test"]), tv["member"].shape[1])
+
+
+@pytest.mark.parametrize("mode", ["ep", "dp"])
+def test_plugin_two_processes_one_gpu(mode, tmp_path):
+    """torchrun's situation for real at world size 2: two processes, each with its own engine on this GPU, collectives over gloo (RCCL refuses two ranks on
+    one device): Bnn.learn / test in the expert-sharded and the data-parallel form write the files of the single-process run with its weights."""
+    import socket
+    import subprocess
+    import sys
+    from opentf_amd.mdl.bnn import Bnn
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import plugin_two_process_check as chk
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path.insert(0, %r); import plugin_two_process_check as m; m.worker(%%d, 2, %d, %r, %r)" % (here, port, str(tmp_path), mode)   # (imported, not __main__: the checkpoint pickles m.Cfg)
+    procs = [subprocess.Popen([sys.executable, "-c", code % r], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    tv, splits = chk.dataset()
+    ref = Bnn(str(tmp_path / "single"), "cuda:0", 0, Cfg(chk.CFG)); ref.learn(tv, splits, None)
+    out_dir = [d for d in os.listdir(tmp_path / mode)][0]
+    a = torch.load(f"{ref.output}/f0.pt", map_location="cpu", weights_only=False)
+    b = torch.load(f"{tmp_path}/{mode}/{out_dir}/f0.pt", map_location="cpu", weights_only=False)
+    assert os.path.basename(ref.output) == out_dir and list(a.keys()) == list(b.keys()) and a["e"] == b["e"]
+    assert abs(a["t_loss"] - b["t_loss"]) <= 1e-4 * abs(a["t_loss"]) and abs(a["v_loss"] - b["v_loss"]) <= 1e-4 * abs(a["v_loss"])
+    for name, v in a["model_state_dict"].items():
+        w = b["model_state_dict"][name]
+        assert tuple(w.shape) == tuple(v.shape), name
+        assert torch.allclose(v, w, rtol=2e-4, atol=2e-5), (name, float((v - w).abs().max()))
+    pr = torch.load(f"{tmp_path}/{mode}/{out_dir}/f0.test.pred", map_location="cpu", weights_only=False)
+    assert tuple(pr["y_pred"].shape) == (len(splits["test"]), tv["member"].shape[1])
+
+
+@pytest.mark.parametrize("parallel", ["ep", "dp"])
+def test_bench_multi_rank_launch_on_one_gpu(parallel):
+    """the driver's N > 1 launch line (`python -m torch.distributed.run ... bench.py --gpus N ...`) with both ranks on this GPU over gloo: rank handling,
+    barriers, the max-over-ranks timing and the single JSON line of bench.py's multi-rank path"""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--validate-on-one-gpu", "--parallel", parallel,
+           "--rows", "20000", "--experts", "4096"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2000
+    assert d["config"]["parallelism"].startswith(parallel + "2") and d["value"] > 0 and np.isfinite(d["mean_loss"])
+    assert d["roofline"]["kernel"] in ("out_fused_fwd_loss_dh", "out_fused_dw_adam") and d["cpu_baseline"] is None
