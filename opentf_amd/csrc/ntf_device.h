@@ -96,6 +96,16 @@ template <int NP> __device__ __forceinline__ void planes_store_pair(uint16_t* pl
     for (int q = 0; q < NP; ++q) o[(size_t)q * 16 * H] = p[q];
 }
 
+// the same for four consecutive elements (row, j .. j+3), j % 4 == 0: one 8-byte store per plane
+template <int NP> __device__ __forceinline__ void planes_store_quad(uint16_t* planes, int64_t row, int j, int H, float x0, float x1, float x2, float x3, float scale) {
+    uint32_t p[3], q[3];
+    split_pair_np<NP>(x0, x1, scale, p);
+    split_pair_np<NP>(x2, x3, scale, q);
+    uint2* o = reinterpret_cast<uint2*>(planes + ((row >> 5) * (32 * NP) + (row & 31)) * H + j);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) o[(size_t)k * 8 * H] = make_uint2(p[k], q[k]);   // plane stride = 32 rows x H elements = 64 H bytes = 8 H uint2
+}
+
 // the same on the hardware exp2 / log2 / rcp (1 ulp each): log1p(e) = log(u) * e / (u - 1) with u = fl(1 + e) cancels the rounding of
 // 1 + e (~2 ulp overall, against ~1 ulp of the library call that costs >100 vector instructions); also returns log(sigma) for the KL
 __device__ __forceinline__ float softplus_rho_fast(float rho, float& log_sigma) {

@@ -278,13 +278,13 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
                 const int64_t row = e0 / H; const int j = (int)(e0 - row * H);
                 const float4 m4 = planes_mu ? *reinterpret_cast<const float4*>(pmu + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (np == 3) {
-                    planes_store_pair<3>(planes_w, row, j, H, ov[0], ov[1], 1.f); planes_store_pair<3>(planes_w, row, j + 2, H, ov[2], ov[3], 1.f);
-                    if (planes_mu) { planes_store_pair<3>(planes_mu, row, j, H, m4.x, m4.y, 1.f); planes_store_pair<3>(planes_mu, row, j + 2, H, m4.z, m4.w, 1.f); }
+                    planes_store_quad<3>(planes_w, row, j, H, ov[0], ov[1], ov[2], ov[3], 1.f);
+                    if (planes_mu) planes_store_quad<3>(planes_mu, row, j, H, m4.x, m4.y, m4.z, m4.w, 1.f);
                 } else {
                     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
                     if (planes_mu) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(m4.x), fabsf(m4.y)), fmaxf(fabsf(m4.z), fabsf(m4.w))));
-                    planes_store_pair<2>(planes_w, row, j, H, ov[0], ov[1], pscale); planes_store_pair<2>(planes_w, row, j + 2, H, ov[2], ov[3], pscale);
-                    if (planes_mu) { planes_store_pair<2>(planes_mu, row, j, H, m4.x, m4.y, pscale); planes_store_pair<2>(planes_mu, row, j + 2, H, m4.z, m4.w, pscale); }
+                    planes_store_quad<2>(planes_w, row, j, H, ov[0], ov[1], ov[2], ov[3], pscale);
+                    if (planes_mu) planes_store_quad<2>(planes_mu, row, j, H, m4.x, m4.y, m4.z, m4.w, pscale);
                 }
             }
         } else {
