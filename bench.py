@@ -265,7 +265,9 @@ def main():
                  6: "bf16x6: operands split exactly into 3 bf16 values, 6 bf16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 6",
                  3: "fp16x3: operands * 2^k split into 2 fp16 values (22 bits), 3 fp16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 3"}[nprod]
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": pmc_traffic(dom, a, ds), "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[dom],
+                "traffic": None if ep else pmc_traffic(dom, a, ds),
+                "traffic_source": "per-launch mean of the separate rocprofv3 --pmc passes of this command committed under profiles/ (collect_r2.sh), not counted in this run",
+                "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[dom],
                 "arithmetic": arith, "hw_mfma_tflops": ach * nprod}
     out = {
         "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
