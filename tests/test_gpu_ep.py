@@ -250,3 +250,21 @@ def test_two_processes_one_gpu(tmp_path):
     for k in ref:
         assert got[k].shape == ref[k].shape, k
         np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_inference_on_expert_shards_gives_the_whole_models_columns():
+    """the generators being keyed by global expert ids, an expert shard's inference (MC mean of nmc stochastic forwards, logits) equals the corresponding
+    columns of the whole model's - a test() spread over the GPUs would only have to merge per-shard top-K lists"""
+    ds = make_dataset("dblp", d=128, seed=12, n_rows=800, n_experts=2000)
+    dims = [128, 128, ds["M"]]
+    rows = np.arange(300, dtype=np.int64)
+    full = _mk(ds, dims, True, 300, "uniform")
+    p_full = full.forward(rows, nmc=3); z_full = full.logits(rows)
+    shards = expert_shards(ds["M"], 3)
+    got_p, got_z = [], []
+    for s in shards:
+        e = _mk(ds, dims, True, 300, "uniform", shard=s, world=3)
+        got_p.append(e.forward(rows, nmc=3)); got_z.append(e.logits(rows)); e.close()
+    p, z = np.concatenate(got_p, axis=1), np.concatenate(got_z, axis=1)
+    assert p.shape == p_full.shape
+    assert np.array_equal(z, z_full) and np.array_equal(p, p_full)
