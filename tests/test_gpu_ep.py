@@ -78,19 +78,23 @@ CASES = {
     "bnn_two_hidden_h64_g2": (True, lambda ds: [128, 96, 64, ds["M"]], "uniform", 2, 200, False),
     "bnn_multihot_g2": (True, lambda ds: [ds["S"], 128, ds["M"]], "uniform", 2, 200, True),
     "bnn_no_hidden_g2": (True, lambda ds: [128, ds["M"]], "uniform", 2, 200, False),
+    # where Adam of the output layer runs: 0 = one flat kernel at the end of phase 3, 2 = per expert chunk on a side stream (1, the default above: in the dW epilogue)
+    "bnn_flat_adam_g2": (True, lambda ds: [128, 128, ds["M"]], "uniform", 2, 256, False, 0),
+    "bnn_chunked_adam_g2": (True, lambda ds: [128, 128, ds["M"]], "uniform", 2, 256, False, 2),
 }
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_expert_shards_compute_the_single_engine_step(case):
-    bayesian, mkdims, nsd, G, B, multihot = CASES[case]
+    bayesian, mkdims, nsd, G, B, multihot = CASES[case][:6]
+    fuse_adam = CASES[case][6] if len(CASES[case]) > 6 else 1
     ds = make_dataset("dblp", d=128, seed=3, n_rows=1500, n_experts=3000)
     dims = mkdims(ds)
     order = np.random.default_rng(4).permutation(ds["N"])[: 2 * B + 77].astype(np.int64)    # two full batches and a ragged one
     shards = expert_shards(ds["M"], G)
     assert shards[0][0] == 0 and shards[-1][1] == ds["M"] and all(a[1] == b[0] and a[1] % 256 == 0 for a, b in zip(shards, shards[1:]))
-    full = _mk(ds, dims, bayesian, B, nsd, multihot=multihot)
-    eng = [_mk(ds, dims, bayesian, B, nsd, shard=s, world=G, multihot=multihot) for s in shards]
+    full = _mk(ds, dims, bayesian, B, nsd, multihot=multihot, fuse_adam=fuse_adam)
+    eng = [_mk(ds, dims, bayesian, B, nsd, shard=s, world=G, multihot=multihot, fuse_adam=fuse_adam) for s in shards]
 
     # --- first step: the output layer sees bit-identical operands on both sides
     l_full = _full_epoch(full, order[:B], B); l_ep = _ep_epoch(eng, order[:B], B)
