@@ -122,15 +122,19 @@ def make_fnn(base):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 dist.barrier()
 
+        def _model_dims(self, teamsvecs):
+            """[D, *h, M] of the model for these matrices (D = the table's width when a skill table is registered)"""
+            table = teamsvecs.get("skill_table") if hasattr(teamsvecs, "get") else None
+            n_in = int(np.asarray(table).shape[1]) if table is not None else int(teamsvecs["skill"].shape[1])
+            return [n_in] + [int(x) for x in cfg_get(self.cfg, "h")] + [int(teamsvecs["member"].shape[1])]
+
         def _new_engine(self, teamsvecs, max_batch, train=False):
             from .. import libntf
             skill, member = teamsvecs["skill"], teamsvecs["member"]
-            n_in, n_out = skill.shape[1], member.shape[1]
-            h = [int(x) for x in cfg_get(self.cfg, "h")]
-            dims = [int(n_in)] + h + [int(n_out)]
+            dims = self._model_dims(teamsvecs)
             table = teamsvecs.get("skill_table") if hasattr(teamsvecs, "get") else None
             if table is not None:
-                mode, dims[0] = libntf.INPUT_MEANPOOL, int(np.asarray(table).shape[1])
+                mode = libntf.INPUT_MEANPOOL
             elif scipy.sparse.issparse(skill):
                 mode = libntf.INPUT_MULTIHOT
             else:
@@ -248,12 +252,19 @@ def make_fnn(base):
             import torch
             assert os.path.isdir(self.output), f"No folder for {self.output} exist!"
             b = int(cfg_get(self.cfg, "b"))
-            if dist_rank() != 0:
+            import torch.distributed as dist
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            # expert-sharded runs infer sharded too: every rank computes the probabilities (or the top-K candidates, and its share of the entropy sums) of its own
+            # experts - the generators are keyed by global expert ids, so these ARE the whole model's columns - and rank 0 merges and writes
+            sharded = world > 1 and self._parallel_mode(self._model_dims(teamsvecs), world) == "ep"
+            writer = dist_rank() == 0
+            if not sharded and not writer:
                 # one writer: rank 0 runs the inference and writes the .pred files (the reference's test() is single-process);
                 # the others wait for it so that evaluate() finds complete files
                 self._barrier()
                 return
-            engine, dims = self._engine(teamsvecs, b)
+            engine, dims = self._engine(teamsvecs, b, train=sharded)
+            lo = engine.expert_lo if sharded else 0
             M = dims[-1]
             topK = cfg_get(testcfg, "topK")
             nmc = int(cfg_get(self.cfg, "nmc", 1) or 1)
@@ -275,13 +286,19 @@ def make_fnn(base):
                             if self.is_bayesian:
                                 pred_uncertainty, model_uncertainty = [], []  # re-initialised per batch, as the reference does (fnn.py:203)
                             if on_gpu_topk:
-                                out = engine.forward_topk(rr, int(topK), nmc=nmc, uncertainty=self.is_bayesian)
-                                vals.append(out[0]); idxs.append(out[1])
+                                out = engine.forward_topk(rr, min(int(topK), engine.dims[-1]), nmc=nmc, uncertainty=self.is_bayesian)
+                                v, i = out[0], out[1]
+                                if sharded: v, i = self._merge_topk(v, i.astype(np.int64) + lo, int(topK))
+                                vals.append(v); idxs.append(i)
                             else:
                                 out = engine.forward(rr, nmc=nmc, uncertainty=self.is_bayesian)
-                                dense.append(out[0] if self.is_bayesian else out)
-                            if self.is_bayesian:
-                                pred_uncertainty.append(out[-2]); model_uncertainty.append(out[-1])
+                                p = out[0] if self.is_bayesian else out
+                                dense.append(self._gather_columns(p) if sharded else p)
+                            if self.is_bayesian:   # both entropies are sums over experts: a shard returns its share
+                                pu, mu = (self._sum_over_ranks(out[-2]), self._sum_over_ranks(out[-1])) if sharded else (out[-2], out[-1])
+                                pred_uncertainty.append(pu); model_uncertainty.append(mu)
+                        if not writer:
+                            continue
                         if on_gpu_topk:
                             y_pred = self._coo_from_topk(np.concatenate(vals), np.concatenate(idxs), (len(rows), M))
                         else:
@@ -295,6 +312,45 @@ def make_fnn(base):
                         log.info(f"{self.name()} model predictions for fold{foldidx}.{pred_set}.{epoch} has saved at {self.output}/f{foldidx}.{pred_set}.{epoch}pred")
             self._barrier()
             self._release(engine)
+
+        # ---- collectives of the sharded test() (small host arrays; nccl moves them through the GPU, gloo directly)
+        @staticmethod
+        def _all_gather_cols(a):
+            """[B, m_r] per rank -> list of the ranks' arrays, on every rank"""
+            import torch
+            import torch.distributed as dist
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            world = dist.get_world_size()
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            n = torch.tensor([t.shape[1]], dtype=torch.int64, device=dev)
+            counts = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(counts, n)
+            counts = [int(c.item()) for c in counts]
+            pad = torch.zeros((t.shape[0], max(counts)), dtype=t.dtype, device=dev)
+            pad[:, : t.shape[1]] = t
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad)
+            return [p[:, :c].cpu().numpy() for p, c in zip(parts, counts)]
+
+        def _gather_columns(self, p):
+            return np.concatenate(self._all_gather_cols(p), axis=1)
+
+        def _merge_topk(self, vals, idx, k):
+            """per-shard top-K candidates (global expert ids) -> the K largest of their union per row; ties go to the smaller expert id"""
+            v = np.concatenate(self._all_gather_cols(vals), axis=1)
+            i = np.concatenate(self._all_gather_cols(idx), axis=1)
+            o = np.argsort(i, axis=1, kind="stable")
+            v, i = np.take_along_axis(v, o, axis=1), np.take_along_axis(i, o, axis=1)
+            o = np.argsort(-v, axis=1, kind="stable")[:, :k]
+            return np.take_along_axis(v, o, axis=1), np.take_along_axis(i, o, axis=1)
+
+        @staticmethod
+        def _sum_over_ranks(a):
+            import torch
+            import torch.distributed as dist
+            t = torch.from_numpy(np.ascontiguousarray(a)).to("cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.cpu().numpy()
 
         @staticmethod
         def _topk_sparse(probs, k):

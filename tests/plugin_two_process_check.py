@@ -37,6 +37,14 @@ def dataset():
 CFG = dict(b=64, e=2, ns=3, lr=0.01, es=5, h=[128], spe=0, l="bce", tpw=10, tnw=1, nsd="uniform", nmc=2)
 
 
+def predictions(m, tv, splits, writer):
+    """test() twice: dense predictions (kept as f0.test.dense.pred) and the top-5 sparse form (f0.test.pred)"""
+    import shutil
+    m.test(tv, splits, Cfg(per_epoch=False, on_train=False, topK=None))
+    if writer: shutil.copy(f"{m.output}/f0.test.pred", f"{m.output}/f0.test.dense.pred")
+    m.test(tv, splits, Cfg(per_epoch=False, on_train=False, topK=5))
+
+
 def worker(rank, world, port, out_dir, mode):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", NTF_PARALLEL=mode)
@@ -47,7 +55,7 @@ def worker(rank, world, port, out_dir, mode):
     m = Bnn(os.path.join(out_dir, mode), "cuda:0", 0, Cfg(CFG))
     m.learn(tv, splits, None)
     assert type(m._runner).__name__ == {"ep": "ExpertParallel", "dp": "DataParallel"}[mode]
-    m.test(tv, splits, Cfg(per_epoch=False, on_train=False, topK=None))
+    predictions(m, tv, splits, rank == 0)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -398,8 +398,22 @@ def test_plugin_two_processes_one_gpu(mode, tmp_path):
         w = b["model_state_dict"][name]
         assert tuple(w.shape) == tuple(v.shape), name
         assert torch.allclose(v, w, rtol=2e-4, atol=2e-5), (name, float((v - w).abs().max()))
-    pr = torch.load(f"{tmp_path}/{mode}/{out_dir}/f0.test.pred", map_location="cpu", weights_only=False)
-    assert tuple(pr["y_pred"].shape) == (len(splits["test"]), tv["member"].shape[1])
+    # predictions: under "ep" every rank infers its own experts and rank 0 merges (dense columns, top-K candidates, entropy shares); under "dp" rank 0 alone
+    chk.predictions(ref, tv, splits, True)
+    for name in ("f0.test.dense.pred", "f0.test.pred"):
+        pa = torch.load(f"{ref.output}/{name}", map_location="cpu", weights_only=False)
+        pb = torch.load(f"{tmp_path}/{mode}/{out_dir}/{name}", map_location="cpu", weights_only=False)
+        ya, yb = pa["y_pred"], pb["y_pred"]
+        assert tuple(yb.shape) == (len(splits["test"]), tv["member"].shape[1]) and ya.is_sparse == yb.is_sparse
+        if ya.is_sparse:
+            assert yb.is_coalesced() and yb._nnz() == ya._nnz() == 5 * len(splits["test"])
+            va = np.sort(ya.values().numpy().reshape(-1, 5), axis=1); vb = np.sort(yb.values().numpy().reshape(-1, 5), axis=1)
+            np.testing.assert_allclose(vb, va, rtol=2e-3, atol=2e-4)          # the two runs' weights agree to rounding: so do the five largest probabilities
+        else:
+            np.testing.assert_allclose(yb.numpy(), ya.numpy(), rtol=2e-3, atol=2e-4)
+        for key in ("pred", "model"):
+            assert len(pb["uncertainty"][key]) == len(pa["uncertainty"][key]) == 1
+            np.testing.assert_allclose(pb["uncertainty"][key][0], pa["uncertainty"][key][0], rtol=5e-3, atol=5e-3)
 
 
 @pytest.mark.parametrize("parallel", ["ep", "dp"])
