@@ -100,7 +100,8 @@ struct ntf_engine {
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
     hipStream_t st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the hidden layers' backward runs beside the output layer's dW kernel
-    int side_bwd = 1;                 // NTF_SIDE_BWD=0 keeps the whole backward on one stream (A/B runs)
+    hipStream_t st4 = nullptr; hipEvent_t ev_aux = nullptr;   // auxiliary stream: what the step's head needs from the row ids / sign keys only (sampler, s_out words)
+    int side_bwd = 1;                 // NTF_SIDE_BWD=0 keeps the whole step on one stream (A/B runs)
     // expert-sharded output layer (ntf_config.expert_lo ..): this engine owns experts [ep_lo, ep_lo + dims[L]) of Mg
     bool ep = false; int ep_lo = 0, Mg = 0, ep_world = 1;
     bool ep_side = false;                   // this step's phase 2 runs on the side stream
@@ -685,6 +686,7 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
 struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } };   // launches and timing scopes follow e->st
 static int side_stream(ntf_engine* e) {
     if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
+    if (!e->st4) { HIPCHK(e, hipStreamCreateWithFlags(&e->st4, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_aux, hipEventDisableTiming)); }
     return NTF_OK;
 }
 
@@ -698,32 +700,50 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
     int nslots;
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
-    bool prod_side = false;
+    bool prod_side = false, aux = false, swt_aux = false, loss_side = false;
+    // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
+    const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
     if (c.part >= 2) goto backward;   // expert-sharded step, later phases
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
     if (e->cfg.bayesian) HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 12, e->st));
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
-    if (fused && e->cfg.bayesian && e->side_bwd) {
-        // The output layer's operand producer (eps, sigma, Wp, split planes, KL: one HBM-bound pass over 2 x M x H floats, 0.13 ms at config 2) reads
-        // parameters only: it runs on the side stream beside the step's small latency-bound head (gather, sampler, hidden layers, operand preparation)
-        // and is joined before the forward kernel.
+    if (fused && e->side_bwd) {
+        // Three streams through the step's head (round 3; profiles/r3_step_timeline.md).  What precedes the forward kernel is a chain of small latency-bound
+        // launches and one HBM-bound pass, and most links of it do not depend on each other:
+        //   side (st3): the output layer's operand producer (eps, sigma, Wp, split planes, KL: one pass over 2 x M x H floats, 0.12 ms at config 2) - parameters only;
+        //   aux  (st4): what needs the row ids / the sign key only - the bias producer, the negative sampler, the transposed s_out words of the dW kernel;
+        //   main (st):  gather -> hidden layers -> h planes, which is then shorter than the producer beside it.
         if ((r = side_stream(e))) return r;
         HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
-        HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
-        {
-            StreamRestore guard{e, e->st};
+        StreamRestore guard{e, e->st};
+        if (e->cfg.bayesian) {
+            HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
             e->st = e->st3;
-            Scope t(e, F_FLIPOUT_OPERAND);
-            launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], e->P + lo.off[NTF_P_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                   1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, e->P + lo.off[NTF_P_WEIGHT], lo.in, mfma_np(e), kW16Scale, range_ptr(e));
-            launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], e->P + lo.off[NTF_P_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
-                                   1.0 / out_nb, e->d_kl);
+            { Scope t(e, F_FLIPOUT_OPERAND);
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], e->P + lo.off[NTF_P_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
+                                     1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, e->P + lo.off[NTF_P_WEIGHT], lo.in, mfma_np(e), kW16Scale, range_ptr(e)); }
+            HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
+            prod_side = true;
         }
-        HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
-        prod_side = true;
+        HIPCHK(e, hipStreamWaitEvent(e->st4, e->ev_fork, 0));
+        e->st = e->st4;
+        if (e->cfg.bayesian) { Scope t(e, F_FLIPOUT_OPERAND);
+            launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], e->P + lo.off[NTF_P_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
+                                   1.0 / out_nb, e->d_kl); }
+        if ((r = sample_negatives(e, c))) return r;
+        if (c.train && e->cfg.bayesian && e->cfg.mfma != NTF_MFMA_F32 && mfma_np(e) == 2 && lo.in == 128 && e->pl_mu != nullptr) {
+            const SignSpec so = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out), si = sign_spec(e, c, e->L - 1, T_S_IN, lo.in);
+            if (so.inj == nullptr && si.inj == nullptr) {   // (injected signs: the words are transposed from the packed image k_sign_bits writes on the main stream)
+                Scope t(e, F_OUT_FUSED_AUX);
+                launch_fused_prep_planes(e->st, B, lo.in, M, 1, e->fws, 2, kH16Scale, &so, 0, 1);
+                swt_aux = true;
+            }
+        }
+        HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
+        aux = true;
     }
     if ((r = make_input(e, c))) return r;
-    if ((r = sample_negatives(e, c))) return r;
+    if (!aux && (r = sample_negatives(e, c))) return r;
     if (fused) {
         if ((r = forward_layers(e, c, false, true))) return r;
         FusedOut f;
@@ -757,9 +777,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             Scope t(e, F_OUT_FUSED_AUX);
             const bool dz_packed = f.np == 2 && lo.in == 128 && e->pl_mu != nullptr;
             const bool so_inj = e->cfg.bayesian && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
-            launch_fused_prep_planes(e->st, B, lo.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale, dz_packed ? &f.s_out : nullptr, so_inj);
+            launch_fused_prep_planes(e->st, B, lo.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale, dz_packed ? &f.s_out : nullptr, so_inj, swt_aux ? 2 : 3);
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
+        if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
         nslots = fused_loss_slots(M);
@@ -771,7 +792,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         launch_loss_special(e->st, e->Zout, M, B, M, c.rows_dev, e->m_indptr, e->m_indices, neg, e->cfg.ns, e->cfg.tpw, e->cfg.tnw, inv_B,
                             c.train ? e->dZout : nullptr, e->row_fix);
     }
-    {
+    loss_side = side;   // a whole train step: the loss reduction is not on the way to the dW kernel - it goes first on the side stream, beside it
+    if (!loss_side) {
         Scope t(e, F_LOSS);
         const double kl_scale = ((double)B / (double)c.global_B) / (double)c.global_B;
         launch_loss_finalize(e->st, e->partial, nslots, e->row_fix, B, inv_B, e->cfg.bayesian ? e->d_kl : nullptr, kl_scale, e->d_loss,
@@ -783,18 +805,26 @@ backward:
     const float kl_share = (float)B / (float)c.global_B;
     // Whole step on one GPU: the hidden layers' backward (a chain of small kernels, ~0.1 ms) needs d(hidden) only, not the output layer's dW kernel (0.4-0.6 ms,
     // whose last round leaves CUs idle): it runs on a side stream beside it; both are joined before Adam.
-    const bool side = fused && e->cfg.bayesian && e->L > 1 && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
     StreamRestore restore{e, e->st};
     if (side) {
         if ((r = side_stream(e))) return r;
         HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
+        HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
+        if (loss_side) {
+            e->st = e->st3;
+            { Scope t(e, F_LOSS);
+              const double kl_scale = ((double)B / (double)c.global_B) / (double)c.global_B;
+              launch_loss_finalize(e->st, e->partial, nslots, e->row_fix, B, inv_B, e->cfg.bayesian ? e->d_kl : nullptr, kl_scale, e->d_loss,
+                                   accumulate_epoch ? e->d_acc : nullptr, e->d_acc_steps); }
+            e->st = restore.main;
+        }
     }
     for (int l = e->L - 1; l >= 0; --l) {
         const LayerInfo& li = e->layers[l];
         const bool last = (l == e->L - 1);
         if (c.part == 2 && !last) break;       // the hidden layers wait for the sum of d(hidden) over the expert shards
         if (c.part == 3 && last) continue;
-        if (side && l == e->L - 2) { HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0)); e->st = e->st3; }   // from here on: launches and timing scopes on the side stream
+        if (side && l == e->L - 2) e->st = e->st3;   // from here on: launches and timing scopes on the side stream (which waits for ev_fork, above)
         const float* in = e->act[l];
         float* gW = e->G + li.off[NTF_P_WEIGHT]; float* gb = e->G + li.off[NTF_P_BIAS];
         float* gRW = e->cfg.bayesian ? e->G + li.off[NTF_P_RHO_WEIGHT] : nullptr;
@@ -926,17 +956,16 @@ static int apply_adam(ntf_engine* e) {
     e->adam_t += 1;
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - std::pow(b1, (double)e->adam_t), bc2 = 1.0 - std::pow(b2, (double)e->adam_t);
-    auto run = [&](int64_t lo, int64_t hi) {
-        if (hi > lo) launch_adam(e->st, e->P + lo, e->G + lo, e->M1 + lo, e->V2 + lo, hi - lo, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
-    };
-    if (!e->adam_in_dw) { run(0, e->n_params); return NTF_OK; }
-    // the output layer's weight (and rho_weight) segments were updated inside the dW kernel: run over the rest
+    if (!e->adam_in_dw) { launch_adam(e->st, e->P, e->G, e->M1, e->V2, e->n_params, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2)); return NTF_OK; }
+    // the output layer's weight (and rho_weight) segments were updated inside the dW kernel: one launch over the rest
     e->adam_in_dw = false;
     const LayerInfo& lo = e->layers[e->L - 1];
     const int64_t w0 = lo.off[NTF_P_WEIGHT], w1 = lo.off[NTF_P_BIAS];  // segments are laid out weight, bias, rho_weight, rho_bias
-    run(0, w0);
-    if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS]; run(w1, r0); run(r1, e->n_params); }
-    else run(w1, e->n_params);
+    int64_t rg[6]; int n = 0;
+    rg[2 * n] = 0; rg[2 * n + 1] = w0; ++n;
+    if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS]; rg[2 * n] = w1; rg[2 * n + 1] = r0; ++n; rg[2 * n] = r1; rg[2 * n + 1] = e->n_params; ++n; }
+    else { rg[2 * n] = w1; rg[2 * n + 1] = e->n_params; ++n; }
+    launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
     return NTF_OK;
 }
 
@@ -952,8 +981,8 @@ static int apply_adam_ranges(ntf_engine* e, const int64_t* lo_hi, int n) {
     for (int k = 0; k < n; ++k) {
         const int64_t lo = lo_hi[2 * k], hi = lo_hi[2 * k + 1];
         if (lo < 0 || hi > e->n_params || lo > hi || (lo & 3)) FAIL(e, NTF_EINVAL, "apply_ranges: a range outside the flat buffers, reversed, or not 16-byte aligned");
-        if (hi > lo) launch_adam(e->st, e->P + lo, e->G + lo, e->M1 + lo, e->V2 + lo, hi - lo, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
     }
+    launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, lo_hi, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
     return NTF_OK;
 }
 

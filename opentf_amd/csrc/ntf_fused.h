@@ -72,7 +72,7 @@ int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are p
 // phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
 // s_out != null: also the transposed s_out sign words the packed fp16x3 dW kernel reads (k_sign_words_T)
-void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 3, float h_scale = 1.f, const SignSpec* s_out = nullptr, int s_out_inj = 0);
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 3, float h_scale = 1.f, const SignSpec* s_out = nullptr, int s_out_inj = 0, int which = 3);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
 // after a probs pass: ent_rows[i] += scale * the pass's entropy terms (nullable); transpose: P [B, M] = PT^T
 // unpack_inv_scale > 0: PT holds packed fp16 plane pairs (the fp16x3 step's dzT): P = (hi + lo) * unpack_inv_scale

@@ -2284,15 +2284,17 @@ exact_f32:
 }
 
 // bf16 split planes of the hidden activations for the dW kernel (once per step, after launch_fused_out_fwd's phase 1)
-void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws_, int np, float h_scale, const SignSpec* s_out, int s_out_inj) {
+// which: 1 = the transposed s_out words (they depend on the sign key only: the engine issues them on its auxiliary stream), 2 = the h planes, 3 = both
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws_, int np, float h_scale, const SignSpec* s_out, int s_out_inj, int which) {
     const Geom g = geom(B, M);
     const WsLayout w = ws_layout(B, H, M);
     char* ws = static_cast<char*>(ws_);
-    if (bayes && s_out) {   // packed fp16x3 path: the dW kernel's s_out words, transposed once
+    if (bayes && s_out && (which & 1)) {   // packed fp16x3 path: the dW kernel's s_out words, transposed once
         const int ncb_all = rup(M, DW_TC) / 32, nib = g.Bpad / 32;
         hipLaunchKernelGGL(k_sign_words_T, dim3((ncb_all + 7) / 8, (nib + SWT_IB - 1) / SWT_IB), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws + w.sbits), s_out_inj, s_out->k0, s_out->k1,
                            B, g.nCB, ncb_all, nib, reinterpret_cast<uint32_t*>(ws + w.sbitsT));
     }
+    if (!(which & 2)) return;
     const int n = g.Bpad * H;
     hipLaunchKernelGGL(k_prep_planes_T, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(ws + w.hz), reinterpret_cast<const float*>(ws + w.hs),
                        bayes, g.Bpad, H, np == 2 ? 2 : 3, h_scale, reinterpret_cast<uint16_t*>(ws + w.hb));

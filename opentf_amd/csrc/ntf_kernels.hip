@@ -515,6 +515,37 @@ __device__ __forceinline__ bool is_member(const int32_t* mi, int npos, int c) {
     for (int p = 0; p < npos; ++p) if (mi[p] == c) return true;
     return false;
 }
+// The sampler threads are one dependent chain per row (rows -> indptr -> indices -> candidates): what they re-read - the row's positives and the picks
+// made so far - stays in registers (statically indexed, so not in scratch); rows with more than 8 positives / ns > 8 read the rest from memory.
+constexpr int NS_REG = 8;
+struct RowSet {
+    int pos[NS_REG], pick[NS_REG];
+    const int32_t* mi; int npos; int64_t* o;
+    __device__ __forceinline__ void init(const int32_t* mi_, int npos_, int64_t* o_) {
+        mi = mi_; npos = npos_; o = o_;
+#pragma unroll
+        for (int p = 0; p < NS_REG; ++p) { pos[p] = p < npos ? mi[p] : -1; pick[p] = -1; }
+    }
+    __device__ __forceinline__ bool member(int c) const {
+        bool b = false;
+#pragma unroll
+        for (int p = 0; p < NS_REG; ++p) b |= (pos[p] == c);      // unused slots hold -1, candidates are >= 0
+        for (int p = NS_REG; p < npos && !b; ++p) b = (mi[p] == c);
+        return b;
+    }
+    __device__ __forceinline__ bool picked(int q, int c) const {
+        bool b = false;
+#pragma unroll
+        for (int p = 0; p < NS_REG; ++p) b |= (pick[p] == c);     // slots >= q still hold -1
+        for (int p = NS_REG; p < q && !b; ++p) b = ((int)o[p] == c);
+        return b;
+    }
+    __device__ __forceinline__ void put(int q, int c) {
+#pragma unroll
+        for (int p = 0; p < NS_REG; ++p) if (p == q) pick[p] = c;
+        o[q] = c;
+    }
+};
 
 __global__ void k_ns_uniform(const int64_t* __restrict__ rows, int B, int M, int ns, const int64_t* __restrict__ m_indptr,
                              const int32_t* __restrict__ m_indices, uint32_t k0, uint32_t k1, uint32_t step, uint32_t row0, int64_t* __restrict__ out) {
@@ -524,32 +555,24 @@ __global__ void k_ns_uniform(const int64_t* __restrict__ rows, int B, int M, int
     const int32_t* mi = m_indices + m_indptr[team];
     const int npos = (int)(m_indptr[team + 1] - m_indptr[team]);
     int64_t* o = out + (int64_t)i * ns;
+    RowSet rs; rs.init(mi, npos, o);
     uint32_t ctr = 0;
     for (int q = 0; q < ns; ++q) {
         int pick = -1;
         for (int tries = 0; tries < 4096 && pick < 0; ++tries) {
             const uint4 r = philox4x32(make_uint4((uint32_t)i + row0, ctr++, step, 0x4e533031u), make_uint2(k0, k1));
             const uint32_t cand[4] = {r.x, r.y, r.z, r.w};
-            for (int u = 0; u < 4 && pick < 0; ++u) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 const int c = (int)__umulhi(cand[u], (uint32_t)M);
-                bool bad = is_member(mi, npos, c);
-                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
-                if (!bad) pick = c;
+                if (pick < 0 && !rs.member(c) && !rs.picked(q, c)) pick = c;
             }
         }
         if (pick < 0) {  // fewer than ns negatives in the row: topk then returns positives (fnn.py:54); any unused column
-            for (int c = 0; c < M && pick < 0; ++c) {
-                bool bad = false;
-                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
-                if (!bad && !is_member(mi, npos, c)) pick = c;
-            }
-            for (int c = 0; c < M && pick < 0; ++c) {
-                bool bad = false;
-                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
-                if (!bad) pick = c;
-            }
+            for (int c = 0; c < M && pick < 0; ++c) if (!rs.picked(q, c) && !rs.member(c)) pick = c;
+            for (int c = 0; c < M && pick < 0; ++c) if (!rs.picked(q, c)) pick = c;
         }
-        o[q] = pick;
+        rs.put(q, pick);
     }
 }
 void launch_ns_uniform(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
@@ -567,6 +590,7 @@ __global__ void k_ns_alias(const int64_t* __restrict__ rows, int B, int M, int n
     const int32_t* mi = m_indices + m_indptr[team];
     const int npos = (int)(m_indptr[team + 1] - m_indptr[team]);
     int64_t* o = out + (int64_t)i * ns;
+    RowSet rs; rs.init(mi, npos, o);
     double negw = total_weight;
     for (int p = 0; p < npos; ++p) negw -= weight[mi[p]];
     const bool fallback = !(negw > 1e-12 * total_weight);  // all sampling weight sits on the row's members (fnn.py:67-69)
@@ -582,20 +606,16 @@ __global__ void k_ns_alias(const int64_t* __restrict__ rows, int B, int M, int n
                 if (fallback) bad = false;  // uniform over ALL columns, members included
                 else {
                     if (u01(b) >= prob[c]) c = alias[c];
-                    bad = is_member(mi, npos, c) || !(weight[c] > 0.0);
+                    bad = rs.member(c) || !(weight[c] > 0.0);
                 }
-                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) bad = rs.picked(q, c);
                 if (!bad) pick = c;
             }
         }
         if (pick < 0) {  // fewer than ns columns with weight: multinomial would raise; take any unused column
-            for (int c = 0; c < M && pick < 0; ++c) {
-                bool bad = false;
-                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
-                if (!bad) pick = c;
-            }
+            for (int c = 0; c < M && pick < 0; ++c) if (!rs.picked(q, c)) pick = c;
         }
-        o[q] = pick;
+        rs.put(q, pick);
     }
 }
 void launch_ns_alias(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
@@ -617,6 +637,7 @@ __global__ void k_ns_alias_sparse(const int64_t* __restrict__ rows, int B, int M
     const int32_t* mi = m_indices + m_indptr[team];
     const int npos = (int)(m_indptr[team + 1] - m_indptr[team]);
     int64_t* o = out + (int64_t)i * ns;
+    RowSet rs; rs.init(mi, npos, o);
     double negw = total_weight;
     for (int p = 0; p < npos; ++p) {
         int lo = 0, hi = nsup;
@@ -637,20 +658,16 @@ __global__ void k_ns_alias_sparse(const int64_t* __restrict__ rows, int B, int M
                     int sl = (int)__umulhi(a, (uint32_t)nsup);
                     if (u01(b) >= prob[sl]) sl = alias[sl];
                     c = cols[sl];
-                    bad = is_member(mi, npos, c) || !(weight[sl] > 0.f);
+                    bad = rs.member(c) || !(weight[sl] > 0.f);
                 }
-                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
+                if (!bad) bad = rs.picked(q, c);
                 if (!bad) pick = c;
             }
         }
         if (pick < 0) {  // fewer than ns admissible experts: take any unused column (multinomial would raise)
-            for (int c = 0; c < M && pick < 0; ++c) {
-                bool bad = false;
-                for (int p = 0; p < q && !bad; ++p) bad = ((int)o[p] == c);
-                if (!bad) pick = c;
-            }
+            for (int c = 0; c < M && pick < 0; ++c) if (!rs.picked(q, c)) pick = c;
         }
-        o[q] = pick;
+        rs.put(q, pick);
     }
 }
 void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, int ns, const int64_t* m_indptr, const int32_t* m_indices,
@@ -692,6 +709,53 @@ void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, i
     const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
     const int blocks = (int)std::min<int64_t>(((aligned ? n / 4 : n) + 255) / 256 + 1, 256 * 8);   // unaligned: never the case for the engine's segments
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr / bc1, b1, b2, eps, bc2_sqrt, aligned ? 1 : 0);
+}
+
+// the same update over up to four [lo, lo + n) ranges of the flat buffers in ONE launch (the rest of the model beside the dW kernel's in-epilogue
+// Adam: hidden layers, biases, rho biases - three short ranges, three dependent launches before)
+struct AdamRanges { int64_t lo[4], n[4]; int blk0[5]; int cnt; };
+__global__ void k_adam_ranges(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M1, float* __restrict__ V2, AdamRanges r,
+                              float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+    int k = 0;
+    while (k + 1 < r.cnt && (int)blockIdx.x >= r.blk0[k + 1]) ++k;
+    const int64_t lo = r.lo[k], n = r.n[k];
+    const int64_t first = (int64_t)((int)blockIdx.x - r.blk0[k]) * blockDim.x + threadIdx.x, stride = (int64_t)(r.blk0[k + 1] - r.blk0[k]) * blockDim.x;
+    float *p = P + lo, *m = M1 + lo, *v = V2 + lo; const float* g = G + lo;
+    const int64_t nq = n >> 2;    // lo is a multiple of 4 floats (checked by the launcher): 16-byte accesses
+    for (int64_t q = first; q < nq; q += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[q], mm = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
+        const float4 gg = reinterpret_cast<const float4*>(g)[q];
+        adam_one(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        adam_one(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        reinterpret_cast<float4*>(p)[q] = pp; reinterpret_cast<float4*>(m)[q] = mm; reinterpret_cast<float4*>(v)[q] = vv;
+    }
+    for (int64_t e = (nq << 2) + first; e < n; e += stride) {
+        float pe = p[e], me = m[e], ve = v[e];
+        adam_one(pe, g[e], me, ve, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        p[e] = pe; m[e] = me; v[e] = ve;
+    }
+}
+// lo_hi: n pairs [lo, hi) of float offsets into the flat buffers (P, G, M1, V2 are the buffers' bases, 16-byte aligned)
+void launch_adam_ranges(hipStream_t st, float* P, const float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,
+                        float eps, float bc1, float bc2_sqrt) {
+    int k = 0;
+    while (k < n) {
+        AdamRanges r; r.cnt = 0; int blocks = 0;
+        for (; k < n && r.cnt < 4; ++k) {
+            const int64_t lo = lo_hi[2 * k], cnt = lo_hi[2 * k + 1] - lo;
+            if (cnt <= 0) continue;
+            if (lo & 3) {   // not 16-byte aligned (never the case for the engine's segments): its own plain launch
+                launch_adam(st, P + lo, G + lo, M1 + lo, V2 + lo, cnt, lr, b1, b2, eps, bc1, bc2_sqrt);
+                continue;
+            }
+            r.lo[r.cnt] = lo; r.n[r.cnt] = cnt; r.blk0[r.cnt] = blocks;
+            blocks += (int)std::min<int64_t>((cnt / 4 + 255) / 256 + 1, 256 * 8);
+            r.cnt += 1;
+        }
+        if (r.cnt == 0) continue;
+        for (int j = r.cnt; j <= 4; ++j) r.blk0[j] = blocks;
+        hipLaunchKernelGGL(k_adam_ranges, dim3(blocks), dim3(256), 0, st, P, G, M1, V2, r, lr / bc1, b1, b2, eps, bc2_sqrt);
+    }
 }
 
 __global__ void k_fill(float* p, int64_t n, float v) {
