@@ -124,6 +124,11 @@ int ntf_skip_step(ntf_engine* e);
  * |h| < 4094.  Operands are range-checked where they are split; a step (or inference call) in which one leaves that window runs on the
  * exact-f32 kernels instead - never on saturated values.  This reports how many steps / calls did so since the engine was created. */
 int ntf_range_fallbacks(ntf_engine* e, int64_t* steps);
+/* A fused train step's dW + Adam kernel holds the output layer's UPDATED mu / rho in its epilogue and writes, from them, the NEXT step's Flipout operands
+ * (eps of step + 1, sigma * eps, the split planes, the layer's KL - bayesian-torch's LinearFlipout.forward / kl_loss, called at src/mdl/fnn.py:126,136) -
+ * that step then starts without the operand producer's own pass over the layer.  Reports how many steps started that way (same results either way:
+ * the arithmetic is the producer's; NTF_PREFETCH=0 in the environment turns it off). */
+int ntf_prefetched_steps(ntf_engine* e, int64_t* steps);
 
 /* ---- the step:  body of the hot loop                              src/mdl/fnn.py:118-151
  * rows = B global team ids (host).  loss_out may be NULL: then nothing is synchronised and the loss is

@@ -91,6 +91,10 @@ struct ntf_engine {
     double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
     int last_global_B = 0; int last_B = 0; float last_dz_packed_scale = 0.f;
     bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
+    // the dW + Adam kernel of a train step also produced the NEXT step's output-layer operands (FusedDw.produce): valid for step pre_step as long as nothing else
+    // touched the output layer's parameters or the operand buffers (Wp, split planes); d_kl[2] / d_range[4] hold that step's KL and range flag until it starts
+    bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
+    int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
     // data-parallel pipelining: the output layer's dW kernel deferred by ntf_step_staged_deferred, launched by ntf_dw_chunk
     bool pend_valid = false; FusedDw pend; NormalSpec pend_eps_b; float pend_klw_b = 0.f; int pend_chunks = 0;
     // unigram_b staging (sparse per-batch alias table)
@@ -192,6 +196,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->seed = cfg->seed;
     if (const char* fk = getenv("NTF_FWD_KERNEL")) e->fwd_kernel = atoi(fk);
     if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
+    if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
@@ -395,6 +400,7 @@ static int param_span(ntf_engine* e, int layer, int kind, int64_t& off, int64_t&
     return NTF_OK;
 }
 extern "C" int ntf_set_param(ntf_engine* e, int layer, int kind, const float* host, int64_t count) {
+    if (e) e->pre_valid = false;   // prefetched operands were made from the old parameters
     if (!e || !host) return NTF_EINVAL;
     int64_t off, n; int r = param_span(e, layer, kind, off, n); if (r) return r;
     if (count != n) FAIL(e, NTF_EINVAL, "param: element count mismatch");
@@ -441,8 +447,9 @@ extern "C" int ntf_reset_optimizer(ntf_engine* e) {
     return NTF_OK;
 }
 extern "C" int ntf_set_lr(ntf_engine* e, float lr) { if (!e) return NTF_EINVAL; e->lr = lr; return NTF_OK; }
-extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; return NTF_OK; }
+extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; e->pre_valid = false; return NTF_OK; }
 extern "C" int ntf_skip_step(ntf_engine* e) { if (!e) return NTF_EINVAL; e->step += 1; return NTF_OK; }
+extern "C" int ntf_prefetched_steps(ntf_engine* e, int64_t* steps) { if (!e || !steps) return NTF_EINVAL; *steps = e->pre_used; return NTF_OK; }
 extern "C" int ntf_range_fallbacks(ntf_engine* e, int64_t* steps) {
     if (!e || !steps) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
@@ -574,6 +581,7 @@ static int forward_layers(ntf_engine* e, const StepCtx& c, bool want_logits, boo
         float* W = e->P + li.off[NTF_P_WEIGHT]; float* b = e->P + li.off[NTF_P_BIAS];
         if (e->cfg.bayesian) {
             Scope t(e, F_FLIPOUT_OPERAND);
+            if (last) e->pre_valid = false;   // overwrites the output layer's Wp
             const bool kl = !want_logits;  // loss steps: this layer's KL rides on the producer's pass over rho (and mu)
             const double share = (e->ep && !last) ? 1.0 / (double)e->ep_world : 1.0;   // expert shards: a replicated layer's KL is counted once over the shards
             launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_WEIGHT], kl ? W : nullptr, li.nw(), normal_spec(e, c, l, T_EPS_W), e->Wp[l],
@@ -700,12 +708,19 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
     int nslots;
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
-    bool prod_side = false, aux = false, swt_aux = false, loss_side = false;
+    bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false;
     // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
     const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
     if (c.part >= 2) goto backward;   // expert-sharded step, later phases
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
-    if (e->cfg.bayesian) HIPCHK(e, hipMemsetAsync(e->d_kl, 0, 12, e->st));
+    {
+        const bool pre_ok = fused && e->cfg.bayesian && e->pre_valid && e->pre_step == c.step && e->pl_wp != nullptr &&
+                            !(c.inj && c.inj->eps_w[e->L - 1]);   // (an injected eps: the operands are made from it in this step)
+        e->pre_valid = false;   // consumed, or stale
+        use_pre = pre_ok;
+        if (use_pre) e->pre_used += 1;
+    }
+    if (e->cfg.bayesian) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0);   // kl = range flag = 0, or the prefetched values; clears the prefetch slots
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
     if (fused && e->side_bwd) {
         // Three streams through the step's head (round 3; profiles/r3_step_timeline.md).  What precedes the forward kernel is a chain of small latency-bound
@@ -716,7 +731,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if ((r = side_stream(e))) return r;
         HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
         StreamRestore guard{e, e->st};
-        if (e->cfg.bayesian) {
+        if (e->cfg.bayesian && !use_pre) {
             HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
             e->st = e->st3;
             { Scope t(e, F_FLIPOUT_OPERAND);
@@ -755,9 +770,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.dh = e->L > 1 ? e->dAct[(e->L - 1) & 1] : nullptr;
         f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
         if (e->cfg.bayesian) {
-            if (!prod_side) { Scope t(e, F_FLIPOUT_OPERAND);
+            if (!prod_side && !use_pre) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                     1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));   // + the split planes of Wp and mu
+                                     1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e)); }   // + the split planes of Wp and mu
+            if (!aux) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                      1.0 / out_nb, e->d_kl); }
             f.planes_ready = e->pl_wp != nullptr;
@@ -889,6 +905,13 @@ backward:
                 f.w_mu = e->P + li.off[NTF_P_WEIGHT]; f.m_mu = e->M1 + li.off[NTF_P_WEIGHT]; f.v_mu = e->V2 + li.off[NTF_P_WEIGHT];
                 if (e->cfg.bayesian) { f.w_rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.m_rho = e->M1 + li.off[NTF_P_RHO_WEIGHT]; f.v_rho = e->V2 + li.off[NTF_P_RHO_WEIGHT]; }
                 e->adam_in_dw = true;
+                if (e->prefetch && e->cfg.bayesian && f.dz_packed && e->pl_wp && e->pl_mu && range_ptr(e)) {
+                    // the Adam epilogue holds the updated mu / rho: it is also the operand producer of step + 1 (FusedDw.produce)
+                    StepCtx nx; nx.step = c.step + 1;
+                    f.produce = 1; f.nx_eps = normal_spec(e, nx, l, T_EPS_W); f.nx_wp = e->Wp[l]; f.nx_pl_wp = e->pl_wp; f.nx_pl_mu = e->pl_mu; f.nx_pscale = kW16Scale;
+                    f.nx_klw = 1.0 / out_nw; f.nx_kl = e->d_kl + 2; f.nx_rflag = e->d_range + 4;
+                    e->pre_valid = true; e->pre_step = c.step + 1;
+                }
             }
             { Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f); }
         dw_done:;
@@ -956,7 +979,7 @@ static int apply_adam(ntf_engine* e) {
     e->adam_t += 1;
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - std::pow(b1, (double)e->adam_t), bc2 = 1.0 - std::pow(b2, (double)e->adam_t);
-    if (!e->adam_in_dw) { launch_adam(e->st, e->P, e->G, e->M1, e->V2, e->n_params, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2)); return NTF_OK; }
+    if (!e->adam_in_dw) { e->pre_valid = false; launch_adam(e->st, e->P, e->G, e->M1, e->V2, e->n_params, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2)); return NTF_OK; }
     // the output layer's weight (and rho_weight) segments were updated inside the dW kernel: one launch over the rest
     e->adam_in_dw = false;
     const LayerInfo& lo = e->layers[e->L - 1];
@@ -975,7 +998,7 @@ static int apply_adam(ntf_engine* e) {
 static int apply_adam_ranges(ntf_engine* e, const int64_t* lo_hi, int n) {
     Scope t(e, F_ADAM);
     e->adam_t += 1;
-    e->adam_in_dw = false;
+    e->adam_in_dw = false; e->pre_valid = false;
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - std::pow(b1, (double)e->adam_t), bc2 = 1.0 - std::pow(b2, (double)e->adam_t);
     for (int k = 0; k < n; ++k) {
@@ -1301,6 +1324,7 @@ static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const
     f.bf16x6 = 1; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
     f.np = mfma_np(e); f.w_scale = kW16Scale; f.h_scale = kH16Scale; f.dz_scale = 1.f;
     if (e->cfg.bayesian) {
+        e->pre_valid = false;   // this pass's operands overwrite any prefetched ones
         { Scope t(e, F_FLIPOUT_OPERAND);
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, e->d_kl,
                                  e->pl_wp, e->pl_mu, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));

@@ -59,6 +59,11 @@ struct FusedDw {
                                                     // of fused_dw_part_floats(M, H, ksplit) floats.  For few expert tiles (a narrow expert shard under a wide minibatch).
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
+    // produce != 0 (adam, bayes, H = 128, fp16x3 planes): the Adam epilogue also writes the NEXT step's operands from the updated parameters - eps' (nx_eps: the
+    // generator of step + 1), Wp' (f32, nx_wp), the split planes of Wp' and mu' (nx_pl_*, scale nx_pscale), KL' * nx_klw added to *nx_kl, *nx_rflag raised when an
+    // operand leaves the fp16 window - what k_flipout_perturb would do in its own pass at the head of that step
+    int produce = 0; NormalSpec nx_eps; float* nx_wp = nullptr; uint16_t *nx_pl_wp = nullptr, *nx_pl_mu = nullptr; float nx_pscale = 1.f; double nx_klw = 0.0;
+    double* nx_kl = nullptr; int* nx_rflag = nullptr;
 };
 
 bool fused_supported(int H);

@@ -566,7 +566,8 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct DwArgs {
     int B, M, Bpad;
-    const float *__restrict__ dzT, *__restrict__ h, *__restrict__ hs, *__restrict__ mu, *__restrict__ rho, *__restrict__ wp;
+    const float *__restrict__ dzT, *__restrict__ h, *__restrict__ hs, *__restrict__ mu, *__restrict__ rho;
+    const float* wp;     // (not restrict: with `produce` the epilogue overwrites the element it has just read with the next step's value)
     const uint32_t* sbits; int nCB; uint32_t so_k0, so_k1; int so_inj;   // s_out signs: packed row image (injected) or hash keys
     float *__restrict__ g_mu, *__restrict__ g_rho, *__restrict__ g_b, *__restrict__ g_bp;
     float klw;
@@ -582,6 +583,11 @@ struct DwArgs {
     // split-K (k_out_dw_p2 only): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
     // contiguous part of the K blocks into part[(split * 2 + matrix) * slab ..] (bias sums behind the slabs); k_out_dw_finish adds the parts and runs the epilogue
     int ksplit; float* part; int64_t slab;
+    // produce != 0 (fused Adam, Flipout, fp16x3 planes): the epilogue holds the UPDATED mu' / rho' of its elements - it also is the next step's operand producer:
+    // eps' (Philox keyed by step + 1), Wp' = softplus(rho') eps' (f32, in place over this step's Wp), the fp16 split planes of Wp' and mu' that the forward kernel
+    // streams, the layer's KL' and fp16 range flag of the next step.  Saves k_flipout_perturb's own pass over the layer (0.72 GB, 0.12 ms at config 2) and takes
+    // it off the path between two steps: what it would read is in registers here.
+    int produce; NormalSpec nx_eps; float* nx_wp; uint16_t *nx_pl_wp, *nx_pl_mu; float nx_pscale; double nx_klw; double* nx_kl; int* nx_rflag;
 };
 
 // N consecutive floats (N = 1, 2, 4) as one access
@@ -617,6 +623,35 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t a, int il) {
         m ^= m << (j >> 1);
     }
     return a;
+}
+
+// DwArgs.produce: the next step's operands of the quad idx0 .. idx0 + 3 (one expert's four consecutive hidden units) from its updated parameters; the arithmetic is
+// k_flipout_perturb's (ntf_kernels.hip), so a step that follows reads bit for bit what the stand-alone producer would have written
+__device__ __forceinline__ void dw_produce_next(const DwArgs& p, int64_t idx0, const float (&mu4)[4], const float (&rho4)[4], float& kl, float& amax) {
+    float z[4], ov[4];
+    normal4(p.nx_eps, idx0 >> 2, idx0, INT64_MAX, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float ls;
+        const float sigma = softplus_rho_fast(rho4[j], ls);
+        ov[j] = sigma * z[j];
+        kl += -ls + 0.5f * (sigma * sigma + mu4[j] * mu4[j]) - 0.5f;
+    }
+    *reinterpret_cast<float4*>(p.nx_wp + idx0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    const int64_t row = idx0 >> 7; const int j = (int)(idx0 & 127);      // H = 128
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(mu4[0]), fabsf(mu4[1])), fmaxf(fabsf(mu4[2]), fabsf(mu4[3]))));
+    planes_store_quad<2>(p.nx_pl_wp, row, j, 128, ov[0], ov[1], ov[2], ov[3], p.nx_pscale);
+    planes_store_quad<2>(p.nx_pl_mu, row, j, 128, mu4[0], mu4[1], mu4[2], mu4[3], p.nx_pscale);
+}
+// ... and once per workgroup: the KL' sum (one double atomic, as the stand-alone producer) and the range flag.  red = 8-byte-aligned LDS scratch of >= nwaves doubles
+__device__ __forceinline__ void dw_produce_finish(const DwArgs& p, float kl, float amax, double* red, int nwaves) {
+    if (!(amax * p.nx_pscale <= 65504.f)) *p.nx_rflag = 1;
+    const double s = wave_reduce_sum_d((double)kl);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < nwaves; ++w) t += red[w]; atomicAdd(p.nx_kl, t * p.nx_klw); }
 }
 
 template <int H, bool BAYES, bool ADAM>
@@ -728,6 +763,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
     sum2 += __shfl_xor(sum2, 32, 64);
     if (half == 0 && c < p.M) { p.g_b[c] = sum1; if (BAYES) p.g_bp[c] = sum2; }
 
+    float nx_kl = 0.f, nx_amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
@@ -751,19 +787,22 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) { p.g_mu[idx0 + jt] = gm[jt]; if (BAYES) p.g_rho[idx0 + jt] = gr[jt]; }
         } else {
+            float nmu[4] = {0.f, 0.f, 0.f, 0.f}, nrho[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
                 float m = p.m_mu[idx0 + jt], v = p.v_mu[idx0 + jt];
-                p.w_mu[idx0 + jt] = adam_update(pm[jt], gm[jt], m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                nmu[jt & 3] = p.w_mu[idx0 + jt] = adam_update(pm[jt], gm[jt], m, v, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
                 p.m_mu[idx0 + jt] = m; p.v_mu[idx0 + jt] = v;
                 if (BAYES) {
                     float m2 = p.m_rho[idx0 + jt], v2 = p.v_rho[idx0 + jt];
-                    p.w_rho[idx0 + jt] = adam_update(pr[jt], gr[jt], m2, v2, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+                    nrho[jt & 3] = p.w_rho[idx0 + jt] = adam_update(pr[jt], gr[jt], m2, v2, p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
                     p.m_rho[idx0 + jt] = m2; p.v_rho[idx0 + jt] = v2;
                 }
             }
+            if constexpr (BAYES && H == 128) { if (p.produce) dw_produce_next(p, idx0, nmu, nrho, nx_kl, nx_amax); }   // (this kernel as the fp16x3 step's range fallback)
         }
     }
+    if constexpr (BAYES && ADAM && H == 128) { if (p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem), DW_WAVES); }
 }
 
 // ================================================================================================
@@ -1030,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_sign_words_T(const uint32_t* __restrict
 // Epilogue of the output layer's dW for N consecutive hidden units of one expert (idx0 = expert * H + first unit), from the finished sums s1 = dz^T h and
 // s2 = (dz s_out)^T (h s_in): Flipout chain rule for rho (eps recovered as Wp / sigma) + the KL terms, then either the gradients or, with ADAM, the update in place.
 template <bool BAYES, bool ADAM, int N>
-__device__ __forceinline__ void dw_finish_vec(const DwArgs& p, int64_t idx0, const float (&s1)[N], const float (&s2)[N]) {
+__device__ __forceinline__ void dw_finish_vec(const DwArgs& p, int64_t idx0, const float (&s1)[N], const float (&s2)[N], float& nx_kl, float& nx_amax) {
     float v_rho[N], v_mu[N], v_wp[N], o_mu[N], o_rho[N];
     if (BAYES) { ld_vec<N>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<N>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<N>(p.wp + idx0, v_wp); }
     else if (ADAM) ld_vec<N>(p.w_mu + idx0, v_mu);
@@ -1059,6 +1098,7 @@ __device__ __forceinline__ void dw_finish_vec(const DwArgs& p, int64_t idx0, con
     else {
         st_vec<N>(p.w_mu + idx0, o_mu); st_vec<N>(p.m_mu + idx0, a_m1); st_vec<N>(p.v_mu + idx0, a_v1);
         if (BAYES) { st_vec<N>(p.w_rho + idx0, o_rho); st_vec<N>(p.m_rho + idx0, a_m2); st_vec<N>(p.v_rho + idx0, a_v2); }
+        if constexpr (BAYES && N == 4) { if (p.produce) dw_produce_next(p, idx0, o_mu, o_rho, nx_kl, nx_amax); }
     }
 }
 
@@ -1074,8 +1114,11 @@ __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
         for (int s = 0; s < p.ksplit; ++s) { b1 += pb[(int64_t)(s * 2) * Mp + q]; if (BAYES) b2 += pb[(int64_t)(s * 2 + 1) * Mp + q]; }
         p.g_b[q] = b1; if (BAYES) p.g_bp[q] = b2;
     }
-    if (idx0 >= (int64_t)p.M * 128) return;
+    float nx_kl = 0.f, nx_amax = 0.f;
+    const bool produce = BAYES && ADAM && p.produce;
+    if (idx0 >= (int64_t)p.M * 128 && !produce) return;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (idx0 < (int64_t)p.M * 128) {
     for (int s = 0; s < p.ksplit; ++s) {
         float t[4];
         ld_vec<4>(p.part + (int64_t)(s * 2) * p.slab + idx0, t);
@@ -1087,7 +1130,9 @@ __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
             for (int k = 0; k < 4; ++k) s2[k] += t[k];
         }
     }
-    dw_finish_vec<BAYES, ADAM, 4>(p, idx0, s1, s2);
+    dw_finish_vec<BAYES, ADAM, 4>(p, idx0, s1, s2, nx_kl, nx_amax);
+    }
+    if (produce) { __shared__ double red[4]; dw_produce_finish(p, nx_kl, nx_amax, red, 4); }
 }
 
 // dW of the fp16x3 training step (H = 128).  Same tiling as k_out_dw_b6 (8 waves x 32 experts, K = batch in 32-row blocks, two LDS stages by LDS-DMA),
@@ -1231,6 +1276,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
         } else { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
     }
 
+    float nx_kl = 0.f, nx_amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
@@ -1242,8 +1288,9 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
         if (split) {   // raw partial sums of this K range; k_out_dw_finish adds the ranges and finalises
             st_vec<NJT>(p.part + (int64_t)(ksi * 2) * p.slab + idx0, s1);
             if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + idx0, s2);
-        } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2);
+        } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
+    if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem), DW_WAVES);   // (the stages are dead: every wave passed the loop's last barrier)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2226,6 +2273,8 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     if (grid <= 0) return;
     a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
     a.rflag = f.rflag; a.rmode = 0;
+    a.produce = (f.produce && f.adam && f.bayes && f.H == 128) ? 1 : 0;
+    a.nx_eps = f.nx_eps; a.nx_wp = f.nx_wp; a.nx_pl_wp = f.nx_pl_wp; a.nx_pl_mu = f.nx_pl_mu; a.nx_pscale = f.nx_pscale; a.nx_klw = f.nx_klw; a.nx_kl = f.nx_kl; a.nx_rflag = f.nx_rflag;
     { static const int abl = getenv("NTF_DW_ABLATE") ? atoi(getenv("NTF_DW_ABLATE")) : 0; a.ablate = abl; }
     const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
     a.sT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);

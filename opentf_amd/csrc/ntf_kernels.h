@@ -97,6 +97,7 @@ void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, i
 
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2_sqrt);
+void launch_step_scalars(hipStream_t st, double* kl, int take_next);
 void launch_adam_ranges(hipStream_t st, float* P, const float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,
                         float eps, float bc1, float bc2_sqrt);   // up to four ranges per launch
 void launch_fill(hipStream_t st, float* p, int64_t n, float v);

@@ -758,6 +758,16 @@ void launch_adam_ranges(hipStream_t st, float* P, const float* G, float* M1, flo
     }
 }
 
+// per-step scalars behind d_kl (ntf_engine.hip): [0] the step's KL sum (double), int32 view [2] its fp16x3 range flag, [3] the fallback counter (kept);
+// [2] (double) and int32 [6]: the same two for the NEXT step, written by the dW + Adam epilogue when it also produced that step's operands (FusedDw.produce)
+__global__ void k_step_scalars(double* kl, int take_next) {
+    int32_t* w = reinterpret_cast<int32_t*>(kl);
+    kl[0] = take_next ? kl[2] : 0.0;
+    w[2] = take_next ? w[6] : 0;
+    kl[2] = 0.0; w[6] = 0;
+}
+void launch_step_scalars(hipStream_t st, double* kl, int take_next) { hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(1), 0, st, kl, take_next); }
+
 __global__ void k_fill(float* p, int64_t n, float v) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
 }

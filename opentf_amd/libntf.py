@@ -58,6 +58,7 @@ SYMBOLS = {
     "ntf_set_seed": (C.c_int, [_P, _U64, _U64]),
     "ntf_skip_step": (C.c_int, [_P]),
     "ntf_range_fallbacks": (C.c_int, [_P, C.POINTER(_I64)]),
+    "ntf_prefetched_steps": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_get_dlogits": (C.c_int, [_P, _P, _I64]),
     "ntf_train_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_eval_step": (C.c_int, [_P, _P, _I32, _P, _P]),
@@ -281,6 +282,12 @@ class Engine:
         """steps / inference calls that ran on the exact-f32 kernels because an operand left the fp16x3 window"""
         n = C.c_int64()
         self._ck(lib().ntf_range_fallbacks(self._h, C.byref(n)))
+        return n.value
+
+    def prefetched_steps(self):
+        """steps that started on output-layer operands written by the previous step's dW + Adam epilogue (no producer pass of their own)"""
+        n = C.c_int64()
+        self._ck(lib().ntf_prefetched_steps(self._h, C.byref(n)))
         return n.value
 
     def dlogits(self, B):

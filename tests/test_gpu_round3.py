@@ -1,0 +1,58 @@
+"""Round 3: the step's head.  The dW + Adam kernel of a fused train step also writes the NEXT step's Flipout operands from the parameters it has just
+updated (FusedDw.produce, include/opentf_amd.h ntf_prefetched_steps); sampler / sign words / loss reduction run on side streams.  Same results as the
+stand-alone producer at the head of every step (bayesian-torch LinearFlipout.forward + kl_loss, called at src/mdl/fnn.py:126,136)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from opentf_amd.synth import make_dataset, init_params       # noqa: E402
+from test_gpu_ep import _mk, _full_epoch, _ep_epoch, _gathered  # noqa: E402
+from opentf_amd.ep import expert_shards                      # noqa: E402
+
+
+def _run(ds, dims, order, B, monkeypatch, prefetch, ep=0):
+    monkeypatch.setenv("NTF_PREFETCH", prefetch)
+    if ep:
+        engines = [_mk(ds, dims, True, B, "uniform", shard=s, world=ep) for s in expert_shards(ds["M"], ep)]
+        l1 = _ep_epoch(engines, order, B)
+        v = _ep_epoch(engines, order[:B], B, train=False)
+        l2 = _ep_epoch(engines, order[::-1].copy(), B)
+        out = (l1, v, l2, _gathered(engines), sum(e.prefetched_steps() for e in engines))
+        for e in engines: e.close()
+        return out
+    e = _mk(ds, dims, True, B, "uniform")
+    l1 = _full_epoch(e, order, B)                           # train steps back to back: every step after the first starts on prefetched operands
+    v = _full_epoch(e, order[:B], B, train=False)           # an eval step right behind a train step consumes them too (same step counter, same parameters)
+    sd = e.state_dict(); e.load_state_dict(sd)              # parameters touched from outside: the prefetched operands are stale and must not be used
+    l2 = _full_epoch(e, order[::-1].copy(), B)
+    p = e.forward(order[:64], nmc=2)                        # inference overwrites the operand buffers ...
+    l3 = _full_epoch(e, order[:B], B)                       # ... so this step makes its own
+    out = (l1, v, l2, l3, p, e.state_dict(), e.prefetched_steps())
+    e.close()
+    return out
+
+
+@pytest.mark.parametrize("M", [70_000, 3000])               # several rounds of the dW kernel / few tiles: its split-K form (the finish kernel produces)
+def test_operands_written_by_the_adam_epilogue_equal_the_producers(M, monkeypatch):
+    ds = make_dataset("dblp", d=128, seed=9, n_rows=3000, n_experts=M)
+    dims = [128, 64, 128, ds["M"]]
+    order = np.random.default_rng(2).permutation(ds["N"])[:2500].astype(np.int64)
+    a = _run(ds, dims, order, 1000, monkeypatch, "0")
+    b = _run(ds, dims, order, 1000, monkeypatch, "1")
+    assert a[-1] == 0 and b[-1] == 2 + 1 + 2, (a[-1], b[-1])   # epoch 1: steps 2, 3; the eval step; epoch 2: steps 2, 3 (its first follows load_state_dict)
+    for x, y in zip(a[:4], b[:4]): assert abs(x - y) <= 1e-9 * abs(x), (x, y)
+    assert np.array_equal(a[4], b[4])
+    for k in a[5]: assert np.array_equal(a[5][k], b[5][k]), k
+
+
+def test_operands_written_by_the_adam_epilogue_on_expert_shards(monkeypatch):
+    """an expert shard's dW + Adam kernel (phase 2 of ntf_step_staged_ep) produces its rows of the next step's operands, eps keyed by GLOBAL element ids"""
+    ds = make_dataset("dblp", d=128, seed=3, n_rows=1500, n_experts=3000)
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(4).permutation(ds["N"])[:600].astype(np.int64)
+    a = _run(ds, dims, order, 200, monkeypatch, "0", ep=3)
+    b = _run(ds, dims, order, 200, monkeypatch, "1", ep=3)
+    assert a[-1] == 0 and b[-1] > 0
+    for x, y in zip(a[:3], b[:3]): assert abs(x - y) <= 1e-9 * abs(x), (x, y)
+    for k in a[3]: assert np.array_equal(a[3][k], b[3][k]), k
