@@ -3,6 +3,7 @@
 #include "../../include/opentf_amd.h"
 #include "ntf_kernels.h"
 #include "ntf_fused.h"
+#include "ntf_head.h"
 
 #include <algorithm>
 #include <cmath>
@@ -93,8 +94,11 @@ struct ntf_engine {
     bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
     // the dW + Adam kernel of a train step also produced the NEXT step's output-layer operands (FusedDw.produce): valid for step pre_step as long as nothing else
     // touched the output layer's parameters or the operand buffers (Wp, split planes); d_kl[2] / d_range[4] hold that step's KL and range flag until it starts
+    int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
+    bool pre_rotated = false;         // ... and whose KL / range-flag scalars the previous step's last kernel already moved into place
+    bool fin_pend = false; NormalSpec fin_eps; float fin_klw = 0.f;   // the output layer's bias-gradient finalisation rides in the Adam launch that follows (fused-Adam steps)
     // data-parallel pipelining: the output layer's dW kernel deferred by ntf_step_staged_deferred, launched by ntf_dw_chunk
     bool pend_valid = false; FusedDw pend; NormalSpec pend_eps_b; float pend_klw_b = 0.f; int pend_chunks = 0;
     // unigram_b staging (sparse per-batch alias table)
@@ -197,6 +201,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* fk = getenv("NTF_FWD_KERNEL")) e->fwd_kernel = atoi(fk);
     if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
     if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
+    if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
@@ -709,6 +714,9 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     int nslots;
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
     bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false;
+    // one kernel for gather -> hidden layer -> operand images (ntf_head.hip): one hidden layer of 128 units over a dense / mean-pooled input, native generators, fp16x3 planes
+    const bool use_head = fused && e->head && e->L == 2 && c.part <= 1 && !c.inj && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
+                          (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
     // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
     const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
     if (c.part >= 2) goto backward;   // expert-sharded step, later phases
@@ -720,8 +728,11 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         use_pre = pre_ok;
         if (use_pre) e->pre_used += 1;
     }
-    if (e->cfg.bayesian) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0);   // kl = range flag = 0, or the prefetched values; clears the prefetch slots
+    // the step's KL sum and fp16x3 range flag: zero, or the values the previous step's dW epilogue produced for this one (moved into place by that step's Adam launch
+    // if pre_rotated, else here)
+    if (e->cfg.bayesian) { if (!(use_pre && e->pre_rotated)) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0); }
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
+    e->pre_rotated = false;
     if (fused && e->side_bwd) {
         // Three streams through the step's head (round 3; profiles/r3_step_timeline.md).  What precedes the forward kernel is a chain of small latency-bound
         // launches and one HBM-bound pass, and most links of it do not depend on each other:
@@ -742,7 +753,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         HIPCHK(e, hipStreamWaitEvent(e->st4, e->ev_fork, 0));
         e->st = e->st4;
-        if (e->cfg.bayesian) { Scope t(e, F_FLIPOUT_OPERAND);
+        if (e->cfg.bayesian && !use_head) { Scope t(e, F_FLIPOUT_OPERAND);
             launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], e->P + lo.off[NTF_P_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                    1.0 / out_nb, e->d_kl); }
         if ((r = sample_negatives(e, c))) return r;
@@ -757,10 +768,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
         aux = true;
     }
-    if ((r = make_input(e, c))) return r;
+    if (!use_head && (r = make_input(e, c))) return r;
     if (!aux && (r = sample_negatives(e, c))) return r;
     if (fused) {
-        if ((r = forward_layers(e, c, false, true))) return r;
+        if (!use_head && (r = forward_layers(e, c, false, true))) return r;
         FusedOut f;
         f.B = B; f.H = lo.in; f.M = M; f.bayes = e->cfg.bayesian; f.train = c.train;
         f.h = e->act[e->L - 1];
@@ -773,7 +784,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             if (!prod_side && !use_pre) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
                                      1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e)); }   // + the split planes of Wp and mu
-            if (!aux) { Scope t(e, F_FLIPOUT_OPERAND);
+            if (!aux && !use_head) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                      1.0 / out_nb, e->d_kl); }
             f.planes_ready = e->pl_wp != nullptr;
@@ -786,14 +797,45 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if (e->fwd_kernel >= 0) f.wide = e->fwd_kernel;   // A/B runs: NTF_FWD_KERNEL = 0, 1, 2 (ntf_fused.h), read when the engine is created
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
         f.c_lo = e->ep_lo;
+        if (use_head) {
+            Scope t(e, F_GEMM_HIDDEN);
+            const LayerInfo& l0 = e->layers[0];
+            const FusedWsPtrs wp = fused_ws_ptrs(e->fws, B, lo.in, M);
+            HeadArgs a;
+            a.B = B; a.Bpad = wp.Bpad; a.D = l0.in; a.mode = e->cfg.input_mode == NTF_INPUT_DENSE ? 0 : 1; a.bayes = e->cfg.bayesian;
+            a.rows = c.rows_dev; a.s_indptr = e->s_indptr; a.s_indices = e->s_indices; a.table = e->table; a.Xall = e->Xall;
+            a.mu0 = e->P + l0.off[NTF_P_WEIGHT]; a.b0 = e->P + l0.off[NTF_P_BIAS];
+            a.X = e->act[0]; a.act1 = e->act[1]; a.hz = wp.hz; a.hs = wp.hs; a.sinbits = wp.sinbits;
+            a.hb = (c.train && e->cfg.mfma != NTF_MFMA_F32) ? wp.hb : nullptr;
+            a.h_scale = f.h_scale;
+            const bool guard = f.np == 2 && f.rflag != nullptr;
+            a.h_limit = guard ? 65504.f / f.h_scale : 0.f; a.rflag = guard ? f.rflag : nullptr;
+            if (e->cfg.bayesian) {
+                const double share = e->ep ? 1.0 / (double)e->ep_world : 1.0;   // expert shards: a replicated layer's KL is counted once over the shards
+                a.rho0 = e->P + l0.off[NTF_P_RHO_WEIGHT]; a.rhob0 = e->P + l0.off[NTF_P_RHO_BIAS];
+                a.eps_w0 = normal_spec(e, c, 0, T_EPS_W); a.eps_b0 = normal_spec(e, c, 0, T_EPS_B);
+                a.si0 = sign_spec(e, c, 0, T_S_IN, l0.in); a.so0 = sign_spec(e, c, 0, T_S_OUT, l0.out); a.si1 = f.s_in;
+                a.klw_w0 = share / (double)l0.nw(); a.klw_b0 = share / (double)l0.out; a.kl = e->d_kl;
+                a.M = lo.out; a.rho_b1 = e->P + lo.off[NTF_P_RHO_BIAS]; a.mu_b1 = f.mu_b; a.eps_b1 = normal_spec(e, c, e->L - 1, T_EPS_B); a.bp1 = e->bp[e->L - 1];
+                a.klw_b1 = 1.0 / out_nb;
+            }
+            launch_head(e->st, a);
+            f.h_ready = 1;
+            if (!f.planes_ready) launch_fused_out_fwd(e->st, f, 1);   // (Fnn: the split planes of mu are made per step)
+            if (c.train && e->cfg.mfma != NTF_MFMA_F32 && !swt_aux) {   // (one stream: the s_out words were not made beside the head)
+                const bool dz_packed = f.np == 2 && lo.in == 128 && e->pl_mu != nullptr;
+                launch_fused_prep_planes(e->st, B, lo.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale, dz_packed ? &f.s_out : nullptr, 0, 1);
+            }
+        } else {
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 1); }
-        if (c.train && e->cfg.mfma != NTF_MFMA_F32) {
-            // operands of the dW kernel that depend on h and on the sign keys only (split planes of h / h*s_in, transposed s_out words): prepared here, in the
-            // step's head (beside the side-stream producer), not between the forward and the dW kernel
-            Scope t(e, F_OUT_FUSED_AUX);
-            const bool dz_packed = f.np == 2 && lo.in == 128 && e->pl_mu != nullptr;
-            const bool so_inj = e->cfg.bayesian && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
-            launch_fused_prep_planes(e->st, B, lo.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale, dz_packed ? &f.s_out : nullptr, so_inj, swt_aux ? 2 : 3);
+            if (c.train && e->cfg.mfma != NTF_MFMA_F32) {
+                // operands of the dW kernel that depend on h and on the sign keys only (split planes of h / h*s_in, transposed s_out words): prepared here, in the
+                // step's head (beside the side-stream producer), not between the forward and the dW kernel
+                Scope t(e, F_OUT_FUSED_AUX);
+                const bool dz_packed = f.np == 2 && lo.in == 128 && e->pl_mu != nullptr;
+                const bool so_inj = e->cfg.bayesian && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
+                launch_fused_prep_planes(e->st, B, lo.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale, dz_packed ? &f.s_out : nullptr, so_inj, swt_aux ? 2 : 3);
+            }
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
@@ -912,6 +954,7 @@ backward:
                     f.nx_klw = 1.0 / out_nw; f.nx_kl = e->d_kl + 2; f.nx_rflag = e->d_range + 4;
                     e->pre_valid = true; e->pre_step = c.step + 1;
                 }
+                if (e->cfg.bayesian) { e->fin_pend = true; e->fin_eps = normal_spec(e, c, l, T_EPS_B); e->fin_klw = kl_share / ((float)out_nb * (float)c.global_B); }
             }
             { Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f); }
         dw_done:;
@@ -962,6 +1005,7 @@ backward:
             if (!(last && fused))  // the fused dW kernel finalises the output layer's weights in its epilogue
                 launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], gW, gRW, li.nw(),
                                              normal_spec(e, c, l, T_EPS_W), kl_share / ((float)li.nw() * (float)c.global_B));
+            if (!(last && e->fin_pend))   // (fused-Adam step: the output layer's biases are finalised inside the Adam launch, apply_adam)
             launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_BIAS], e->P + li.off[NTF_P_RHO_BIAS], gb, gRb, li.out,
                                          normal_spec(e, c, l, T_EPS_B), kl_share / ((last ? (float)out_nb : (float)li.out) * (float)c.global_B));
         }
@@ -984,11 +1028,15 @@ static int apply_adam(ntf_engine* e) {
     e->adam_in_dw = false;
     const LayerInfo& lo = e->layers[e->L - 1];
     const int64_t w0 = lo.off[NTF_P_WEIGHT], w1 = lo.off[NTF_P_BIAS];  // segments are laid out weight, bias, rho_weight, rho_bias
-    int64_t rg[6]; int n = 0;
+    int64_t rg[6]; int fin[3] = {0, 0, 0}; int n = 0;
     rg[2 * n] = 0; rg[2 * n + 1] = w0; ++n;
-    if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS]; rg[2 * n] = w1; rg[2 * n + 1] = r0; ++n; rg[2 * n] = r1; rg[2 * n + 1] = e->n_params; ++n; }
+    if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS];
+        rg[2 * n] = w1; rg[2 * n + 1] = r0; fin[n] = e->fin_pend ? 1 : 0; ++n; rg[2 * n] = r1; rg[2 * n + 1] = e->n_params; fin[n] = e->fin_pend ? 2 : 0; ++n; }
     else { rg[2 * n] = w1; rg[2 * n + 1] = e->n_params; ++n; }
-    launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2));
+    const bool rotate = e->cfg.bayesian && e->pre_valid && e->pre_step == e->step;   // this step's dW epilogue left the next step's KL / range flag behind the current ones
+    launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2), fin, &e->fin_eps, e->fin_klw,
+                       rotate ? e->d_kl : nullptr);
+    e->pre_rotated = rotate; e->fin_pend = false;
     return NTF_OK;
 }
 

@@ -29,6 +29,7 @@ struct FusedOut {
     int wide = 1;                                   // np = 2 training step: 1 the 64-expert-tile kernel (one wave per SIMD), 0 the 32-expert-tile kernel,
                                                     // 2 (Flipout only) the role-split kernel: mu-wave / Wp-wave pairs, two waves per SIMD
     int planes_ready = 0;
+    int h_ready = 0;                                // the zero-padded h, h * s_in and the s_in words are in the workspace already (ntf_head.hip): phase 1 skips k_prep_h
     // inference (train = 0, probs = 1): dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale instead of the loss; the row entropy partials go to the workspace
     int probs = 0, pacc = 0; float pscale = 1.f;
     int plogit = 0;                                 // probs pass that stores leaky_relu(z) instead of its sigmoid (ntf_logits)
@@ -70,6 +71,9 @@ bool fused_supported(int H);
 int fused_loss_slots(int M);
 int64_t fused_dh_slab_floats(int B, int H, int M);
 size_t fused_workspace_bytes(int B, int H, int M);
+// where phase 1 of launch_fused_out_fwd and launch_fused_prep_planes leave their images in the workspace (the one-kernel head, ntf_head.hip, writes the same ones)
+struct FusedWsPtrs { float *hz, *hs; uint32_t* sinbits; uint16_t* hb; int Bpad; };
+FusedWsPtrs fused_ws_ptrs(void* ws, int B, int H, int M);
 int fused_ldb(int B);
 int64_t fused_planes_elems(int M, int H);   // uint16 elements of one matrix's split planes
 int64_t fused_dw_part_floats(int M, int H, int ksplit);

@@ -69,6 +69,12 @@ static WsLayout ws_layout(int Bmax, int H, int M) {
     return w;
 }
 size_t fused_workspace_bytes(int B, int H, int M) { return ws_layout(B, H, M).total; }
+FusedWsPtrs fused_ws_ptrs(void* ws_, int B, int H, int M) {
+    const WsLayout w = ws_layout(B, H, M); char* ws = static_cast<char*>(ws_);
+    FusedWsPtrs r; r.hz = reinterpret_cast<float*>(ws + w.hz); r.hs = reinterpret_cast<float*>(ws + w.hs); r.sinbits = reinterpret_cast<uint32_t*>(ws + w.sinbits);
+    r.hb = reinterpret_cast<uint16_t*>(ws + w.hb); r.Bpad = rup(B, BM);
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // sign bit images: sbits[i][cb] (bit c&31 of word cb = c>>5), its 32x32-block transpose sbitsT[c][i>>5],
@@ -123,6 +129,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p; }
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);   // wave-uniform by construction; hipcc cannot always prove it (a loop-carried stage index)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
@@ -583,6 +590,7 @@ struct DwArgs {
     // split-K (k_out_dw_p2 only): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
     // contiguous part of the K blocks into part[(split * 2 + matrix) * slab ..] (bias sums behind the slabs); k_out_dw_finish adds the parts and runs the epilogue
     int ksplit; float* part; int64_t slab;
+    int ntile, stagger;   // k_out_dw_p2, unsplit: expert tiles of this launch (walked by persistent workgroups), start delay of every second workgroup (100 MHz ticks)
     // produce != 0 (fused Adam, Flipout, fp16x3 planes): the epilogue holds the UPDATED mu' / rho' of its elements - it also is the next step's operand producer:
     // eps' (Philox keyed by step + 1), Wp' = softplus(rho') eps' (f32, in place over this step's Wp), the fp16 split planes of Wp' and mu' that the forward kernel
     // streams, the layer's KL' and fp16 range flag of the next step.  Saves k_flipout_perturb's own pass over the layer (0.72 GB, 0.12 ms at config 2) and takes
@@ -1154,27 +1162,29 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
     if (range_guard_skip(p.rflag, p.rmode, false)) return;
     const bool split = p.ksplit > 1;
-    const int ntile = split ? (int)gridDim.x / p.ksplit : (int)gridDim.x;
+    // Unsplit: workgroups walk the launch's expert tiles with stride gridDim.x (default grid = the tile count: one tile each).  A tile is a main loop followed by
+    // an HBM-bound epilogue (Adam in place + the next step's operands: 64 B per mu / rho pair), and with every workgroup in the same phase at the same time
+    // neither hides the other.  Round 3 tried the obvious cure - persistent workgroups (NTF_DW_PGRID=256), every second one of an XCD starting p.stagger ticks
+    // late (NTF_DW_STAGGER, 10 ns ticks per K block), the next tile's first K block issued before the epilogue - and measured NO gain (persistent: same time;
+    // staggered: +2 % per 75 ticks): a workgroup's epilogue keeps 8 waves x 7 KB of loads in flight = 22 GB/s per CU at ~2.5 us latency, which is 5.6 TB/s with
+    // all 256 CUs in it and still 22 GB/s per CU with half of them.  Kept as an option; the default is one tile per workgroup.
+    const int ntile = split ? (int)gridDim.x / p.ksplit : p.ntile;
     const int ksi = split ? (int)blockIdx.x / ntile : 0;                  // which K range (the splits of one tile sit ntile workgroups apart)
-    const int c0 = (p.wg_begin + (split ? (int)blockIdx.x % ntile : (int)blockIdx.x)) * DW_TC;
+    const int tile0 = split ? (int)blockIdx.x % ntile : (int)blockIdx.x, tstride = split ? ntile : (int)gridDim.x;
     const int crow = wave * 32 + il;
-    const int c = c0 + crow;
     const int nib = p.Bpad / 32;
     const int ib0 = split ? (int)((int64_t)ksi * nib / p.ksplit) : 0, ib1 = split ? (int)((int64_t)(ksi + 1) * nib / p.ksplit) : nib;
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char* hb = reinterpret_cast<const char*>(p.hb);
+    if (!split && p.stagger > 0 && (((int)blockIdx.x >> 3) & 1)) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)p.stagger) __builtin_amdgcn_s_sleep(32);
+    }
 
-    f32x16 acc1[NJT], acc2[NJT];
-#pragma unroll
-    for (int j = 0; j < NJT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
-    float sum1 = 0.f, sum2 = 0.f;
     const h2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
-
     constexpr int NA = TA / 1024 / DW_WAVES, NB = (TB / 1024 + DW_WAVES - 1) / DW_WAVES;   // DMA pieces per wave: 4 of the dz tile, 2 or 4 of the planes
-    auto stage_piece = [&](int ib, int buf, int n) {      // piece n of this wave's NA + NB (+ the sign words with the last piece)
+    auto stage_piece = [&](int c0, int ib, int buf, int n) {      // piece n of this wave's NA + NB (+ the sign words with the last piece)
         const uint32_t sb = smem_base + buf * STAGE;
         if (n < NA) {
             const float* src_a = p.dzT + ((int64_t)(c0 >> 8) * nib + ib) * 8192;   // contiguous 32 KiB
@@ -1193,11 +1203,21 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             if (BAYES && n == NA + NB - 1 && wave_u == DW_WAVES - 1) glds16(p.sT + ((int64_t)(c0 >> 8) * nib + ib) * 256 + lane * 4, sb + TA + TB);
         }
     };
-    auto stage = [&](int ib, int buf) {
+    auto stage = [&](int c0, int ib, int buf) {
 #pragma unroll
-        for (int n = 0; n < NA + NB; ++n) stage_piece(ib, buf, n);
+        for (int n = 0; n < NA + NB; ++n) stage_piece(c0, ib, buf, n);
     };
-    stage(ib0, 0);
+    float nx_kl = 0.f, nx_amax = 0.f;
+    if (tile0 < ntile) stage((p.wg_begin + tile0) * DW_TC, ib0, 0);
+    for (int tile = tile0; tile < ntile; tile += tstride) {
+    const int c0 = (p.wg_begin + tile) * DW_TC;
+    const int c = c0 + crow;
+    f32x16 acc1[NJT], acc2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
+    float sum1 = 0.f, sum2 = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int ib = ib0; ib < ib1; ++ib) {
@@ -1254,16 +1274,17 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);
             // the next K block's DMA, one piece per half-group: a burst of 8-9 LDS-DMA issues in one gap stalls the wave's own MFMA stream
-            if (hg < NA + NB && ib + 1 < ib1 && !(p.ablate & 4)) { if (p.ablate & 16) { if (hg == 0) stage(ib + 1, buf ^ 1); } else stage_piece(ib + 1, buf ^ 1, hg); }
+            if (hg < NA + NB && ib + 1 < ib1 && !(p.ablate & 4)) { if (p.ablate & 16) { if (hg == 0) stage(c0, ib + 1, buf ^ 1); } else stage_piece(c0, ib + 1, buf ^ 1, hg); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (tile + tstride < ntile) stage((p.wg_begin + tile + tstride) * DW_TC, ib0, 0);   // both stages are dead: the next tile's first K block lands under the epilogue
     if (p.ablate & 1) {
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) { asm volatile("" :: "v"(acc1[jt][0]), "v"(acc1[jt][15])); asm volatile("" :: "v"(acc2[jt][0]), "v"(acc2[jt][15])); }
         if (sum1 == 123.456f) p.g_b[0] = sum2;
-        return;
+        continue;
     }
 
     sum1 += __shfl_xor(sum1, 32, 64);
@@ -1276,7 +1297,6 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
         } else { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
     }
 
-    float nx_kl = 0.f, nx_amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int cr = c0 + wave * 32 + rowmap(r, half);
@@ -1290,7 +1310,8 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + idx0, s2);
         } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
-    if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem), DW_WAVES);   // (the stages are dead: every wave passed the loop's last barrier)
+    }
+    if (BAYES && ADAM && !split && p.produce && !(p.ablate & 1)) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2150,7 +2171,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     const bool inj = f.bayes && (f.s_out.inj != nullptr || f.s_in.inj != nullptr);
     const bool guard = f.np == 2 && f.rflag != nullptr;   // fp16x3 arithmetic somewhere in this step (forward and / or dW): range-checked operands
     if (inj && (phases & 1)) hipLaunchKernelGGL(k_sign_bits, dim3((g.nCB + 63) / 64, g.Bpad), dim3(64), 0, st, f.s_out, f.B, f.M, g.nCB, sbits);
-    if (phases & 1) {
+    if ((phases & 1) && !f.h_ready) {
         const int n = g.Bpad * (f.H / 32);
         hipLaunchKernelGGL(k_prep_h, dim3((n + 63) / 64), dim3(64), 0, st, f.s_in, f.bayes, f.h, f.B, f.H, g.Bpad, sinbits, hs, hz,
                            guard ? 65504.f / f.h_scale : 0.f, guard ? f.rflag : nullptr);
@@ -2276,6 +2297,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.produce = (f.produce && f.adam && f.bayes && f.H == 128) ? 1 : 0;
     a.nx_eps = f.nx_eps; a.nx_wp = f.nx_wp; a.nx_pl_wp = f.nx_pl_wp; a.nx_pl_mu = f.nx_pl_mu; a.nx_pscale = f.nx_pscale; a.nx_klw = f.nx_klw; a.nx_kl = f.nx_kl; a.nx_rflag = f.nx_rflag;
     { static const int abl = getenv("NTF_DW_ABLATE") ? atoi(getenv("NTF_DW_ABLATE")) : 0; a.ablate = abl; }
+    a.ntile = 0; a.stagger = 0;
     const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
     a.sT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
     a.ksplit = 1; a.part = nullptr; a.slab = 0;
@@ -2296,10 +2318,16 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
             a.rmode = 2; a.ksplit = 1;
             goto exact_f32;
         }
-        const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0));
+        const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0)) + 64;
+        // persistent workgroups, one per CU; with several tiles per workgroup and an epilogue that updates in place, every second one starts late (see the kernel)
+        static const int stagger_env = getenv("NTF_DW_STAGGER") ? atoi(getenv("NTF_DW_STAGGER")) : -1;   // ticks (10 ns) per K block; default below
+        static const int pgrid_env = getenv("NTF_DW_PGRID") ? atoi(getenv("NTF_DW_PGRID")) : (1 << 30);   // default: one tile per workgroup (measured: persistent = the same time)
+        const int pgrid = std::min(grid, std::max(1, pgrid_env));
+        a.ntile = grid;
+        a.stagger = (f.adam && grid >= 2 * pgrid) ? (stagger_env >= 0 ? stagger_env : 0) * (g.Bpad / 32) : 0;
 #define NTF_DWP(BY, AD) do { auto kf = k_out_dw_p2<BY, AD>;                                                                    \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
+        hipLaunchKernelGGL(kf, dim3(pgrid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
         if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
 #undef NTF_DWP
         if (!guard) return;

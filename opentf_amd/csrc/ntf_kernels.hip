@@ -711,53 +711,6 @@ void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, i
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr / bc1, b1, b2, eps, bc2_sqrt, aligned ? 1 : 0);
 }
 
-// the same update over up to four [lo, lo + n) ranges of the flat buffers in ONE launch (the rest of the model beside the dW kernel's in-epilogue
-// Adam: hidden layers, biases, rho biases - three short ranges, three dependent launches before)
-struct AdamRanges { int64_t lo[4], n[4]; int blk0[5]; int cnt; };
-__global__ void k_adam_ranges(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M1, float* __restrict__ V2, AdamRanges r,
-                              float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
-    int k = 0;
-    while (k + 1 < r.cnt && (int)blockIdx.x >= r.blk0[k + 1]) ++k;
-    const int64_t lo = r.lo[k], n = r.n[k];
-    const int64_t first = (int64_t)((int)blockIdx.x - r.blk0[k]) * blockDim.x + threadIdx.x, stride = (int64_t)(r.blk0[k + 1] - r.blk0[k]) * blockDim.x;
-    float *p = P + lo, *m = M1 + lo, *v = V2 + lo; const float* g = G + lo;
-    const int64_t nq = n >> 2;    // lo is a multiple of 4 floats (checked by the launcher): 16-byte accesses
-    for (int64_t q = first; q < nq; q += stride) {
-        float4 pp = reinterpret_cast<float4*>(p)[q], mm = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
-        const float4 gg = reinterpret_cast<const float4*>(g)[q];
-        adam_one(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, b1, b2, eps, bc2_sqrt);
-        adam_one(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, b1, b2, eps, bc2_sqrt);
-        reinterpret_cast<float4*>(p)[q] = pp; reinterpret_cast<float4*>(m)[q] = mm; reinterpret_cast<float4*>(v)[q] = vv;
-    }
-    for (int64_t e = (nq << 2) + first; e < n; e += stride) {
-        float pe = p[e], me = m[e], ve = v[e];
-        adam_one(pe, g[e], me, ve, lr_over_bc1, b1, b2, eps, bc2_sqrt);
-        p[e] = pe; m[e] = me; v[e] = ve;
-    }
-}
-// lo_hi: n pairs [lo, hi) of float offsets into the flat buffers (P, G, M1, V2 are the buffers' bases, 16-byte aligned)
-void launch_adam_ranges(hipStream_t st, float* P, const float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,
-                        float eps, float bc1, float bc2_sqrt) {
-    int k = 0;
-    while (k < n) {
-        AdamRanges r; r.cnt = 0; int blocks = 0;
-        for (; k < n && r.cnt < 4; ++k) {
-            const int64_t lo = lo_hi[2 * k], cnt = lo_hi[2 * k + 1] - lo;
-            if (cnt <= 0) continue;
-            if (lo & 3) {   // not 16-byte aligned (never the case for the engine's segments): its own plain launch
-                launch_adam(st, P + lo, G + lo, M1 + lo, V2 + lo, cnt, lr, b1, b2, eps, bc1, bc2_sqrt);
-                continue;
-            }
-            r.lo[r.cnt] = lo; r.n[r.cnt] = cnt; r.blk0[r.cnt] = blocks;
-            blocks += (int)std::min<int64_t>((cnt / 4 + 255) / 256 + 1, 256 * 8);
-            r.cnt += 1;
-        }
-        if (r.cnt == 0) continue;
-        for (int j = r.cnt; j <= 4; ++j) r.blk0[j] = blocks;
-        hipLaunchKernelGGL(k_adam_ranges, dim3(blocks), dim3(256), 0, st, P, G, M1, V2, r, lr / bc1, b1, b2, eps, bc2_sqrt);
-    }
-}
-
 // per-step scalars behind d_kl (ntf_engine.hip): [0] the step's KL sum (double), int32 view [2] its fp16x3 range flag, [3] the fallback counter (kept);
 // [2] (double) and int32 [6]: the same two for the NEXT step, written by the dW + Adam epilogue when it also produced that step's operands (FusedDw.produce)
 __global__ void k_step_scalars(double* kl, int take_next) {
@@ -767,6 +720,86 @@ __global__ void k_step_scalars(double* kl, int take_next) {
     kl[2] = 0.0; w[6] = 0;
 }
 void launch_step_scalars(hipStream_t st, double* kl, int take_next) { hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(1), 0, st, kl, take_next); }
+
+// the same update over up to four [lo, lo + n) ranges of the flat buffers in ONE launch (the rest of the model beside the dW kernel's in-epilogue
+// Adam: hidden layers, biases, rho biases - three short ranges, three dependent launches before).  Two more small launches ride here:
+//   fin[k] = 1 / 2: the range is the output layer's bias / rho_bias, whose raw gradients (sums of dz, of dz * s_out: the dW kernel's by-product) still need the
+//                   Flipout chain rule and the KL terms - k_flipout_grad_finalize's arithmetic, applied (and written back to G) before the update;
+//   rotate != null: thread 0 moves the NEXT step's KL sum and range flag, written by this step's dW epilogue (FusedDw.produce), to the current slots.
+struct AdamRanges { int64_t lo[4], n[4]; int blk0[5]; int cnt; int fin[4]; NormalSpec eps; float klw; double* rotate; };
+__device__ __forceinline__ void fin_mu(float& g, float p, float klw) { g += klw * p; }
+__device__ __forceinline__ void fin_rho(float& g, float r, float z, float klw) {
+    const float sg = 1.f / (1.f + expf(-r));  // d softplus / d rho
+    const float sigma = softplus_rho(r);
+    g = g * z * sg + klw * (sigma - 1.f / sigma) * sg;
+}
+__global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, float* __restrict__ M1, float* __restrict__ V2, AdamRanges r,
+                              float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+    if (r.rotate && blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t* w = reinterpret_cast<int32_t*>(r.rotate);
+        r.rotate[0] = r.rotate[2]; w[2] = w[6]; r.rotate[2] = 0.0; w[6] = 0;
+    }
+    int k = 0;
+    while (k + 1 < r.cnt && (int)blockIdx.x >= r.blk0[k + 1]) ++k;
+    const int64_t lo = r.lo[k], n = r.n[k];
+    const int fin = r.fin[k];
+    const int64_t first = (int64_t)((int)blockIdx.x - r.blk0[k]) * blockDim.x + threadIdx.x, stride = (int64_t)(r.blk0[k + 1] - r.blk0[k]) * blockDim.x;
+    float *p = P + lo, *m = M1 + lo, *v = V2 + lo, *g = G + lo;
+    const int64_t nq = n >> 2;    // lo is a multiple of 4 floats (checked by the launcher): 16-byte accesses
+    for (int64_t q = first; q < nq; q += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[q], mm = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
+        float4 gg = reinterpret_cast<const float4*>(g)[q];
+        if (fin == 1) { fin_mu(gg.x, pp.x, r.klw); fin_mu(gg.y, pp.y, r.klw); fin_mu(gg.z, pp.z, r.klw); fin_mu(gg.w, pp.w, r.klw); reinterpret_cast<float4*>(g)[q] = gg; }
+        else if (fin == 2) {
+            float z[4];
+            normal4(r.eps, q, q * 4, n, z);
+            fin_rho(gg.x, pp.x, z[0], r.klw); fin_rho(gg.y, pp.y, z[1], r.klw); fin_rho(gg.z, pp.z, z[2], r.klw); fin_rho(gg.w, pp.w, z[3], r.klw);
+            reinterpret_cast<float4*>(g)[q] = gg;
+        }
+        adam_one(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        adam_one(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        reinterpret_cast<float4*>(p)[q] = pp; reinterpret_cast<float4*>(m)[q] = mm; reinterpret_cast<float4*>(v)[q] = vv;
+    }
+    for (int64_t e = (nq << 2) + first; e < n; e += stride) {
+        float pe = p[e], me = m[e], ve = v[e], ge = g[e];
+        if (fin == 1) { fin_mu(ge, pe, r.klw); g[e] = ge; }
+        else if (fin == 2) {
+            float z[4];
+            normal4(r.eps, e >> 2, e & ~(int64_t)3, n, z);
+            const int j = (int)(e & 3);
+            fin_rho(ge, pe, j == 0 ? z[0] : j == 1 ? z[1] : j == 2 ? z[2] : z[3], r.klw); g[e] = ge;
+        }
+        adam_one(pe, ge, me, ve, lr_over_bc1, b1, b2, eps, bc2_sqrt);
+        p[e] = pe; m[e] = me; v[e] = ve;
+    }
+}
+// lo_hi: n pairs [lo, hi) of float offsets into the flat buffers (P, G, M1, V2 are the buffers' bases, 16-byte aligned); fin (nullable): per range 0 / 1 / 2, see above
+void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,
+                        float eps, float bc1, float bc2_sqrt, const int* fin, const NormalSpec* fin_eps, float fin_klw, double* rotate) {
+    int k = 0;
+    bool launched = false;
+    while (k < n) {
+        AdamRanges r; r.cnt = 0; int blocks = 0;
+        r.klw = fin_klw; if (fin_eps) r.eps = *fin_eps; r.rotate = launched ? nullptr : rotate;
+        for (; k < n && r.cnt < 4; ++k) {
+            const int64_t lo = lo_hi[2 * k], cnt = lo_hi[2 * k + 1] - lo;
+            if (cnt <= 0) continue;
+            if ((lo & 3) && !(fin && fin[k])) {   // not 16-byte aligned (never the case for the engine's segments): its own plain launch
+                launch_adam(st, P + lo, G + lo, M1 + lo, V2 + lo, cnt, lr, b1, b2, eps, bc1, bc2_sqrt);
+                continue;
+            }
+            r.lo[r.cnt] = lo; r.n[r.cnt] = cnt; r.blk0[r.cnt] = blocks; r.fin[r.cnt] = fin ? fin[k] : 0;
+            blocks += (int)std::min<int64_t>((cnt / 4 + 255) / 256 + 1, 256 * 8);
+            r.cnt += 1;
+        }
+        if (r.cnt == 0) continue;
+        for (int j = r.cnt; j <= 4; ++j) r.blk0[j] = blocks;
+        for (int j = r.cnt; j < 4; ++j) { r.lo[j] = 0; r.n[j] = 0; r.fin[j] = 0; }
+        hipLaunchKernelGGL(k_adam_ranges, dim3(blocks), dim3(256), 0, st, P, G, M1, V2, r, lr / bc1, b1, b2, eps, bc2_sqrt);
+        launched = true;
+    }
+    if (!launched && rotate) launch_step_scalars(st, rotate, 1);
+}
 
 __global__ void k_fill(float* p, int64_t n, float v) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;

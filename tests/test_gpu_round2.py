@@ -257,7 +257,8 @@ def _fused_vs_generic(dims, mode, data, B, nsd, seed, unigram=None, n_rows=50_00
     for k in g_g:
         scale = np.abs(g_g[k]).max()
         d = np.abs(g_f[k] - g_g[k])
-        assert (d > 2e-5 * scale).sum() <= 64 * dims[-2], k      # a handful of leaky_relu' kink flips move one expert's row each
+        assert (d > 2e-5 * scale).sum() <= 160 * dims[-2], k     # leaky_relu' kink flips (|z| within rounding of 0: ~1e-7 of up to 1.4e9 logits) move one expert's row each;
+                                                                 # since round 3 the two paths also differ in the summation order of the hidden layer (ntf_head.hip)
         assert d.max() <= 2e-2 * scale, (k, float(d.max()), float(scale))
     return l_f
 

@@ -56,3 +56,38 @@ def test_operands_written_by_the_adam_epilogue_on_expert_shards(monkeypatch):
     assert a[-1] == 0 and b[-1] > 0
     for x, y in zip(a[:3], b[:3]): assert abs(x - y) <= 1e-9 * abs(x), (x, y)
     for k in a[3]: assert np.array_equal(a[3][k], b[3][k]), k
+
+
+# ------------------------------------------------------------------------------------------ the one-kernel head (ntf_head.hip)
+@pytest.mark.parametrize("bayesian", [True, False])
+@pytest.mark.parametrize("d,dense,B", [(128, False, 1000), (64, False, 333), (256, False, 77), (128, True, 500)])
+def test_one_kernel_head_equals_the_kernel_chain(bayesian, d, dense, B, monkeypatch):
+    """gather -> hidden Flipout layer -> h images in ONE kernel (NTF_HEAD, default on) against the chain of kernels it replaces (k_gather_pool, k_flipout_perturb x 2,
+    k_gemm x 2, k_prep_h, k_prep_planes_T): the same generators and arithmetic, another summation order in the 128 x d products - loss, every gradient and the
+    mean-pooled input agree to rounding; ragged last row blocks, d = 64 / 128 / 256, dense input rows"""
+    from opentf_amd import libntf
+    ds = make_dataset("dblp", d=d, seed=21, n_rows=1200, n_experts=3000)
+    dims = [d, 128, ds["M"]]
+    rows = np.random.default_rng(1).permutation(ds["N"])[:B].astype(np.int64)
+    X = None
+    if dense:
+        from oracle import ntf_oracle as O
+        X = O.gather_meanpool_fast(ds["skill"][0], ds["skill"][1], ds["table"])
+    out = []
+    for head in ("0", "1"):
+        monkeypatch.setenv("NTF_HEAD", head)
+        e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_DENSE if dense else libntf.INPUT_MEANPOOL, max_batch=1000, ns=5, nsd="uniform",
+                          tpw=10.0, tnw=1.0, lr=1e-3, seed=5, fuse_adam=0)
+        if dense: e.set_dense_input(X)
+        else: e.set_skill_table(ds["table"]); e.set_skill_csr(ds["skill"])
+        e.set_member(ds["member"]); e.load_state_dict(init_params(dims, bayesian, 0))
+        ev = e.eval_step(rows)
+        loss = e.backward(rows)
+        g = e.grads()
+        l2 = e.train_step(rows)          # and one more through the fused-Adam-free apply
+        out.append((ev, loss, l2, g, e.state_dict())); e.close()
+    a, b = out
+    for x, y in zip(a[:3], b[:3]): assert abs(x - y) <= 2e-6 * abs(x), (x, y)
+    for k in a[3]:
+        tol = 2e-5 * float(np.abs(a[3][k]).max()) + 1e-12
+        assert float(np.abs(a[3][k] - b[3][k]).max()) <= tol, (k, float(np.abs(a[3][k] - b[3][k]).max()), tol)
