@@ -16,6 +16,9 @@
 #include "ntf_fused.h"
 #include "ntf_device.h"
 #include <algorithm>
+#include <vector>
+#include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 namespace ntf {
@@ -1345,6 +1348,7 @@ struct OutFwd6Args {
     const uint16_t *mu_pl, *wp_pl;   // k_split_planes images of mu and Wp
     float pscale; int pacc;          // PROBS: dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale; pacc: accumulate onto the previous MC passes
     int plogit;                      // PROBS: store the logit leaky_relu(z) itself instead (ntf_logits: the quantity the 1e-4 parity bar is stated on)
+    unsigned long long* stamps;           // diagnostics (k_out_fwd_h3x<.., ABL = 9>): per wave 8 cycle sums, see NTF_FWD_STAMP
     float h_scale, dz_scale, u_z, u_dh;   // fp16x3 (NP = 2): scales applied to h / dz before their split, and 1/(w scale * h scale), 1/(dz scale * w scale); 1 for bf16x6
 };
 // fp16x3 training step: dzT holds, per element, the two fp16 planes of dz * dz_scale packed in one dword (hi | lo << 16) - the split the forward
@@ -1893,6 +1897,387 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Round 3: the same kernel with its four 48-MFMA phases ROTATED ACROSS TILES.  In k_out_fwd_h3w the vector work of a tile (the epilogue of its two
+// sub-tiles: bias, sign, leaky_relu, BCE, dz, its fp16 split and stores - ~1.1 k instructions) rides on the two MIDDLE phases only, ~11 vector instructions
+// per MFMA there (a wave alone on its SIMD issues one per ~4.3 cycles: those phases are vector-bound at ~2x their MFMA time) while zT(u=0) and dh(u=1)
+// run bare (ISA of the tile loop + PMC: profiles/r3_fwd_isa.md).  Every phase can carry half an epilogue when the order of the matrix work is
+//   zT(0,t) | dh(1,t-1) | zT(1,t) | dh(0,t)        with the epilogue of sub-tile (1,t-1) over [dh(0,t-1), zT(0,t)] and of (0,t) over [dh(1,t-1), zT(1,t)]:
+// an epilogue needs its zT finished and must finish before its dh starts, which leaves it exactly those two phases.  Stage t-1 stays alive until dh(1,t-1)
+// is through (a barrier), then takes the DMA of tile t+1, issued one piece per MFMA group of zT(1,t) instead of a burst of 18 at the top of the tile.
+// Same sums in the same order as k_out_fwd_h3w (dh accumulates sub-tiles in the order (0,t-1), (1,t-1), (0,t), ...); the first tile's "previous" sub-tile is a
+// zero one (its dz planes are zero, its stores go to an empty buffer resource, its loss terms are masked).  Also trimmed here: the dz split needs no range
+// clamp (|dz| <= max weight / B is scaled below 2^14 by construction) and takes its scale from the row constant; accumulators start from the MFMA's zero
+// operand instead of 64 register clears per tile.
+// ------------------------------------------------------------------------------------------------
+// ABL (diagnostics, NTF_FWD_ABL; results are wrong for ABL != 0): 1 = no epilogue arithmetic, 2 = no epilogue at all (no splits, no dz stores), 3 = no MFMAs
+template <bool BAYES, bool INJ, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OutFwdArgs& p = pp.a;
+    constexpr int H = 128, NJT = 4, NKS = H / 16, NP = 2, BNT = 64;
+    constexpr int PLANE = BNT * H * 2;          // 16 KiB
+    constexpr int TM = NP * PLANE;              // one matrix of a tile
+    constexpr int NMAT = BAYES ? 2 : 1;
+    constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (range_guard_skip(p.rflag, p.rmode, false)) return;
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int cg = bid / p.NRB, rb = bid % p.NRB;
+    const int t_beg = (int)((int64_t)cg * p.T / p.NCG), t_end = (int)((int64_t)(cg + 1) * p.T / p.NCG);   // p.T = 64-expert tiles
+    const int i0 = rb * BM + wave * 32;
+    const int i = i0 + il;
+    const bool row_ok = i < p.B;
+
+    u32x4 hp[NKS][3];
+    uint32_t sinw[NJT];
+#pragma unroll
+    for (int w = 0; w < NJT; ++w)
+        sinw[w] = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) : 0u;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
+        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t pq[3];
+            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
+            hp[s][0][q] = pq[0]; hp[s][1][q] = pq[1]; hp[s][2][q] = 0u;
+        }
+    }
+    const float rmask = row_ok ? 1.f : 0.f;
+    const float rscale_pos = row_ok ? p.tnw * p.inv_B * pp.dz_scale : 0.f;    // dz * dz_scale = this * sigmoid(l)   (z > 0), ...
+    const float rscale_neg = rscale_pos * kLeakySlope;                         // ... * leaky slope                       (z <= 0)
+
+    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
+    int troff[2][NJT];                              // transposed read (rr, jt): rows 8*rr + 4*half + q (+ 16 per k-step, 32 per sub-tile as immediates)
+    {
+        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int row = 8 * rr + 4 * half + q;
+                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
+            }
+    }
+
+    f32x16 Y1[NJT], Y2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
+    LossAcc lacc;
+
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
+    constexpr int NPIECE = NMAT * PER_WAVE + 1; // DMA pieces per wave and tile (+ the bias piece)
+    auto stage_piece = [&](int t, int buf, int n) {
+        const uint32_t sb = smem_base + buf * STAGE;
+        if (n < NMAT * PER_WAVE) {
+            const int mat = n / PER_WAVE;
+            const int inst = wave_u * PER_WAVE + n % PER_WAVE;
+            const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row (0..63), physical chunk
+            const int plane = pos / PLANE, row = (pos >> 8) & 63, chp = (pos >> 4) & 15;
+            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
+            const size_t src = ((size_t)(2 * t + (row >> 5)) * (32 * NP) + plane * 32 + (row & 31)) * 256 + 16 * ch;
+            glds16(reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + src, sb + mat * TM + inst * 1024);
+        } else {   // the two bias tiles, branch-free: even waves fetch mu_b's, odd waves bp's (twice each: the same bytes to the same place)
+            const int c0 = t * BNT;
+            const int which = BAYES ? (wave_u & 1) : 0;
+            glds4((which ? p.bp : p.mu_b) + min(c0 + lane, p.M - 1), sb + NMAT * TM + which * 256);
+        }
+    };
+    auto sign_words = [&](int t) -> uint2 {         // s_out signs of (row i, experts 64t .. 64t+63)
+        if (!BAYES || !row_ok) return make_uint2(0u, 0u);
+        if (INJ) return *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);
+        return make_uint2(sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t)), sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t + 1)));
+    };
+    if (t_beg < t_end) {
+        // the first tile into BOTH stages: the zero "previous" sub-tile multiplies whatever stage 1 holds - it must be finite
+#pragma unroll
+        for (int n = 0; n < NPIECE; ++n) { stage_piece(t_beg, 0, n); stage_piece(t_beg, 1, n); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per-sub-tile state; index 1 is carried across iterations (sub-tile (1, t-1) is finished in iteration t)
+    f32x16 X1[2], X2[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { X1[1][r] = 0.f; X2[1][r] = 0.f; X1[0][r] = 0.f; X2[0][r] = 0.f; }
+    u32x4 ad[2][2][3];      // [u][k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ad[u][k][q] = u32x4{0u, 0u, 0u, 0u};
+    uint32_t swp = 0u;                  // s_out word of sub-tile (1, t-1), shifted by 4 * half
+    float rm_prev = 0.f, rsp_prev = 0.f, rsn_prev = 0.f;    // row constants of sub-tile (1, t-1): zero for the virtual one before the first tile
+    constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
+    const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
+    __amdgpu_buffer_rsrc_t rsrc_prev = __builtin_amdgcn_make_buffer_rsrc(p.dzT, 0, 0, 0x00020000);   // zero records: the virtual sub-tile's stores are dropped
+
+    constexpr int NHG = NKS * NMAT;     // half-groups (k-step, matrix) of one sub-tile's zT: 2 fragment reads + 3 MFMAs each
+    constexpr int NGD = 2 * NJT * NMAT; // groups (k-step of 16 experts, jt, matrix) of one sub-tile's dh: 4 transposed reads + 3 MFMAs each
+    static_assert(NHG == NGD, "the four phases have the same number of MFMA groups");
+    constexpr int NG = NHG, BG = 2;
+
+    // ---- pieces (all take the stage base of the tile they work on)
+    // LDS addresses: a per-lane base register (set once per tile) + a compile-time offset in the instruction (hipcc otherwise spends one vector add per read:
+    // 232 of the tile's ~930 vector instructions)
+    typedef const __attribute__((address_space(3))) char* ldsp_t;
+    int zrow[NKS];                                   // row read of k-step s: 256 * il + 16 * ((2 s + half) ^ fil)
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) zrow[s] = 256 * il + 16 * ((2 * s + half) ^ fil);
+    auto z_load = [&](const ldsp_t (&zb)[NKS], int u, int hg, u32x4 (&fr)[3]) {
+        const int s = hg / NMAT, mat = hg % NMAT;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(zb[s] + (8192 * u + mat * TM + q * PLANE));
+    };
+    auto z_mma = [&](int u, int hg, const u32x4 (&fr)[3]) {
+        const int s = hg / NMAT, mat = hg % NMAT;
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        if (ABL == 3) { asm volatile("" :: "v"(fr[0][0]), "v"(fr[1][3])); if (mat == 0) { if (s == 0) X1[u] = zero; asm volatile("" :: "v"(hp[s][0][0]), "v"(hp[s][1][3])); } else if (s == 0) X2[u] = zero; return; }
+        if (mat == 0) X1[u] = mfma_np<NP>(fr, hp[s], s == 0 ? zero : X1[u]);
+        else {
+            u32x4 hs[3];
+            const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
+            u32x4 hm;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hm[q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) hs[q] = hp[s][q] ^ hm;
+            hs[2] = hm;
+            X2[u] = mfma_np<NP>(fr, hs, s == 0 ? zero : X2[u]);
+        }
+    };
+    // epilogue of register r of sub-tile u: lane = batch row i, register r <-> expert c0 + 32u + rowmap(r, half); leaves dz * dz_scale in X1[u][r]
+    // the biases of half an epilogue (8 registers = two runs of four experts, per matrix) are fetched at the START of the phase that carries it: a bias read inside
+    // the riders makes hipcc drain the whole LDS queue (lgkmcnt(0)) - the prefetched MFMA fragments included - once per register
+    auto load_bias = [&](const char* sb, int u, int hf, float (&bm)[8], float (&bq)[8]) {
+        const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half + 32 * u + 16 * hf;
+        const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half + 32 * u + 16 * hf;
+        const float4 m0 = *reinterpret_cast<const float4*>(bias_mu), m1 = *reinterpret_cast<const float4*>(bias_mu + 8);
+        bm[0] = m0.x; bm[1] = m0.y; bm[2] = m0.z; bm[3] = m0.w; bm[4] = m1.x; bm[5] = m1.y; bm[6] = m1.z; bm[7] = m1.w;
+        if (BAYES) {
+            const float4 q0 = *reinterpret_cast<const float4*>(bias_p), q1 = *reinterpret_cast<const float4*>(bias_p + 8);
+            bq[0] = q0.x; bq[1] = q0.y; bq[2] = q0.z; bq[3] = q0.w; bq[4] = q1.x; bq[5] = q1.y; bq[6] = q1.z; bq[7] = q1.w;
+        }
+    };
+    auto epilogue = [&](const float (&bm)[8], const float (&bq)[8], int u, int r, uint32_t swu, float rm, float rsp, float rsn, float& ltile) {
+        const int cr = 32 * u + (r & 3) + 8 * (r >> 2);
+        if (ABL == 1) { X1[u][r] = fmaf(X1[u][r], rsp, X2[u][r]); return; }
+        float z = fmaf(X1[u][r], pp.u_z, bm[r & 7]);
+        if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[u][r], pp.u_z, bq[r & 7])) ^ ((swu << (31 - (cr & 31))) & 0x80000000u));
+        const bool pos = z > 0.f;
+        const float l = pos ? z : z * kLeakySlope;
+        const float lc = fmaxf(l, -80.f);
+        const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
+        ltile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rm, ltile);
+        X1[u][r] = __builtin_amdgcn_rcpf(tt) * (pos ? rsp : rsn);
+    };
+    // registers r0, r0 + 1 (r0 even) of sub-tile u -> fp16 planes (A operand of dh) + the packed store
+    auto split_pair_a = [&](int u, int r0, __amdgpu_buffer_rsrc_t rsrc) {
+        uint32_t p0, p1;
+        split_pair_h(X1[u][r0], X1[u][r0 + 1], p0, p1);    // (no clamp: |dz| * dz_scale < 2^14)
+        ad[u][r0 >> 3][0][(r0 & 7) >> 1] = p0; ad[u][r0 >> 3][1][(r0 & 7) >> 1] = p1;
+        uint32_t d0, d1;
+        pack_planes(p0, p1, d0, d1);
+        __builtin_amdgcn_raw_buffer_store_b32(d0, rsrc, dz_voff, (32 * u + (r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(d1, rsrc, dz_voff, (32 * u + ((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
+    };
+    auto signed_a = [&](int u, int s2, uint32_t swu, u32x4 (&o)[3]) {   // planes of dz * s_out
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r0 = 8 * s2 + 2 * q, c0r = (r0 & 3) + 8 * (r0 >> 2);
+            const uint32_t m = (((swu << (31 - c0r)) & 0x80000000u) >> 16) | ((swu << (30 - c0r)) & 0x80000000u);
+            o[0][q] = ad[u][s2][0][q] ^ m; o[1][q] = ad[u][s2][1][q] ^ m;
+        }
+        o[2] = o[0];
+    };
+    auto tr_load = [&](const ldsp_t (&tb)[2][NJT], int u, int g, u32x4 (&bf)[3]) {   // g = (s2, jt, mat)
+        const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            constexpr int dummy = 0; (void)dummy;
+            const int o = 8192 * u + 4096 * s2 + q * PLANE + mat * TM;
+            const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[0][jt] + o)));
+            const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[1][jt] + o)));
+            bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
+        }
+    };
+    auto d_mma = [&](int u, int g, uint32_t swu, const u32x4 (&bf)[3]) {
+        const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
+        if (ABL == 3) { asm volatile("" :: "v"(bf[0][0]), "v"(bf[1][3]), "v"(ad[u][s2][0][0]), "v"(ad[u][s2][1][3])); if (mat) { u32x4 asg[3]; signed_a(u, s2, swu, asg); asm volatile("" :: "v"(asg[0][0]), "v"(asg[1][3])); } return; }
+        if (mat == 0) Y1[jt] = mfma_np<NP>(ad[u][s2], bf, Y1[jt]);
+        else { u32x4 asg[3]; signed_a(u, s2, swu, asg); Y2[jt] = mfma_np<NP>(asg, bf, Y2[jt]); }
+    };
+    // half an epilogue (registers 8 hf .. 8 hf + 7 of sub-tile u) spread over the NG groups of a phase
+    constexpr int GPR = NG / 8;         // groups per register (2 with Flipout, 1 without)
+    auto ride = [&](const float (&bm)[8], const float (&bq)[8], int u, int hf, int g, uint32_t swu, float rm, float rsp, float rsn, __amdgpu_buffer_rsrc_t rsrc, float& ltile) {
+        if (ABL == 2) return;
+        if (g % GPR == 0) {
+            const int r = 8 * hf + g / GPR;
+            epilogue(bm, bq, u, r, swu, rm, rsp, rsn, ltile);
+            if (r & 1) split_pair_a(u, r - 1, rsrc);
+        }
+    };
+
+    // One phase = NG groups of 3 MFMAs in BUNDLES of BG: the fragments of a whole bundle (BG x 8 registers) are fetched while the previous bundle's 3 BG MFMAs run.
+    // kind 0: zT of sub-tile (u, this tile) from stage sb; kind 1: dh of sub-tile u from stage sb.  `extra(g)` = the vector work riding on group g.
+    u32x4 fb[2][BG][3];
+
+
+    // ABL == 9: cycle stamps (s_memtime) around the phases, summed per wave and written to pp.stamps (never part of a result)
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int slot) {
+        if (ABL != 9) return;
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long tnow;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot >= 0) st_sum[slot] += tnow - st_prev;
+        st_prev = tnow;
+    };
+    stamp(-1);
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        const uint2 w2 = sign_words(t);
+        char* sb = smem + buf * STAGE;
+        char* sbp = smem + (buf ^ 1) * STAGE;                 // stage of tile t - 1 (tile t_beg again in the first iteration)
+        const uint32_t sbase = lds_addr(sb), sbasep = lds_addr(sbp);
+        const int c0 = t * BNT;
+        const int tn = min(t + 1, t_end - 1);
+        if (c0 + BNT > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
+            if (tid < BNT && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -1e30f;
+            __syncthreads();
+        }
+        const uint32_t sw[2] = {w2.x >> (4 * half), w2.y >> (4 * half)};
+        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
+        float lt = 0.f;
+
+        // the four phases; each is its own fully unrolled loop over its NG / BG bundles (one loop over all 16 bundles exceeds the unroller's budget and
+        // leaves the fragment buffers in scratch).  The last bundle of a phase fetches the first bundle of the next one.
+        ldsp_t zb[NKS], tb[2][NJT], tbp[2][NJT];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) zb[s] = (ldsp_t)(size_t)(sbase + zrow[s]);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) { tb[rr][jt] = (ldsp_t)(size_t)(sbase + troff[rr][jt]); tbp[rr][jt] = (ldsp_t)(size_t)(sbasep + troff[rr][jt]); }
+        auto load_for = [&](int ph, int g, u32x4 (&dst)[3]) {
+            if (ph == 0) z_load(zb, 0, g, dst);             // zT(0, t)
+            else if (ph == 1) tr_load(tbp, 1, g, dst);      // dh(1, t-1) from the previous tile's stage
+            else if (ph == 2) z_load(zb, 1, g, dst);        // zT(1, t)
+            else tr_load(tb, 0, g, dst);                    // dh(0, t)
+        };
+        auto run_phase = [&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            constexpr int NBP = NG / BG;
+            static_assert(NBP % 2 == 0, "the fragment double buffer keeps its parity across phases");
+            float bm[8], bq[8];
+            if (ph == 0) load_bias(sbp, 1, 1, bm, bq); else if (ph == 1) load_bias(sb, 0, 0, bm, bq); else if (ph == 2) load_bias(sb, 0, 1, bm, bq); else load_bias(sb, 1, 0, bm, bq);
+#pragma unroll
+            for (int lb = 0; lb < NBP; ++lb) {
+                if (lb + 1 < NBP) {
+#pragma unroll
+                    for (int k = 0; k < BG; ++k) load_for(ph, (lb + 1) * BG + k, fb[(lb + 1) & 1][k]);
+                } else if (ph < 3) {
+#pragma unroll
+                    for (int k = 0; k < BG; ++k) load_for(ph + 1, k, fb[0][k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // the next bundle's fragment reads stay ABOVE this bundle's MFMAs (hipcc otherwise sinks them next to their uses)
+#pragma unroll
+                for (int k = 0; k < BG; ++k) {
+                    const int g = lb * BG + k;
+                    if (ph == 0) { z_mma(0, g, fb[lb & 1][k]); ride(bm, bq, 1, 1, g, swp, rm_prev, rsp_prev, rsn_prev, rsrc_prev, lt); }   // second half of the epilogue of (1, t-1)
+                    else if (ph == 1) { d_mma(1, g, swp, fb[lb & 1][k]); ride(bm, bq, 0, 0, g, sw[0], rmask, rscale_pos, rscale_neg, dz_rsrc, lt); }
+                    else if (ph == 2) {
+                        z_mma(1, g, fb[lb & 1][k]); ride(bm, bq, 0, 1, g, sw[0], rmask, rscale_pos, rscale_neg, dz_rsrc, lt);
+                        // stage t-1 is free since the barrier that closed phase 1.  Unconditional (a branch per piece would cut the phase into 16 basic blocks):
+                        // behind the last tile the free stage takes that tile once more
+                        if (g < NPIECE - 1) stage_piece(tn, buf ^ 1, g);
+                        if (g == 0) stage_piece(tn, buf ^ 1, NPIECE - 1);
+                    }
+                    else { d_mma(0, g, sw[0], fb[lb & 1][k]); ride(bm, bq, 1, 0, g, sw[1], rmask, rscale_pos, rscale_neg, dz_rsrc, lt); }
+                }
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < BG; ++k) load_for(0, k, fb[0][k]);
+        stamp(0);
+        run_phase(std::integral_constant<int, 0>{});
+        stamp(1);
+        run_phase(std::integral_constant<int, 1>{});
+        stamp(2);
+        // dh(1, t-1) is through: every wave's reads of stage t-1 have returned (its MFMAs consumed them) - the stage may take tile t+1
+        __builtin_amdgcn_s_barrier();
+        stamp(3);
+        run_phase(std::integral_constant<int, 2>{});
+        stamp(4);
+        run_phase(std::integral_constant<int, 3>{});
+        stamp(5);
+        lacc.tile = lt; lacc.end_tile();
+        swp = sw[1]; rm_prev = rmask; rsp_prev = rscale_pos; rsn_prev = rscale_neg; rsrc_prev = dz_rsrc;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the DMA of tile t+1 is older than all but (at most) the 8 dzT stores of the last phase
+        __builtin_amdgcn_s_barrier();
+        stamp(6);
+    }
+    if (ABL == 9 && pp.stamps && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pp.stamps[((int64_t)blockIdx.x * 4 + wave) * 8 + q] = q == 7 ? (unsigned long long)(t_end - t_beg) : st_sum[q];
+    }
+
+    if (t_beg < t_end) {
+        // ---- drain: second half of the epilogue of (1, last), then dh(1, last)
+        const int t = t_end - 1, buf = (t - t_beg) & 1;
+        const char* sb = smem + buf * STAGE;
+        const uint32_t sbase = lds_addr(sb);
+        float lt = 0.f;
+        float bm[8], bq[8];
+        load_bias(sb, 1, 1, bm, bq);
+#pragma unroll
+        for (int r = 8; r < 16; ++r) { epilogue(bm, bq, 1, r, swp, rm_prev, rsp_prev, rsn_prev, lt); if (r & 1) split_pair_a(1, r - 1, rsrc_prev); }
+        ldsp_t tbd[2][NJT];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) tbd[rr][jt] = (ldsp_t)(size_t)(sbase + troff[rr][jt]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { u32x4 bf[3]; tr_load(tbd, 1, g, bf); d_mma(1, g, swp, bf); }
+        lacc.tile = lt; lacc.end_tile();
+    }
+
+    float lsum = lacc.sum;
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int irow = i0 + rowmap(r, half);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            float v = Y1[jt][r] * pp.u_dh;
+            if (BAYES) {
+                const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
+                const float y2 = Y2[jt][r] * pp.u_dh;
+                v += ((w >> il) & 1u) ? -y2 : y2;
+            }
+            p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Training forward (loss + dz + dh) of the Flipout output layer in fp16x3 with TWO WAVES PER SIMD (round 2).
 // k_out_fwd_h3w keeps one wave per SIMD at 512 registers: per 64-expert tile its 192 MFMAs (6.1 k cycles) sit beside ~1.1 k vector instructions and
 // 44 waits and the tile takes 14.9 k cycles - exposed LDS latency with nobody to cover it.  Here the two matrices are split over a wave PAIR that
@@ -2200,7 +2585,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
             if (f.bayes) hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.wp, f.M, f.H, np, f.w_scale, f.wp_pl, guard ? f.rflag : nullptr);
         }
         if (phases & 2) {
-            OutFwd6Args a6; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc; a6.plogit = f.plogit;
+            OutFwd6Args a6; a6.stamps = nullptr; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc; a6.plogit = f.plogit;
             a6.a.rmode = (guard && np == 2) ? 1 : 0;
             a6.h_scale = np == 2 ? f.h_scale : 1.f; a6.dz_scale = np == 2 ? f.dz_scale : 1.f;
             a6.u_z = np == 2 ? 1.f / (f.w_scale * f.h_scale) : 1.f; a6.u_dh = np == 2 ? 1.f / (f.dz_scale * f.w_scale) : 1.f;
@@ -2224,7 +2609,29 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_LW(BY, IJ) do { auto kf = k_out_fwd_h3w<BY, IJ>;                                                                    \
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
                 hipLaunchKernelGGL(kf, dim3(grid), dim3(256), ldsw, st, a6); } while (0)
-                if (f.bayes) { if (inj) NTF_LW(true, true); else NTF_LW(true, false); } else NTF_LW(false, false);
+#define NTF_LXA(BY, IJ, AB) do { auto kf = k_out_fwd_h3x<BY, IJ, AB>;                                                                    \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
+                hipLaunchKernelGGL(kf, dim3(grid), dim3(256), ldsw, st, a6); } while (0)
+#define NTF_LX(BY, IJ) NTF_LXA(BY, IJ, 0)
+                static const int fwd_abl = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
+                if (f.wide == 3 && fwd_abl == 9 && f.bayes && !inj) {
+                    static unsigned long long* d_st = nullptr; static int n_launch = 0;
+                    if (!d_st) hipMalloc(&d_st, (size_t)grid * 4 * 8 * 8);
+                    a6.stamps = d_st;
+                    NTF_LXA(true, false, 9);
+                    if (++n_launch == 30) {
+                        std::vector<unsigned long long> hst((size_t)grid * 32);
+                        hipStreamSynchronize(st); hipMemcpy(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost);
+                        double sum[8] = {0}; for (size_t w = 0; w < (size_t)grid * 4; ++w) for (int q = 0; q < 8; ++q) sum[q] += (double)hst[w * 8 + q];
+                        fprintf(stderr, "[fwd stamps] cycles per tile and wave: load0 %.0f | ph0 %.0f | ph1 %.0f | barrier %.0f | ph2 %.0f | ph3 %.0f | wait+barrier %.0f  (tiles/wave %.1f)\n",
+                                sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7], sum[7] / (grid * 4.0));
+                    }
+                }
+                else if (f.wide == 3 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
+                else if (f.wide == 3) { if (f.bayes) { if (inj) NTF_LX(true, true); else NTF_LX(true, false); } else NTF_LX(false, false); }
+                else if (f.bayes) { if (inj) NTF_LW(true, true); else NTF_LW(true, false); } else NTF_LW(false, false);
+#undef NTF_LX
+#undef NTF_LXA
 #undef NTF_LW
             } else if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
 #undef NTF_L6B
