@@ -1197,13 +1197,13 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             glds16(src_a + row * 32 + 4 * q, sb + inst * 1024);
         } else {
             const char* src = hb + (size_t)ib * TB;
+            static_assert((TB / 1024) % DW_WAVES == 0, "every wave moves the same number of plane pieces");
             const int inst = wave_u * NB + (n - NA);
-            if (inst < TB / 1024) {
-                const int pos = inst * 1024 + lane * 16;
-                const int j = (pos % PLANE) >> 6, cd = (pos >> 4) & 3;
-                glds16(src + (pos & ~63) + 16 * (cd ^ ((j >> 2) & 3)), sb + TA + inst * 1024);
-            }
-            if (BAYES && n == NA + NB - 1 && wave_u == DW_WAVES - 1) glds16(p.sT + ((int64_t)(c0 >> 8) * nib + ib) * 256 + lane * 4, sb + TA + TB);
+            const int pos = inst * 1024 + lane * 16;
+            const int j = (pos % PLANE) >> 6, cd = (pos >> 4) & 3;
+            glds16(src + (pos & ~63) + 16 * (cd ^ ((j >> 2) & 3)), sb + TA + inst * 1024);
+            // the tile's 1 KiB of s_out words: fetched by EVERY wave (the same bytes to the same place) - a wave-uniform branch here splits the K block's body
+            if (BAYES && n == NA + NB - 1) glds16(p.sT + ((int64_t)(c0 >> 8) * nib + ib) * 256 + lane * 4, sb + TA + TB);
         }
     };
     auto stage = [&](int c0, int ib, int buf) {
@@ -1223,7 +1223,10 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     float sum1 = 0.f, sum2 = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int ib = ib0; ib < ib1; ++ib) {
+    // one K block; MORE: the next K block's DMA rides on the first MFMA groups.  (Round 3: a compile-time flag and two call sites instead of a run-time test per DMA
+    // piece, and no run-time ablation switches: they cut the unrolled body into ~40 basic blocks that hipcc could not schedule across)
+    auto k_block = [&](int ib, auto more_c) {
+        constexpr bool MORE = decltype(more_c)::value;
         const int buf = (ib - ib0) & 1;
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + TA;
@@ -1269,27 +1272,18 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             asm volatile("" ::: "memory");
             const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT;
             const int jt = g % NJT;
-            if (p.ablate & 2) {
-                asm volatile("" :: "v"(bq[hg & 1][0][0]), "v"(bq[hg & 1][1][3]), "v"(a[ks][0][0]), "v"(a[ks][1][3]));
-                if (BAYES) asm volatile("" :: "v"(as[ks][0][0]), "v"(as[ks][1][3]));
-            }
-            else if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
+            if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
             else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);
             // the next K block's DMA, one piece per half-group: a burst of 8-9 LDS-DMA issues in one gap stalls the wave's own MFMA stream
-            if (hg < NA + NB && ib + 1 < ib1 && !(p.ablate & 4)) { if (p.ablate & 16) { if (hg == 0) stage(c0, ib + 1, buf ^ 1); } else stage_piece(c0, ib + 1, buf ^ 1, hg); }
+            if (MORE && hg < NA + NB) stage_piece(c0, ib + 1, buf ^ 1, hg);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
+    };
+    for (int ib = ib0; ib < ib1 - 1; ++ib) k_block(ib, std::true_type{});
+    k_block(ib1 - 1, std::false_type{});
     if (tile + tstride < ntile) stage((p.wg_begin + tile + tstride) * DW_TC, ib0, 0);   // both stages are dead: the next tile's first K block lands under the epilogue
-    if (p.ablate & 1) {
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) { asm volatile("" :: "v"(acc1[jt][0]), "v"(acc1[jt][15])); asm volatile("" :: "v"(acc2[jt][0]), "v"(acc2[jt][15])); }
-        if (sum1 == 123.456f) p.g_b[0] = sum2;
-        continue;
-    }
-
     sum1 += __shfl_xor(sum1, 32, 64);
     sum2 += __shfl_xor(sum2, 32, 64);
     const float inv_a = 1.f / p.a_scale;
@@ -1314,7 +1308,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
         } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
     }
-    if (BAYES && ADAM && !split && p.produce && !(p.ablate & 1)) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
+    if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1977,17 +1971,24 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
     constexpr int NPIECE = NMAT * PER_WAVE + 1; // DMA pieces per wave and tile (+ the bias piece)
+    // DMA source offsets of this wave's PER_WAVE pieces of a matrix image (the same for mu and Wp, for every tile): bytes from the tile's first plane
+    uint32_t dsrc[PER_WAVE];
+#pragma unroll
+    for (int n = 0; n < PER_WAVE; ++n) {
+        const int inst = wave_u * PER_WAVE + n;
+        const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row (0..63), physical chunk
+        const int plane = pos / PLANE, row = (pos >> 8) & 63, chp = (pos >> 4) & 15;
+        const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
+        dsrc[n] = (uint32_t)((((row >> 5) * (32 * NP) + plane * 32 + (row & 31)) * 256) + 16 * ch);
+    }
     auto stage_piece = [&](int t, int buf, int n) {
         const uint32_t sb = smem_base + buf * STAGE;
         if (n < NMAT * PER_WAVE) {
-            const int mat = n / PER_WAVE;
-            const int inst = wave_u * PER_WAVE + n % PER_WAVE;
-            const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row (0..63), physical chunk
-            const int plane = pos / PLANE, row = (pos >> 8) & 63, chp = (pos >> 4) & 15;
-            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
-            // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
-            const size_t src = ((size_t)(2 * t + (row >> 5)) * (32 * NP) + plane * 32 + (row & 31)) * 256 + 16 * ch;
-            glds16(reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + src, sb + mat * TM + inst * 1024);
+            const int mat = n / PER_WAVE, nn = n % PER_WAVE;
+            const int inst = wave_u * PER_WAVE + nn;
+            const char* base = reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)t * (2 * 32 * NP * 256);    // wave-uniform: the tile's planes
+            glds16(base + dsrc[nn], sb + mat * TM + inst * 1024);
         } else {   // the two bias tiles, branch-free: even waves fetch mu_b's, odd waves bp's (twice each: the same bytes to the same place)
             const int c0 = t * BNT;
             const int which = BAYES ? (wave_u & 1) : 0;
@@ -2205,7 +2206,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
                         z_mma(1, g, fb[lb & 1][k]); ride(bm, bq, 0, 1, g, sw[0], rmask, rscale_pos, rscale_neg, dz_rsrc, lt);
                         // stage t-1 is free since the barrier that closed phase 1.  Unconditional (a branch per piece would cut the phase into 16 basic blocks):
                         // behind the last tile the free stage takes that tile once more
-                        if (g < NPIECE - 1) stage_piece(tn, buf ^ 1, g);
+                        if (g < NPIECE - 1) stage_piece(tn, buf ^ 1, g);                          // (one piece per group: two per group over half the phase cost +20 % of it)
                         if (g == 0) stage_piece(tn, buf ^ 1, NPIECE - 1);
                     }
                     else { d_mma(0, g, sw[0], fb[lb & 1][k]); ride(bm, bq, 1, 0, g, sw[1], rmask, rscale_pos, rscale_neg, dz_rsrc, lt); }
