@@ -10,8 +10,17 @@ negative sampling, KL term, backward, (gradient all-reduce,) Adam.  Inputs (CSR 
 weights) are resident in HBM before the timed region; nothing is skipped inside it.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel (HIP
-events recorded on the engine's stream during the timed region) and `cpu_baseline` (the oracle's
-reference-shaped dense step, timed on this box's host cores, N=1 only).
+events recorded on the engine's stream during the timed region; the other output-layer kernel under
+`roofline_other`) and `cpu_baseline` (the oracle's reference-shaped dense step, timed on this box's host cores,
+N=1 only).  A timed region shorter than 0.3 s is repeated five times: `ms_per_step` is the median region,
+`ms_per_step_spread` = (max - min) / median.
+
+N > 1 (`--parallel auto`, the default) times, in the same processes, the three ways a node shares a step:
+  headline `value`  data parallel, b = 1000 teams per GPU (weak scaling) - rows split over the GPUs, gradients reduce-scattered / parameters
+                    all-gathered over RCCL (opentf_amd/dp.py): what BASELINE.json's north_star names;
+  `ep_weak`         the output layer split along the expert axis, every GPU steps the global minibatch of 1000 N teams (opentf_amd/ep.py);
+  `strong_b1000`    what the plugin runs under torchrun: the reference's global minibatch of cfg.b = 1000 teams (src/mdl/__config__.yaml),
+                    shared in the form opentf_amd/mdl/fnn.py::_parallel_mode picks.
 """
 import argparse
 import json
@@ -59,6 +68,7 @@ def parse():
     ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "dp"],
                     help="N > 1: ep = expert-sharded output layer (every GPU steps the whole global minibatch on its 1/N of the experts; the only exchange is "
                          "d(hidden), opentf_amd/ep.py); dp = rows split over GPUs, gradients reduce-scattered (opentf_amd/dp.py); auto = ep when the model shards")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the short dblp_full (unfiltered matrix, M = 5 022 955) measurement printed under extra_configs at N = 1")
     ap.add_argument("--ep-emulate", type=int, default=0, metavar="G",
                     help="N = 1 only: run what ONE rank of G runs under --parallel ep (its 1/G of the experts, a global minibatch of G * --batch teams, two-phase "
                          "step, no exchange) - the per-rank compute time behind the scaling projection in DESIGN.md; not the headline")
@@ -94,25 +104,82 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
     for _ in range(steps):
         O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], sample_rows), member, cfg)
     dt = time.perf_counter() - t0
-    return {"value": steps * sample_rows / dt, "unit": "teams/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of B={sample_rows} at full M={ds['M']} (oracle/ntf_oracle.py reference_shaped_step, torch {torch.__version__} CPU)"}
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"): model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": steps * sample_rows / dt, "unit": "teams/s", "cores": cores, "threads_used": cores, "cores_total": ncpu, "cpu_model": model, "kind": "port",
+            "sample": f"{steps} steps of B={sample_rows} at full M={ds['M']} (oracle/ntf_oracle.py reference_shaped_step, torch {torch.__version__} CPU)",
+            "note": "cores = the torch thread count a short probe found fastest (cores_total = os.cpu_count()); calibration of this port against the imported reference "
+                    "Fnn.learn at M = 20 000: BASELINE.md section 3 (tests/golden/calibrate_cpu_port.py)"}
 
 
 def pmc_traffic(family, a, ds):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
+    """HBM bytes per launch of an output-layer kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
     as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
-    path = os.path.join(ROOT, "profiles", {"f32": "r1_c_pmc_traffic_and_sq.json", "bf16x6": "r1_d_pmc_traffic_and_sq.json"}.get(a.mfma, "r2_pmc_traffic_and_sq.json"))
-    if not os.path.exists(path): path = os.path.join(ROOT, "profiles", "r1_e_pmc_traffic_and_sq.json")
-    if not (os.path.exists(path) and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
+    names = {"f32": ["r1_c_pmc_traffic_and_sq.json"], "bf16x6": ["r1_d_pmc_traffic_and_sq.json"]}.get(a.mfma, ["r3_pmc_traffic_and_sq.json", "r2_pmc_traffic_and_sq.json"])
+    path = next((os.path.join(ROOT, "profiles", n) for n in names if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    if not (path and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
             and a.input == "meanpool" and not a.rows and not a.experts):
-        return None
-    key = {"out_fused_fwd_loss_dh": "k_out_fwd", "out_fused_dw_adam": "k_out_dw"}.get(family)
+        return None, None
+    key = {"out_fused_fwd_loss_dh": "k_out_fwd", "out_fused_dw_adam": "k_out_dw_p2"}.get(family)
     if not key:
-        return None
+        return None, None
+    best = None
     for name, v in json.load(open(path))["kernels"].items():
-        if key in name:
-            return v["hbm_bytes"]
-    return None
+        if key in name and "hbm_bytes" in v and (best is None or v["hbm_bytes"] > best): best = v["hbm_bytes"]   # (the no-op range-fallback kernels share the prefix)
+    return best, os.path.basename(path)
+
+
+def workload_label(a, ds, bayesian, multihot):
+    names = {"dblp": "dblp mt10.ts2 shapes", "dblp_full": "dblp UNFILTERED shapes (output/dblp/dblp.v12.json/prep.teamsvecs.log:18)", "uspt": "uspt mt10.ts2 shapes",
+             "uspt_full": "uspt UNFILTERED shapes (output/uspt/patent.tsv/prep.teamsvecs.log:34)", "gith": "gith UNFILTERED shapes", "imdb": "imdb shapes"}
+    return (f"{names.get(a.dataset, a.dataset)} N={ds['N']} S={ds['S']} M={ds['M']}; {a.model}{' (Flipout)' if bayesian else ''} on " +
+            (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
+            f"h=[{a.hidden}], b={a.batch}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3")
+
+
+def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
+    """roofline objects of the two output-layer kernels from their HIP-event times in the timed region: (dominant, other)"""
+    gemm = 2.0 * eB * H * Mloc  # one [rows,H]x[H,experts]-sized product of a launch
+    k = 2 if bayesian else 1
+    # per timed scope: the unfused families launch one GEMM per Flipout half (k launches), the fused ones a single kernel
+    flops_per_launch = {"out_fwd_gemm": k * gemm, "out_bwd_dw_gemm": k * gemm, "out_bwd_da_gemm": k * gemm,
+                        "out_fused_fwd_loss_dh": 2 * k * gemm, "out_fused_dw_adam": k * gemm}
+    cand = {f: times[f] for f in flops_per_launch if f in times and times[f][1] > 0}
+    out = []
+    for fam in sorted(cand, key=lambda f: -cand[f][0]):
+        ms, calls = cand[fam]
+        t = ms / calls * 1e-3
+        traffic, src = (None, None) if ep else pmc_traffic(fam, a, ds)
+        fused_adam = fam == "out_fused_dw_adam" and a.fuse_adam == 1 and not a.no_fused and a.mfma != "f32"
+        if fused_adam:
+            # dW + Adam (+ the next step's operands) in one kernel: HBM-bound.  Algorithmic bytes (DESIGN.md section 4): the packed dz read once (4 B per row and expert of
+            # the padded [256-expert tile, 128-row block] grid) + per weight 28 B read (mu, rho, sigma*eps, four Adam moments) + 24 B written (mu, rho, moments) + 12 B of
+            # next-step operands (sigma*eps' f32, the fp16 planes of it and of mu) for Flipout; 12 + 12 B for Fnn
+            Bpad = (eB + 127) // 128 * 128; Mpad = (Mloc + 255) // 256 * 256
+            per_w = 64 if bayesian else 24
+            nbytes = 4.0 * Bpad * Mpad + per_w * H * Mloc
+            out.append({"bound": "hbm", "kernel": fam, "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_source": src and f"per-launch mean of the separate rocprofv3 --pmc passes committed as profiles/{src} (FETCH_SIZE doubled per MI355X_MICROARCH.md), not counted in this run",
+                        "avg_ms": ms / calls, "launches": calls, "bytes_per_launch": nbytes, "bytes_def": f"4 B x {Bpad} x {Mpad} (packed dz) + {per_w} B x {H} x {Mloc} (Adam in place + next-step operands)",
+                        "mfma_tflops_algorithmic": flops_per_launch[fam] / t / 1e12})
+            continue
+        ach = flops_per_launch[fam] / t / 1e12
+        # arithmetic of the kernel: "bf16x6" = every f32 operand split exactly into 3 bf16 values, a product = 6 bf16 MFMA products
+        # accumulated in f32 (f32-accurate).  The roof for ALGORITHMIC flops is then the dense bf16 MFMA peak / 6.
+        split = a.mfma != "f32" and not a.no_fused and ((fam == "out_fused_dw_adam") or (fam == "out_fused_fwd_loss_dh" and a.hidden == 128))
+        nprod = (6 if a.mfma == "bf16x6" else 3) if split else 1
+        peak = BF16_MFMA_PEAK_TFLOPS / nprod if split else F32_MFMA_PEAK_TFLOPS
+        arith = {1: "f32 MFMA (v_mfma_f32_32x32x2_f32)",
+                 6: "bf16x6: operands split exactly into 3 bf16 values, 6 bf16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 6",
+                 3: "fp16x3: operands * 2^k split into 2 fp16 values (22 bits), 3 fp16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 3"}[nprod]
+        out.append({"bound": "mfma", "kernel": fam, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                    "traffic_source": src and f"per-launch mean of the separate rocprofv3 --pmc passes committed as profiles/{src} (FETCH_SIZE doubled per MI355X_MICROARCH.md), not counted in this run",
+                    "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[fam], "arithmetic": arith, "hw_mfma_tflops": ach * nprod})
+    return (out[0] if out else None), (out[1] if len(out) > 1 else None)
 
 
 def main():
@@ -148,54 +215,74 @@ def main():
     cfg = {"ns": 5, "nsd": a.nsd, "tpw": 10.0, "tnw": 1.0, "lr": 1e-3}
     if a.ep_emulate and world > 1: raise SystemExit("--ep-emulate is a single-GPU measurement")
     G = a.ep_emulate if a.ep_emulate else world
-    par = "dp"
-    if (G > 1 or (a.force_dist and a.parallel == "ep")) and not a.no_fused and a.parallel != "dp":
-        if can_shard(dims, G): par = "ep"
-        elif a.parallel == "ep": raise SystemExit(f"--parallel ep: {dims} does not shard over {G} GPUs (needs h[-1] in 32/64/128 and >= {G} tiles of 256 experts)")
-    ep = par == "ep"
-    shard = expert_shards(dims[-1], G)[0 if a.ep_emulate else rank] if ep else None
-    eB = a.batch * G if ep else a.batch                     # rows one engine steps: under ep every rank steps the whole global minibatch
+    shardable = (not a.no_fused) and can_shard(dims, G)
+    if a.parallel == "ep" and (G > 1 or a.force_dist) and not shardable:
+        raise SystemExit(f"--parallel ep: {dims} does not shard over {G} GPUs (needs h[-1] in 32/64/128 and >= {G} tiles of 256 experts)")
     stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        e = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=eB, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
-                          lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
-                          fuse_adam=a.fuse_adam if (world == 1 or ep) else 0, mfma=a.mfma, expert_shard=shard, ep_world=G if ep else 1)
-        if not multihot: e.set_skill_table(ds["table"])
-        e.set_skill_csr(ds["skill"]); e.set_member(ds["member"])
-        e.load_state_dict(init_params(dims, bayesian, 0))
-        if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
-            e.set_unigram(np.bincount(ds["member"][1], minlength=ds["M"]) / ds["N"])
-        if a.gather_only:
+    sd0 = init_params(dims, bayesian, 0)
+    n_params = int(sum(v.size for v in sd0.values()))
+    rng = np.random.default_rng(7)
+
+    def run_mode(par, gB, steps, warmup, reps_allowed=True, breakdown=True, data=ds, model_dims=dims, params=sd0):
+        """build an engine for this way of sharing a step (par = dp | ep, gB = the global minibatch), warm up, time `steps` steps between barriers; returns a dict"""
+        ep = par == "ep"
+        shard = expert_shards(model_dims[-1], G)[0 if a.ep_emulate else rank] if ep else None
+        eB = gB if ep else -(-gB // (1 if a.ep_emulate else world))     # rows one engine steps: under ep every rank steps the whole global minibatch
+        with torch.cuda.stream(stream):
+            e = libntf.Engine(model_dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=eB, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
+                              lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
+                              fuse_adam=a.fuse_adam if (world == 1 or ep) else 0, mfma=a.mfma, expert_shard=shard, ep_world=G if ep else 1)
+            if not multihot: e.set_skill_table(data["table"])
+            e.set_skill_csr(data["skill"]); e.set_member(data["member"])
+            e.load_state_dict(params)
+            if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
+                e.set_unigram(np.bincount(data["member"][1], minlength=data["M"]) / data["N"])
+            dp = ExpertParallel(e, two_phase=bool(a.ep_emulate)) if ep else DataParallel(e)
+            reps_max = 5 if reps_allowed else 1
+            order = rng.integers(0, data["N"], (warmup + steps * reps_max) * gB).astype(np.int64)   # the loader's shuffled row order
+            if warmup: dp.train_epoch(order[: warmup * gB], gB)
+            e.kernel_times(enable=2)    # HIP events around the two output-layer kernels only inside the timed region (the roofline's kernels)
+            regions, mean_loss, off = [], None, warmup * gB
+            while len(regions) < reps_max:
+                e.synchronize(); torch.cuda.synchronize()
+                if world > 1: dist.barrier()
+                t0 = time.perf_counter()
+                mean_loss = dp.train_epoch(order[off: off + steps * gB], gB)
+                e.synchronize(); torch.cuda.synchronize()
+                if world > 1: dist.barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                if world > 1: dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank sees the same region time, hence takes the same decision below
+                regions.append(float(t.item())); off += steps * gB
+                if regions[0] >= 0.3: break                                  # a region of >= 0.3 s is timed once
+            times = e.kernel_times(enable=False)
+            bd, k3 = None, 0
+            if breakdown:   # per-family breakdown from a SEPARATE short pass (events around every family perturb the step by a few per cent)
+                k3 = max(5, min(10, steps))
+                e.kernel_times(enable=True)
+                dp.train_epoch(order[: k3 * gB], gB); e.synchronize()
+                bd = {f: round(v[0] / k3, 4) for f, v in e.kernel_times(enable=False).items() if v[1] > 0}
+            dt = float(np.median(regions))
+            res = {"par": par, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "times": times, "breakdown": bd, "k3": k3,
+                   "Mloc": (shard[1] - shard[0]) if ep else model_dims[-1], "engine": e,
+                   "rccl_payload_bytes_per_step": (4 * gB * a.hidden) if ep else (8 * n_params if world > 1 else 0)}
+            return res
+
+    # ---- the headline mode
+    if world > 1 and a.parallel == "auto": head_par = "dp"                 # north_star: data parallel, gradients exchanged over RCCL
+    elif (G > 1 or a.force_dist) and a.parallel != "dp" and shardable: head_par = "ep"
+    else: head_par = "dp"
+    gB = a.batch * G                                       # weak scaling: B teams per GPU
+    head = run_mode(head_par, gB, a.steps, a.warmup)
+    e = head["engine"]
+    if a.gather_only:
+        with torch.cuda.stream(stream):
             for _ in range(5): e.gather_meanpool(n=ds["N"], to_host=False)
             e.synchronize()
-            print(json.dumps({"gather_only": True, "teams": ds["N"]}), file=real_stdout, flush=True)
-            return
-        dp = ExpertParallel(e, two_phase=bool(a.ep_emulate)) if ep else DataParallel(e)
-        gB = a.batch * G                                       # weak scaling: B teams per GPU
-        rng = np.random.default_rng(7)
-        total_steps = a.warmup + a.steps
-        order = rng.integers(0, ds["N"], total_steps * gB).astype(np.int64)   # the loader's shuffled row order
-        if a.warmup:
-            dp.train_epoch(order[: a.warmup * gB], gB)
-        e.kernel_times(enable=2)    # HIP events around the two output-layer kernels only inside the timed region (the roofline's kernels)
-        e.synchronize(); torch.cuda.synchronize()
-        if world > 1: dist.barrier()
-        t0 = time.perf_counter()
-        mean_loss = dp.train_epoch(order[a.warmup * gB:], gB)
-        e.synchronize(); torch.cuda.synchronize()
-        if world > 1: dist.barrier()
-        dt = time.perf_counter() - t0
-        times = e.kernel_times(enable=False)
-        # per-family breakdown from a SEPARATE short pass (events around every family perturb the step by a few per cent)
-        k3 = max(5, min(10, a.steps))
-        e.kernel_times(enable=True)
-        dp.train_epoch(order[: k3 * gB], gB); e.synchronize()
-        breakdown = {f: round(v[0] / k3, 4) for f, v in e.kernel_times(enable=False).items() if v[1] > 0}
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if world > 1: dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        print(json.dumps({"gather_only": True, "teams": ds["N"]}), file=real_stdout, flush=True)
+        return
 
-        gather = None
+    gather = None
+    with torch.cuda.stream(stream):
         if (a.gather_bench or (world == 1 and not a.no_gather_bench and not a.ep_emulate)) and rank == 0 and not multihot:
             e.kernel_times(enable=True)
             n = ds["N"]
@@ -204,86 +291,99 @@ def main():
             ms, calls = e.kernel_times(enable=False)["gather"]
             nnz = ds["skill"][0][-1] / n
             bytes_per_team = nnz * (4 * a.d + 4) + 8 + 4 * a.d
-            gather = {"bound": "hbm", "achieved": bytes_per_team * n / (ms / calls * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            t = ms / calls * 1e-3
+            gather = {"bound": "hbm", "achieved_algorithmic": bytes_per_team * n / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "bytes_per_team": bytes_per_team, "teams": n, "ms": ms / calls}
-            # the roof of THIS kernel: its table rows are random reads of a 46 MB table, served on-die (MI355X_MICROARCH.md, Indexed rows: 8.6 TB/s for
-            # uniformly random rows of a 38 MB table out of the Infinity Cache); only the CSR and the output rows are compulsory HBM traffic (8 TB/s)
-            t_roof = n * nnz * 4 * a.d / 8.6e12 + (n * (4 * a.d + 8 + nnz * 4) + ds["S"] * a.d * 4) / (HBM_PEAK_GBS * 1e9)
-            gather["peak"] = bytes_per_team * n / t_roof / 1e9
-            gather["peak_def"] = "algorithmic bytes / (gathered table bytes / 8.6 TB/s on-die + (output + CSR + table once) / 8 TB/s HBM)"
-            gather["frac"] = gather["achieved"] / gather["peak"]
-            pm = os.path.join(ROOT, "profiles", "r2_pmc_gather.json")
-            if os.path.exists(pm):
+            pm = next((os.path.join(ROOT, "profiles", f) for f in ("r3_pmc_gather.json", "r2_pmc_gather.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+            if pm:
                 for name, v in json.load(open(pm))["kernels"].items():
-                    if "k_gather_pool" in name and "hbm_bytes" in v: gather["traffic"] = v["hbm_bytes"]
-            # the algorithmic bytes count every gathered table row; the 46 MB table itself stays on-die (Infinity Cache / L2), so the compulsory
-            # HBM traffic is the output rows + the CSR (+ the table once)
+                    if "k_gather_pool" in name and "hbm_bytes" in v: gather["traffic"] = v["hbm_bytes"]; gather["traffic_source"] = "profiles/" + os.path.basename(pm)
+            # the algorithmic bytes count every gathered table row, but the 46 MB table is served on-die (Infinity Cache / L2): what crosses the HBM interface is the
+            # counter's figure (PMC) - the fraction of the HBM peak is stated on THAT; the compulsory traffic is the output rows + the CSR (+ the table once)
             comp = n * (4 * a.d + 8 + nnz * 4) + ds["S"] * a.d * 4
-            gather["hbm_compulsory_gbs"] = comp / (ms / calls * 1e-3) / 1e9
-            gather["note"] = "achieved = algorithmic bytes (SURVEY 8d: nnz*(4d+4)+8+4d per team) / time; the table rows are served on-die, so the roof is not the HBM peak (peak_def)"
+            gather["hbm_compulsory_gbs"] = comp / t / 1e9
+            if "traffic" in gather:
+                gather["achieved"] = gather["traffic"] / t / 1e9; gather["frac"] = gather["achieved"] / HBM_PEAK_GBS
+            else:
+                gather["achieved"] = gather["hbm_compulsory_gbs"]; gather["frac"] = gather["achieved"] / HBM_PEAK_GBS
+            gather["note"] = ("achieved = HBM bytes of the launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, committed pass) / time; achieved_algorithmic = SURVEY 8d's nnz*(4d+4)+8+4d per team / time "
+                              "exceeds the HBM peak because ~80 % of the table-row reads are served by the XCDs' L2s and the Infinity Cache (MI355X_MICROARCH.md, Indexed rows: 8.6 TB/s on-die)")
+        e.close()
+
+    # ---- N > 1, --parallel auto: the other two ways of sharing a step, same processes
+    extra_modes = {}
+    if world > 1 and a.parallel == "auto" and not a.ep_emulate:
+        def brief(r, scaling):
+            return {"parallelism": r["par"], "scaling": scaling, "global_batch": r["gB"], "rows_per_rank": r["eB"], "ms_per_step": r["dt"] / a.steps * 1e3,
+                    "value": a.steps * r["gB"] / r["dt"], "unit": "teams/s", "rccl_payload_bytes_per_step": r["rccl_payload_bytes_per_step"], "mean_loss": r["mean_loss"]}
+        if shardable:
+            r = run_mode("ep", a.batch * world, a.steps, a.warmup, breakdown=False); r["engine"].close()
+            extra_modes["ep_weak"] = brief(r, "weak")
+            extra_modes["ep_weak"]["what"] = "output layer split along the expert axis; every GPU steps the global minibatch of b x N teams on 1/N of the experts; only d(hidden) is all-reduced"
+        spar = "ep" if can_shard(dims, world) and not a.no_fused else "dp"      # opentf_amd/mdl/fnn.py::_parallel_mode
+        r = run_mode(spar, a.batch, a.steps, a.warmup, breakdown=False); r["engine"].close()
+        extra_modes["strong_b1000"] = brief(r, "strong")
+        extra_modes["strong_b1000"]["what"] = f"the plugin under torchrun: the reference's global minibatch of cfg.b = {a.batch} teams, shared as _parallel_mode picks ({spar})"
 
     exact_f32 = None
     if world == 1 and a.mfma == "default" and not a.no_f32_line and not a.no_fused and not a.ep_emulate:
         # the same workload on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32, a bit-exact f32 fma chain): quoted beside the fp16x3 headline
         with torch.cuda.stream(stream):
-            e.close()
             e2 = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd,
                                tpw=10.0, tnw=1.0, lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, mfma="f32")
             if not multihot: e2.set_skill_table(ds["table"])
-            e2.set_skill_csr(ds["skill"]); e2.set_member(ds["member"]); e2.load_state_dict(init_params(dims, bayesian, 0))
+            e2.set_skill_csr(ds["skill"]); e2.set_member(ds["member"]); e2.load_state_dict(sd0)
             if a.nsd == "unigram": e2.set_unigram(np.bincount(ds["member"][1], minlength=ds["M"]) / ds["N"])
             k2 = max(5, min(20, a.steps))
+            order = rng.integers(0, ds["N"], (3 + k2) * gB).astype(np.int64)
             e2.train_epoch(order[: 3 * gB], gB); e2.synchronize()
             t1 = time.perf_counter(); e2.train_epoch(order[3 * gB: (3 + k2) * gB], gB); e2.synchronize()
             dt2 = time.perf_counter() - t1
             exact_f32 = {"value": k2 * gB / dt2, "unit": "teams/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2, "arithmetic": "--mfma f32: v_mfma_f32_32x32x2_f32 kernels"}
             e2.close()
 
+    extra_configs = None
+    if world == 1 and rank == 0 and a.dataset == "dblp" and not (a.rows or a.experts or a.no_extra_configs or a.ep_emulate or a.no_fused or multihot) and a.mfma == "default":
+        # the "full DBLP" reading of north_star: the UNFILTERED matrix's expert count (M = 5 022 955, 1.29 G parameters, ~75 GB resident); 10 steps.  The step does not
+        # depend on the number of teams, so a 200 000-team sample of the 4 877 383 is staged.
+        saved = (a.dataset,)
+        dsf = make_dataset("dblp_full", d=a.d, seed=0, n_rows=200_000)
+        dimsf = [a.d, a.hidden, dsf["M"]]
+        a.dataset = "dblp_full"
+        r = run_mode("dp", a.batch, 10, 2, reps_allowed=False, breakdown=False, data=dsf, model_dims=dimsf, params=init_params(dimsf, bayesian, 0)); r["engine"].close()
+        extra_configs = {"dblp_full": {"workload": workload_label(a, dsf, bayesian, False), "steps": 10, "ms_per_step": r["dt"] / 10 * 1e3, "value": 10 * a.batch / r["dt"], "unit": "teams/s",
+                                       "mean_loss": r["mean_loss"]}}
+        a.dataset = saved[0]
+
     if rank != 0:
         if world > 1: dist.destroy_process_group()
         return
     if a.force_dist and world == 1: dist.destroy_process_group()
     B, H, M = a.batch, a.hidden, ds["M"]
-    Mloc = (shard[1] - shard[0]) if ep else M                # experts this GPU's kernels cover, over eB rows
-    gemm = 2.0 * eB * H * Mloc  # one [rows,H]x[H,experts]-sized product of a launch
-    k = 2 if bayesian else 1
-    # per timed scope: the unfused families launch one GEMM per Flipout half (k launches), the fused ones a single kernel
-    flops_per_launch = {"out_fwd_gemm": k * gemm, "out_bwd_dw_gemm": k * gemm, "out_bwd_da_gemm": k * gemm,
-                        "out_fused_fwd_loss_dh": 2 * k * gemm, "out_fused_dw_adam": k * gemm}
-    cand = {f: times[f] for f in flops_per_launch if f in times and times[f][1] > 0}
-    dom = max(cand, key=lambda f: cand[f][0]) if cand else None
-    roof = None
-    if dom:
-        ms, calls = cand[dom]
-        ach = flops_per_launch[dom] / (ms / calls * 1e-3) / 1e12
-        # arithmetic of the dominant kernel: "bf16x6" = every f32 operand split exactly into 3 bf16 values, a product = 6 bf16 MFMA products
-        # accumulated in f32 (f32-accurate).  The roof for ALGORITHMIC flops is then the dense bf16 MFMA peak / 6.
-        split = a.mfma != "f32" and not a.no_fused and ((dom == "out_fused_dw_adam") or (dom == "out_fused_fwd_loss_dh" and a.hidden == 128))
-        nprod = (6 if a.mfma == "bf16x6" else 3) if split else 1
-        peak = BF16_MFMA_PEAK_TFLOPS / nprod if split else F32_MFMA_PEAK_TFLOPS
-        arith = {1: "f32 MFMA (v_mfma_f32_32x32x2_f32)",
-                 6: "bf16x6: operands split exactly into 3 bf16 values, 6 bf16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 6",
-                 3: "fp16x3: operands * 2^k split into 2 fp16 values (22 bits), 3 fp16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 3"}[nprod]
-        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None if ep else pmc_traffic(dom, a, ds),
-                "traffic_source": "per-launch mean of the separate rocprofv3 --pmc passes of this command committed under profiles/ (collect_r2.sh), not counted in this run",
-                "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[dom],
-                "arithmetic": arith, "hw_mfma_tflops": ach * nprod}
+    ep = head["ep"]; dt = head["dt"]
+    roof, roof_other = rooflines(head["times"], a, bayesian, head["eB"], H, head["Mloc"], ds, ep)
+    spread = (max(head["regions"]) - min(head["regions"])) / dt if len(head["regions"]) > 1 else None
+    devices = [torch.cuda.get_device_name(local)]
     out = {
         "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_spread": spread, "timed_regions": len(head["regions"]),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"f32": "f32", "bf16x6": "f32 (bf16x6 split products, f32 accumulate)"}.get(a.mfma, "f32 (fp16x3 split products, f32 accumulate)"), "data": "synthetic",
-        "config": {"workload": f"{a.dataset} mt10.ts2 shapes N={ds['N']} S={ds['S']} M={M}; {a.model}{' (Flipout)' if bayesian else ''} on " +
-                               (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
-                               f"h=[{H}], b={B}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3", "global_batch": gB,
-                   "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else f"dp{world}")},
-        "roofline": roof, "cpu_baseline": None, "exact_f32_mfma": exact_f32, "mean_loss": mean_loss,
-        "kernel_ms_per_step": breakdown, "kernel_ms_note": "separate pass of %d steps with events around every kernel family; the timed region carries events around the two output-layer kernels only" % k3,
+        "config": {"workload": workload_label(a, ds, bayesian, multihot), "global_batch": gB,
+                   "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else
+                                   f"dp{world}" + (": rows split over the GPUs, gradients reduce-scattered / parameters all-gathered over RCCL, Adam on the owned 1/N shard" if world > 1 else ""))},
+        "roofline": roof, "roofline_other": roof_other, "cpu_baseline": None, "exact_f32_mfma": exact_f32, "mean_loss": head["mean_loss"],
+        "kernel_ms_per_step": head["breakdown"], "kernel_ms_note": "separate pass of %d steps with events around every kernel family (side-stream families overlap the big kernels: the column does not sum to the step); the timed region carries events around the two output-layer kernels only" % head["k3"],
+        "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1), "rank0_device": f"cuda:{local} {devices[0]}",
+        "rccl_payload_bytes_per_step": head["rccl_payload_bytes_per_step"],
     }
+    out.update(extra_modes)
+    if extra_configs: out["extra_configs"] = extra_configs
     if gather: out["roofline_gather"] = gather
     if a.validate_on_one_gpu: out["validation_only"] = "all ranks on cuda:0 over gloo: code-path check, not a measurement"
     if a.ep_emulate:
         # one rank of G: it processed the whole global minibatch on 1/G of the experts, i.e. 1/G of the job
+        shard = expert_shards(dims[-1], G)[0]
         out["metric"] += f" [one rank of {G} under --parallel ep, emulated on one GPU without the exchange]"
         out["value"] = a.steps * a.batch / dt; out["n_gpus"] = 1
         out["ep_emulation"] = {"G": G, "experts": [int(shard[0]), int(shard[1])], "rows_per_step": gB, "ms_per_step": dt / a.steps * 1e3,

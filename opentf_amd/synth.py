@@ -13,6 +13,7 @@ import numpy as np
 SHAPES = {
     "dblp": (1_995_708, 90_671, 233_629, 8.57, 3.06),        # dblp.v12.json.mt10.ts2
     "dblp_full": (4_877_383, 132_334, 5_022_955, 8.57, 3.06),
+    "uspt_full": (7_068_508, 241_961, 3_508_807, 6.29, 2.51),    # output/uspt/patent.tsv/prep.teamsvecs.log:34
     "uspt": (2_596_322, 213_317, 394_187, 6.29, 2.51),       # patent.tsv.mt10.ts2
     "gith": (612_119, 486, 1_369_895, 1.37, 5.53),           # repos.csv (unfiltered)
     "imdb": (186_385, 27, 44_774, 1.54, 1.88),

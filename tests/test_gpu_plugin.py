@@ -416,7 +416,7 @@ def test_plugin_two_processes_one_gpu(mode, tmp_path):
             np.testing.assert_allclose(pb["uncertainty"][key][0], pa["uncertainty"][key][0], rtol=5e-3, atol=5e-3)
 
 
-@pytest.mark.parametrize("parallel", ["ep", "dp"])
+@pytest.mark.parametrize("parallel", ["ep", "dp", "auto"])
 def test_bench_multi_rank_launch_on_one_gpu(parallel):
     """the driver's N > 1 launch line (`python -m torch.distributed.run ... bench.py --gpus N ...`) with both ranks on this GPU over gloo: rank handling,
     barriers, the max-over-ranks timing and the single JSON line of bench.py's multi-rank path"""
@@ -435,5 +435,13 @@ def test_bench_multi_rank_launch_on_one_gpu(parallel):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2000
-    assert d["config"]["parallelism"].startswith(parallel + "2") and d["value"] > 0 and np.isfinite(d["mean_loss"])
+    head = "dp" if parallel == "auto" else parallel        # default: the headline is north_star's form - data parallel, b = 1000 per GPU
+    assert d["config"]["parallelism"].startswith(head + "2") and d["value"] > 0 and np.isfinite(d["mean_loss"])
     assert d["roofline"]["kernel"] in ("out_fused_fwd_loss_dh", "out_fused_dw_adam") and d["cpu_baseline"] is None
+    assert d["rccl_ranks"] == 2 and d["timed_regions"] == 5 and d["ms_per_step_spread"] is not None
+    if parallel == "auto":   # ... and the other two ways of sharing a step are timed in the same launch
+        ew, st = d["ep_weak"], d["strong_b1000"]
+        assert ew["parallelism"] == "ep" and ew["scaling"] == "weak" and ew["global_batch"] == 2000 and ew["rows_per_rank"] == 2000 and ew["value"] > 0
+        assert st["scaling"] == "strong" and st["global_batch"] == 1000 and st["parallelism"] == "ep" and st["value"] > 0      # (4096 experts shard over 2 ranks)
+        assert ew["rccl_payload_bytes_per_step"] == 4 * 2000 * 128 and d["rccl_payload_bytes_per_step"] > 8 * 128 * 4096
+        assert np.isfinite(ew["mean_loss"]) and np.isfinite(st["mean_loss"])
