@@ -91,3 +91,74 @@ def test_one_kernel_head_equals_the_kernel_chain(bayesian, d, dense, B, monkeypa
     for k in a[3]:
         tol = 2e-5 * float(np.abs(a[3][k]).max()) + 1e-12
         assert float(np.abs(a[3][k] - b[3][k]).max()) <= tol, (k, float(np.abs(a[3][k] - b[3][k]).max()), tol)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 2 at FULL size against the oracle
+def test_config2_full_size_step_against_the_oracle():
+    """VERDICT r2 missing #4: at [128, 128, 233 629], B = 1000 the HIP path had only been compared with the repo's own generic path.  Here: one Bnn train step of
+    src/mdl/fnn.py:122-140 at exactly that size - mean-pooled input, every random tensor injected (eps, s_in, s_out, negatives) - against oracle/ntf_oracle.py
+    (torch CPU, autograd): logits element-wise on a 64-row slice and in the max norm over all 2.3e8 (1e-4), loss (2e-5), every gradient (3e-4 of its max, with a
+    budget of leaky_relu' kink flips on the output layer), and the parameters after the fused dW + Adam kernel."""
+    import torch
+    from conftest import draw_noise
+    from oracle import ntf_oracle as O
+    from opentf_amd import libntf
+    D, H, M, B, S = 128, 128, 233_629, 1000, 4000
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    sd = O.bnn_init(D, [H], M)
+    table = rng.standard_normal((S, D)).astype(np.float32)
+    nnz = 1 + rng.poisson(7.57, B)
+    s_ip = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int64)
+    s_ix = np.concatenate([np.sort(rng.choice(S, k, replace=False)) for k in nnz]).astype(np.int32)
+    X = torch.from_numpy(O.gather_meanpool_fast(s_ip, s_ix, table))
+    mn = 1 + rng.poisson(2.06, B)
+    m_ip = np.concatenate([[0], np.cumsum(mn)]).astype(np.int64)
+    m_ix = np.concatenate([np.sort(rng.choice(M, k, replace=False)) for k in mn]).astype(np.int32)
+    y = torch.zeros(B, M)
+    y[np.repeat(np.arange(B), mn), m_ix.astype(np.int64)] = 1.0
+    noise = draw_noise(sd, B)
+    neg = O.ns_uniform(y, 5)
+    inj = {"neg_idx": neg.numpy(), "eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise],
+           "s_in": [n["s_in"] for n in noise], "s_out": [n["s_out"] for n in noise]}
+    rows = np.arange(B)
+
+    def engine(fuse_adam):
+        e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", tpw=10.0, tnw=1.0, lr=1e-3, fuse_adam=fuse_adam)
+        e.set_skill_table(table); e.set_skill_csr((s_ip, s_ix)); e.set_member((m_ip, m_ix)); e.load_state_dict(sd)
+        return e
+
+    e = engine(0)
+    ref_logits = O.bnn_forward(sd, X, noise).detach().numpy()
+    got = e.logits(rows, inject=inj)
+    assert got.shape == ref_logits.shape == (B, M)
+    sl = np.arange(7, B, 16)[:64]
+    np.testing.assert_allclose(got[sl], ref_logits[sl], rtol=1e-4, atol=2e-6)
+    assert float(np.abs(got - ref_logits).max()) <= 1e-4 * float(np.abs(ref_logits).max())
+    del got, ref_logits
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    ref_loss, ref_grads = O.train_step(sd_ref, O.Adam(sd_ref, 1e-3), X, y, neg, 10.0, 1.0, noise)     # sd_ref now holds the oracle's updated parameters
+    loss = e.backward(rows, inject=inj)
+    assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss), (loss, ref_loss)
+    grads = e.grads()
+    for k in sd:
+        ref = ref_grads[k].numpy()
+        d = np.abs(grads[k] - ref)
+        tol = 3e-4 * float(np.abs(ref).max())
+        if k.startswith("layers.1."):
+            # |z| within rounding of 0 lands on either side of leaky_relu's kink in another summation order: one (row, expert) pair flips, moving that expert's
+            # gradient row (128 elements of the weight tensors, one of the bias tensors) by up to 0.99 |dz| |h|; ~1e-7 of the 2.3e8 logits
+            assert int((d > tol).sum()) <= 64 * (H if k.endswith("weight") else 1), (k, int((d > tol).sum()))
+        else:
+            assert float(d.max()) <= tol, (k, float(d.max()), tol)
+    e.close()
+    # the default path: dW + Adam fused (the update happens inside the kernel; gradients of the output layer are never written)
+    e = engine(1)
+    loss1 = e.train_step(rows, inject=inj)
+    assert abs(loss1 - ref_loss) <= 2e-5 * abs(ref_loss)
+    st = e.state_dict(); e.close()
+    for k in sd:
+        a, b = st[k], sd_ref[k].numpy()
+        bad = np.abs(a - b) > (1e-3 * np.abs(b) + 2e-5)
+        # Adam's first step is lr * g / (|g| + eps): where |g| ~ 1e-8 .. a rounding difference in g moves the update by up to 2 lr
+        assert float(bad.mean()) <= 2e-4, (k, float(bad.mean()))
