@@ -112,8 +112,9 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
         pass
     return {"value": steps * sample_rows / dt, "unit": "teams/s", "cores": cores, "threads_used": cores, "cores_total": ncpu, "cpu_model": model, "kind": "port",
             "sample": f"{steps} steps of B={sample_rows} at full M={ds['M']} (oracle/ntf_oracle.py reference_shaped_step, torch {torch.__version__} CPU)",
-            "note": "cores = the torch thread count a short probe found fastest (cores_total = os.cpu_count()); calibration of this port against the imported reference "
-                    "Fnn.learn at M = 20 000: BASELINE.md section 3 (tests/golden/calibrate_cpu_port.py)"}
+            "note": "cores = the torch thread count a short probe found fastest (cores_total = os.cpu_count()).  Calibration (tests/golden/calibrate_cpu_port.py, build container, 8 threads, "
+                    "Fnn, M = 20 000, B = 1000): this port runs 1.62 x the rate of the imported reference Fnn.learn (1696 teams/s) - it skips the per-team NtfDataset.__getitem__ + collate "
+                    "of src/mdl/ntf.py:22-24; BASELINE.md section 3"}
 
 
 def pmc_traffic(family, a, ds):
