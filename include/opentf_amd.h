@@ -195,6 +195,9 @@ int ntf_gather_meanpool(ntf_engine* e, const int64_t* rows, int64_t n, float* ou
 /* ---- raw device views for RCCL (torch.distributed) and measurement */
 int ntf_grad_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
 int ntf_param_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
+/* Adam's first / second moments (torch.optim.Adam's exp_avg / exp_avg_sq, src/mdl/fnn.py:104), same flat layout as the parameters: an expert-sharded
+ * run re-broadcasts the replicated hidden layers' parameters AND moments once per epoch (opentf_amd/ep.py) */
+int ntf_moment_buffers(ntf_engine* e, void** dev_m1, void** dev_v2, int64_t* n_floats);
 int ntf_synchronize(ntf_engine* e);
 /* HIP-event timing of the kernels launched by the engine since the last reset, by kernel family:
  * names[i] (static strings), ms[i] total, calls[i].  Returns the number of families (<= cap).

@@ -1488,6 +1488,11 @@ extern "C" int ntf_grad_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats)
 extern "C" int ntf_param_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats) {
     if (!e || !dev_ptr || !n_floats) return NTF_EINVAL; *dev_ptr = e->P; *n_floats = e->n_params; return NTF_OK;
 }
+extern "C" int ntf_moment_buffers(ntf_engine* e, void** dev_m1, void** dev_v2, int64_t* n_floats) {
+    if (!e || !dev_m1 || !dev_v2 || !n_floats) return NTF_EINVAL;
+    *dev_m1 = e->M1; *dev_v2 = e->V2; *n_floats = e->n_params;
+    return NTF_OK;
+}
 extern "C" int ntf_synchronize(ntf_engine* e) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));

@@ -108,7 +108,10 @@ class ExpertParallel:
         from .libntf import P_WEIGHT
         end, _ = e.param_segment(e.L - 1, P_WEIGHT)     # segments are laid out layer by layer: [0, end) = the hidden layers
         if end > 0:
-            dist.broadcast(e.param_tensor()[:end], src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(e.param_tensor()[:end], src=src, group=self.group)
+            if hasattr(e, "moment_tensors"):     # ... and Adam's moments of those layers: replicas that keep their own would drift apart again at once
+                for t in e.moment_tensors(): dist.broadcast(t[:end], src=src, group=self.group)
 
     def train_epoch(self, order, global_B):
         return self._phase(order, global_B, True)

@@ -82,6 +82,7 @@ SYMBOLS = {
     "ntf_forward_topk": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "ntf_gather_meanpool": (C.c_int, [_P, _P, _I64, _P]),
     "ntf_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "ntf_moment_buffers": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_I64)]),
     "ntf_param_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "ntf_synchronize": (C.c_int, [_P]),
     "ntf_kernel_times": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
@@ -344,6 +345,14 @@ class Engine:
         """torch tensor aliasing the flat parameter buffer in HBM (what the sharded step all-gathers)"""
         import torch
         return torch.as_tensor(self.param_view(), device=f"cuda:{torch.cuda.current_device()}")
+
+    def moment_tensors(self):
+        """torch tensors aliasing Adam's exp_avg / exp_avg_sq buffers (flat, the parameters' layout)"""
+        import torch
+        m, v, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._ck(lib().ntf_moment_buffers(self._h, C.byref(m), C.byref(v), C.byref(n)))
+        dev = f"cuda:{torch.cuda.current_device()}"
+        return (torch.as_tensor(DeviceView(m.value, n.value, self), device=dev), torch.as_tensor(DeviceView(v.value, n.value, self), device=dev))
 
     def train_epoch(self, order, B):
         o = self._rows(order); loss = C.c_float()

@@ -8,7 +8,8 @@ What the caller (src/main.py:100-153) does and what it gets here:
       (gnn.py:84-116), `torch_geometric.nn.Node2Vec` (p = q = 1) trained by `_train_rw` (gnn.py:401-453: shuffled node batches, Adam,
       ReduceLROnPlateau on v_loss, EarlyStopping, `f{k}.pt` / `f{k}.e{e}.pt` checkpoints holding `embedding.weight`).  Here the walks,
       the skip-gram loss, its gradient and the dense Adam run in `opentf_amd/csrc/ntf_n2v.hip`; control flow, file names and
-      checkpoint keys are the reference's.  An existing `f{k}.pt` (e.g. one the reference trained) is loaded instead, as gnn.py:402-405 does.
+      checkpoint keys are the reference's.  An existing `f{k}.pt` written by THIS plugin (it carries the node order its rows are sliced by) is loaded instead, as gnn.py:402-405 does; a file
+      without that marker - e.g. one the reference trained, whose node order follows its pickled graph - is refused rather than sliced wrong.
   * `skill_vecs = t2v.get_dense_vecs(teamsvecs, vectype='skill')`                                                  (main.py:148)
       the mean-pool `(skill @ E_skill) / skill.sum(1)` (gnn.py:484-486) by the gather kernel, returned as the dense [N, d] matrix the
       caller stores in `teamsvecs['skill']` — AND `teamsvecs['skill_table'] = E_skill` is registered, so that the Fnn / Bnn plugin of this
@@ -70,6 +71,15 @@ def member_team_edges(member, teams, off):
     return np.concatenate([m, t]), np.concatenate([t, m])
 
 
+NODE_ORDER = "skill|member|team"     # row blocks of the table this plugin trains (stm_graph)
+
+
+def _barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 class Gnn(T2v):
     def __init__(self, output, device, seed, cfg, model):
         super().__init__(output, device, seed, cfg, model)
@@ -110,9 +120,15 @@ class Gnn(T2v):
             self.offsets = off
             init = torch.nn.Embedding(n, d).weight.detach().numpy()       # the draw Node2Vec's constructor makes (gnn.py:153-160)
             path = f"{self.output}/f{foldidx}.pt"
+            _barrier()                                                     # torchrun: nobody looks for the file while rank 0 may still be writing the previous one
             if os.path.exists(path):                                       # gnn.py:402-405: a trained table is loaded, not retrained
+                ck = torch.load(path, map_location="cpu", weights_only=False)
+                # only tables THIS plugin saved: the rows are sliced as [skills | members | teams] (stm_graph).  The reference orders its node stores by iterating a Python
+                # set (src/mdl/emb/gnn.py:29-47: the order depends on PYTHONHASHSEED and lives in its pickled graph) - such a file would be sliced wrong without an error
+                if ck.get("node_order") != NODE_ORDER or tuple(ck.get("node_offsets", ())) != (off["skill"], off["member"], off["team"], n):
+                    raise RuntimeError(f"{path} was not written by opentf_amd.mdl.emb.gnn (no / another node order): remove it to retrain the table on the device")
                 log.info(f"Loading the model {path} ...")
-                self.model = torch.load(path, map_location="cpu", weights_only=False)["model_state_dict"]["embedding.weight"].numpy()
+                self.model = ck["model_state_dict"]["embedding.weight"].numpy()
                 continue
             if w is None: w = self.writer(log_dir=f"{self.output}/logs4tboard/run_{int(time.time())}")
             val_src, val_dst = member_team_edges(member, splits["folds"][foldidx]["valid"], off)
@@ -144,9 +160,14 @@ class Gnn(T2v):
 
     def _save(self, weight, foldidx, e, t_loss, v_loss, path):
         import torch
-        if dist_rank() == 0:   # keys and order of gnn.py:445,453
+        if dist_rank() == 0:   # keys and order of gnn.py:445,453, + the node order the rows are sliced by; written whole, then moved into place
+            off = self.offsets
+            tmp = f"{path}.tmp.{os.getpid()}"
             torch.save({"model_state_dict": {"embedding.weight": torch.from_numpy(np.ascontiguousarray(weight))}, "cfg": self.cfg, "f": foldidx, "e": e,
-                        "t_loss": t_loss, "v_loss": v_loss}, path)
+                        "t_loss": t_loss, "v_loss": v_loss, "node_order": NODE_ORDER,
+                        "node_offsets": (off["skill"], off["member"], off["team"], int(weight.shape[0]))}, tmp)
+            os.replace(tmp, path)
+        _barrier()
 
     def _node_emb(self, teamsvecs, node_type):
         if self.model is None:

@@ -78,6 +78,13 @@ def make_fnn(base):
                 self._resident = {}
             slot = "train" if train else "whole"
             cached = self._resident.get(slot)
+            if cached is None and train:
+                # an UNSHARDED training engine (one GPU, or data parallel) serves both roles and lives in the "whole" slot (below): reuse it when it is this
+                # dataset's - tNtf's intervals then keep ONE engine resident instead of building a second one per interval
+                w = self._resident.get("whole")
+                if w is not None and w[0] == key and getattr(w[1], "parallel_mode", None) != "ep" and \
+                        getattr(w[1], "parallel_mode", None) == self._parallel_mode(w[2], getattr(self, "_world", 1)):
+                    return w[1], w[2]
             if cached is not None:
                 if cached[0] == key:
                     return cached[1], cached[2]

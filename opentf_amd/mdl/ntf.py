@@ -57,6 +57,13 @@ def dist_rank():
     return d.get_rank() if d.is_available() and d.is_initialized() else 0
 
 
+def _dist_barrier():
+    import torch
+    d = torch.distributed
+    if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
+        d.barrier()
+
+
 class _NullWriter:
     def __init__(self, log_dir=None): pass
     def add_scalar(self, tag, scalar_value, global_step): pass
@@ -102,6 +109,8 @@ class Ntf:
         import torch
         from ..evl import metric
         assert os.path.isdir(self.output), f"No folder for {self.output} exist!"
+        if dist_rank() != 0:        # torchrun: ONE writer of the csv / pkl files (as in test()); the others wait for it
+            _dist_barrier(); return
         y_test = teamsvecs["member"][splits["test"]]
         trec = list(cfg_get(cfg_get(evalcfg, "metrics"), "trec") or [])
         other = list(cfg_get(cfg_get(evalcfg, "metrics"), "other") or [])
@@ -152,6 +161,7 @@ class Ntf:
             mean_std.to_csv(f"{self.output}/{pred_set}.pred.eval.mean.csv")
             if per_instance:
                 fold_inst.truediv(len(splits["folds"].keys())).to_csv(f"{self.output}/{pred_set}.pred.eval.instance_mean.csv", index=False)
+        _dist_barrier()   # rank 0 wrote: the other ranks (waiting at the top) may go on
 
     def adila(self, teamsvecs, splits, faircfg):
         raise NotImplementedError("adila() is the reference's fairness stage (src/mdl/ntf.py:108-134); see INTEGRATION.md")

@@ -92,12 +92,23 @@ def test_gnn_n2v_plugin_on_toy_dblp_against_the_committed_reference_run(tmp_path
     ours = []
     for k in range(3):
         ck = torch.load(f"{t2v.output}/f{k}.pt", map_location="cpu", weights_only=False)
-        assert list(ck.keys()) == [str(x) for x in g[f"f{k}.keys"]] and list(ck["model_state_dict"].keys()) == ["embedding.weight"]
+        # the reference's keys in its order (src/mdl/emb/gnn.py:445,453), then the two this plugin adds: the node order its rows are sliced by (a table whose
+        # node order is unknown - e.g. one the reference trained, ordered by its pickled graph - must be refused, not sliced wrong)
+        ref_keys = [str(x) for x in g[f"f{k}.keys"]]
+        assert list(ck.keys()) == ref_keys + ["node_order", "node_offsets"] and list(ck["model_state_dict"].keys()) == ["embedding.weight"]
+        assert ck["node_order"] == "skill|member|team" and ck["node_offsets"][-1] == ck["model_state_dict"]["embedding.weight"].shape[0]
         W = ck["model_state_dict"]["embedding.weight"].numpy()
         assert W.shape == g[f"f{k}.embedding.weight"].shape and W.dtype == np.float32
         assert abs(W.std() - g[f"f{k}.embedding.weight"].std()) < 0.05
         ours.append(ck["t_loss"])
         assert os.path.exists(f"{t2v.output}/f{k}.e0.pt") and os.path.exists(f"{t2v.output}/f{k}.e9.pt")
+    # a table without the marker (what the reference's own run leaves behind) is refused
+    ck = torch.load(f"{t2v.output}/f0.pt", map_location="cpu", weights_only=False)
+    order = ck.pop("node_order"); torch.save(ck, f"{t2v.output}/f0.pt")
+    t3 = Gnn(str(tmp_path), "cuda:0", 0, cfg, "n2v")
+    with pytest.raises(RuntimeError, match="node order"):
+        t3.learn(tv, sp)
+    ck["node_order"] = order; torch.save(ck, f"{t2v.output}/f0.pt")
     assert abs(np.mean(ours) - np.mean(committed)) < 0.6, (ours, committed)
     # a second learn() loads the files instead of training (gnn.py:402-405)
     stamp = os.path.getmtime(f"{t2v.output}/f0.pt")

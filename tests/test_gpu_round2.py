@@ -314,7 +314,11 @@ def test_config5_gith_shapes_temporal_streaming_bnn(tmp_path):
         cfg = Cfg(b=1000, e=1, ns=5, lr=lr, es=5, h=[128], spe=0, l="bce", tpw=10, tnw=1, nsd="uniform", nmc=2)
         inner = Bnn(str(tmp_path / f"lr{lr}"), "cuda:0", 0, cfg)
         t = tNtf(str(tmp_path / f"lr{lr}"), "cuda:0", 0, Cfg(tfolds=2, step_ahead=1), inner, year_idx)
+        built = []
+        orig_new = inner._new_engine
+        inner._new_engine = lambda *a, **k: (built.append(1), orig_new(*a, **k))[1]
         t.learn(tv, sp, None)
+        assert len(built) == 1, len(built)                                              # ONE engine for all intervals and folds (it used to be rebuilt per interval)
         assert not getattr(inner, "_resident", None)                                    # released at the end of the stream
         years = sorted(int(x) for x in os.listdir(t.output) if x.isdigit())
         assert years == [2016, 2017, 2018, 2019, 2020]
