@@ -26,6 +26,9 @@ namespace ntf {
 constexpr int BM = 128;       // batch rows per workgroup: 4 waves x 32
 constexpr int BN = 64;        // experts per tile
 constexpr int NCG_MAX = 256;  // column groups (one workgroup per CU when the batch has a single row block)
+#ifndef DW_PPG
+#define DW_PPG 2      // DMA pieces of the next K block per MFMA group (1: 0.705, 2: 0.693, 4: 0.707 ms at config 2)
+#endif
 constexpr int DW_WAVES = 8;               // waves per workgroup of the dW kernel: two per SIMD
 constexpr int DW_TC = 32 * DW_WAVES;      // experts per workgroup of the dW kernel
 
@@ -175,8 +178,7 @@ __device__ __forceinline__ bool range_guard_skip(int* rflag, int rmode, bool cou
 }
 
 template <int H, bool BAYES, bool TRAIN, bool DH, bool INJ>
-__global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void out_fwd_f32_body(const OutFwdArgs& p, char* smem) {
     constexpr int ROWB = 4 * H;              // bytes per weight row
     constexpr int TB = BN * ROWB;            // bytes per weight tile
     constexpr int NMAT = BAYES ? 2 : 1;
@@ -444,6 +446,12 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
     }
 }
 
+template <int H, bool BAYES, bool TRAIN, bool DH, bool INJ>
+__global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    out_fwd_f32_body<H, BAYES, TRAIN, DH, INJ>(p, smem);
+}
+
 // ------------------------------------------------------------------------------------------------
 struct SpecialArgs {
     int B, M, Bpad, NCG, nCB, ns;
@@ -593,6 +601,7 @@ struct DwArgs {
     // split-K (k_out_dw_p2 only): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
     // contiguous part of the K blocks into part[(split * 2 + matrix) * slab ..] (bias sums behind the slabs); k_out_dw_finish adds the parts and runs the epilogue
     int ksplit; float* part; int64_t slab;
+    unsigned long long* stamps;   // diagnostics (k_out_dw_p2<.., STAMP>)
     int ntile, stagger;   // k_out_dw_p2, unsplit: expert tiles of this launch (walked by persistent workgroups), start delay of every second workgroup (100 MHz ticks)
     // produce != 0 (fused Adam, Flipout, fp16x3 planes): the epilogue holds the UPDATED mu' / rho' of its elements - it also is the next step's operand producer:
     // eps' (Philox keyed by step + 1), Wp' = softplus(rho') eps' (f32, in place over this step's Wp), the fp16 split planes of Wp' and mu' that the forward kernel
@@ -666,8 +675,7 @@ __device__ __forceinline__ void dw_produce_finish(const DwArgs& p, float kl, flo
 }
 
 template <int H, bool BAYES, bool ADAM>
-__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADAM: see DwArgs
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void out_dw_f32_body(const DwArgs& p, char* smem) {  // ADAM: see DwArgs
     constexpr int NJT = H / 32;
     constexpr int KB = 32;                  // batch rows per K block
     constexpr int HROW = 4 * H;
@@ -814,6 +822,12 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {  // ADA
         }
     }
     if constexpr (BAYES && ADAM && H == 128) { if (p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem), DW_WAVES); }
+}
+
+template <int H, bool BAYES, bool ADAM>
+__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    out_dw_f32_body<H, BAYES, ADAM>(p, smem);
 }
 
 // ================================================================================================
@@ -1151,7 +1165,8 @@ __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
 // ds_read_b128 + eight v_perm_b32 instead of an f32 split (the round-1 kernel spent a third of its time on that vector work: with MFMAs, DMA and
 // epilogue ablated it still took 0.20 of 0.63 ms); the s_out words come transposed from k_sign_words_T (one ds_read_b32 per K block instead of a
 // hash + five shuffle stages); the bias gradients are v_dot2_f32_f16 sums over the plane registers.
-template <bool BAYES, bool ADAM>
+// STAMP (diagnostics, NTF_DW_STAMP): s_memtime sums per wave - K-block bodies, their end-of-block DMA wait + barrier, the epilogue - written to p.stamps
+template <bool BAYES, bool ADAM, bool STAMP = false>
 __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128, NJT = 4, NP = 2;
@@ -1163,8 +1178,12 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     constexpr int STAGE = TA + TB + TS;
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    if (range_guard_skip(p.rflag, p.rmode, false)) return;
     const bool split = p.ksplit > 1;
+    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) {
+        // the step runs in exact f32 (see k_out_fwd_h3x): the f32 kernel's body for this tile, here; the split-K form leaves it to the launch behind the finish kernel
+        if (!split && p.ntile == (int)gridDim.x) { DwArgs q = p; q.rmode = 0; out_dw_f32_body<128, BAYES, ADAM>(q, smem); }
+        return;
+    }
     // Unsplit: workgroups walk the launch's expert tiles with stride gridDim.x (default grid = the tile count: one tile each).  A tile is a main loop followed by
     // an HBM-bound epilogue (Adam in place + the next step's operands: 64 B per mu / rho pair), and with every workgroup in the same phase at the same time
     // neither hides the other.  Round 3 tried the obvious cure - persistent workgroups (NTF_DW_PGRID=256), every second one of an XCD starting p.stagger ticks
@@ -1209,6 +1228,16 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     auto stage = [&](int c0, int ib, int buf) {
 #pragma unroll
         for (int n = 0; n < NA + NB; ++n) stage_piece(c0, ib, buf, n);
+    };
+    unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int slot) {
+        if (!STAMP) return;
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long tnow;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot >= 0) st_sum[slot] += tnow - st_prev;
+        st_prev = tnow;
     };
     float nx_kl = 0.f, nx_amax = 0.f;
     if (tile0 < ntile) stage((p.wg_begin + tile0) * DW_TC, ib0, 0);
@@ -1276,11 +1305,21 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);
             // the next K block's DMA, one piece per half-group: a burst of 8-9 LDS-DMA issues in one gap stalls the wave's own MFMA stream
-            if (MORE && hg < NA + NB) stage_piece(c0, ib + 1, buf ^ 1, hg);
+            if (MORE) {   // NTF_DW_BURST (experiment): pieces per MFMA group
+                constexpr int PPG = DW_PPG;
+                if (hg * PPG < NA + NB) {
+#pragma unroll
+                    for (int q = 0; q < PPG; ++q) if (hg * PPG + q < NA + NB) stage_piece(c0, ib + 1, buf ^ 1, hg * PPG + q);
+                }
+            }
         }
+        stamp(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(1);
         __syncthreads();
+        stamp(2);
     };
+    stamp(-1);
     for (int ib = ib0; ib < ib1 - 1; ++ib) k_block(ib, std::true_type{});
     k_block(ib1 - 1, std::false_type{});
     if (tile + tstride < ntile) stage((p.wg_begin + tile + tstride) * DW_TC, ib0, 0);   // both stages are dead: the next tile's first K block lands under the epilogue
@@ -1308,6 +1347,8 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
         } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
     }
+    stamp(3);
+    if (STAMP && p.stamps && lane == 0) { for (int q = 0; q < 4; ++q) p.stamps[((int64_t)blockIdx.x * DW_WAVES + wave) * 4 + q] = st_sum[q]; }
     if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
 }
 
@@ -1914,7 +1955,14 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
     constexpr int NMAT = BAYES ? 2 : 1;
     constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    if (range_guard_skip(p.rflag, p.rmode, false)) return;
+    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) {
+        // an operand of this step left the fp16 window (raised where the operands are split): the step runs in exact f32 - the f32 kernel's body, same grid, same
+        // LDS size, here instead of a second launch that would exit at once in every other step (round 2: two no-op launches per step on the critical path)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(p.rflag + 1, 1);
+        OutFwdArgs q = p; q.rmode = 0;
+        out_fwd_f32_body<128, BAYES, true, true, INJ>(q, smem);
+        return;
+    }
 
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
@@ -2638,7 +2686,8 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #undef NTF_L6B
 #undef NTF_L6
 #undef NTF_L6N
-            if (guard && np == 2 && !f.probs) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
+            const bool merged_fallback = !role_split && np == 2 && f.train && dh && f.wide == 3;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
+            if (guard && np == 2 && !f.probs && !merged_fallback) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
                 OutFwdArgs af = a; af.rmode = 2;
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
             }
@@ -2705,7 +2754,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.produce = (f.produce && f.adam && f.bayes && f.H == 128) ? 1 : 0;
     a.nx_eps = f.nx_eps; a.nx_wp = f.nx_wp; a.nx_pl_wp = f.nx_pl_wp; a.nx_pl_mu = f.nx_pl_mu; a.nx_pscale = f.nx_pscale; a.nx_klw = f.nx_klw; a.nx_kl = f.nx_kl; a.nx_rflag = f.nx_rflag;
     { static const int abl = getenv("NTF_DW_ABLATE") ? atoi(getenv("NTF_DW_ABLATE")) : 0; a.ablate = abl; }
-    a.ntile = 0; a.stagger = 0;
+    a.ntile = 0; a.stagger = 0; a.stamps = nullptr;
     const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
     a.sT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
     a.ksplit = 1; a.part = nullptr; a.slab = 0;
@@ -2736,9 +2785,26 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
 #define NTF_DWP(BY, AD) do { auto kf = k_out_dw_p2<BY, AD>;                                                                    \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         hipLaunchKernelGGL(kf, dim3(pgrid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
-        if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
+        static const int dw_stamp = getenv("NTF_DW_STAMP") ? atoi(getenv("NTF_DW_STAMP")) : 0;
+        if (dw_stamp && f.bayes && f.adam) {
+            static unsigned long long* d_st = nullptr; static int n_launch = 0;
+            if (!d_st) hipMalloc(&d_st, (size_t)grid * DW_WAVES * 4 * 8);
+            a.stamps = d_st;
+            auto kf = k_out_dw_p2<true, true, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kf, dim3(pgrid), dim3(64 * DW_WAVES), lds, st, a);
+            if (++n_launch == 30) {
+                std::vector<unsigned long long> hst((size_t)grid * DW_WAVES * 4);
+                hipStreamSynchronize(st); hipMemcpy(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost);
+                double sum[4] = {0}; for (size_t w = 0; w < (size_t)grid * DW_WAVES; ++w) for (int q = 0; q < 4; ++q) sum[q] += (double)hst[w * 4 + q];
+                const double nw = (double)grid * DW_WAVES, nib = g.Bpad / 32;
+                fprintf(stderr, "[dw stamps] cycles per wave: K-block body %.0f | DMA wait %.0f | barrier %.0f  (x %g K blocks) | epilogue %.0f per tile\n",
+                        sum[0] / nw / nib, sum[1] / nw / nib, sum[2] / nw / nib, nib, sum[3] / nw);
+            }
+        }
+        else if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
 #undef NTF_DWP
-        if (!guard) return;
+        if (!guard || (pgrid == grid && !(dw_stamp && f.bayes && f.adam))) return;   // one tile per workgroup: the kernel runs the f32 body itself when the flag is raised
         a.rmode = 2;
         goto exact_f32;
     }

@@ -66,6 +66,40 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
     uint32_t* SW = reinterpret_cast<uint32_t*>(Hs + 32 * HS_LD);   // [32][4] s_in words of the output layer
     const int i0 = (int)blockIdx.x * 32;
 
+    // ---- 2a (d <= 128: before the gather, whose dependent load chain rows -> indptr -> indices -> table it then overlaps): this lane's weights - hidden unit j, the k half -
+    //         with sigma0 * eps0 made in registers (Philox + Box-Muller, k_flipout_perturb's arithmetic) and the layer's KL terms
+    const int j = wave * 32 + il;
+    const int kb = half * (D / 2);
+    constexpr bool PRE = D <= 128;
+    constexpr int NQ = PRE ? D / 8 : 1;
+    float mvA[NQ][4], wvA[NQ][4];
+    float klw = 0.f;
+    const float* mrow = p.mu0 + (int64_t)j * D + kb;
+    const float* rrow = BAYES ? p.rho0 + (int64_t)j * D + kb : nullptr;
+    auto weights_of = [&](int t4, float (&mv)[4], float (&wv)[4]) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mrow + 4 * t4);
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+        wv[0] = wv[1] = wv[2] = wv[3] = 0.f;
+        if (BAYES) {
+            const float4 r4 = *reinterpret_cast<const float4*>(rrow + 4 * t4);
+            const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
+            float z[4];
+            const int64_t e0 = (int64_t)j * D + kb + 4 * t4;
+            normal4(p.eps_w0, e0 >> 2, e0, INT64_MAX, z);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ls;
+                const float sigma = softplus_rho_fast(rv[e], ls);
+                wv[e] = sigma * z[e];
+                klw += -ls + 0.5f * (sigma * sigma + mv[e] * mv[e]) - 0.5f;
+            }
+        }
+    };
+    if (PRE) {
+#pragma unroll
+        for (int t4 = 0; t4 < NQ; ++t4) weights_of(t4, mvA[t4], wvA[t4]);
+    }
+
     // ---- 1. the 32 input rows -> Xs, act[0]
     {
         constexpr int G = D / 4, TPW = 64 / G;                              // G lanes per row, float4 each (D in {64, 128, 256})
@@ -109,36 +143,13 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
     __syncthreads();
 
     // ---- 2. z = x mu0^T (+ (x * s_in) (sigma0 * eps0)^T): wave = 32 hidden units, lane = (hidden unit j, k half)
-    const int j = wave * 32 + il;
-    const int kb = half * (D / 2);
     f32x16 acc1, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
-    float klw = 0.f;
     uint32_t sw0 = 0u;                           // s_in word of row i0 + il for the 32 columns being multiplied (kb is a multiple of 32)
     const float* xrow = Xs + il * XLD + kb;
-    const float* mrow = p.mu0 + (int64_t)j * D + kb;
-    const float* rrow = BAYES ? p.rho0 + (int64_t)j * D + kb : nullptr;
-#pragma unroll 4
-    for (int t4 = 0; t4 < D / 8; ++t4) {          // (unrolled by 4: the weight loads of four steps are issued together)
+    auto mma4 = [&](int t4, const float (&mv)[4], const float (&wv)[4]) {
         if (BAYES && (t4 & 7) == 0) sw0 = sign_word(p.si0.k0, p.si0.k1, (uint32_t)(i0 + il), (uint32_t)((kb >> 5) + (t4 >> 3)));
-        const float4 m4 = *reinterpret_cast<const float4*>(mrow + 4 * t4);
-        const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
-        float wv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (BAYES) {
-            const float4 r4 = *reinterpret_cast<const float4*>(rrow + 4 * t4);
-            const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
-            float z[4];
-            const int64_t e0 = (int64_t)j * D + kb + 4 * t4;
-            normal4(p.eps_w0, e0 >> 2, e0, INT64_MAX, z);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float ls;
-                const float sigma = softplus_rho_fast(rv[e], ls);
-                wv[e] = sigma * z[e];
-                klw += -ls + 0.5f * (sigma * sigma + mv[e] * mv[e]) - 0.5f;
-            }
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = 4 * t4 + e;                          // column kb + k of row i0 + il
@@ -148,6 +159,17 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
                 const uint32_t bit = (sw0 >> (k & 31)) & 1u;
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(__float_as_uint(a) ^ (bit << 31)), wv[e], acc2, 0, 0, 0);
             }
+        }
+    };
+    if (PRE) {
+#pragma unroll
+        for (int t4 = 0; t4 < NQ; ++t4) mma4(t4, mvA[t4], wvA[t4]);
+    } else {
+#pragma unroll 4
+        for (int t4 = 0; t4 < D / 8; ++t4) {          // d = 256: the weights do not fit in registers beside the gather (unrolled by 4: four steps' loads go together)
+            float mv[4], wv[4];
+            weights_of(t4, mv, wv);
+            mma4(t4, mv, wv);
         }
     }
 

@@ -18,7 +18,7 @@ INPUT_DENSE, INPUT_MEANPOOL, INPUT_MULTIHOT = 0, 1, 2
 NSD = {None: 0, "": 0, "None": 0, "uniform": 1, "unigram": 2, "unigram_b": 3}
 P_WEIGHT, P_BIAS, P_RHO_WEIGHT, P_RHO_BIAS = 0, 1, 2, 3
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libopentf_amd.so")
+_LIB_PATH = os.environ.get("NTF_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libopentf_amd.so")   # (NTF_LIB_PATH: A/B builds of the same ABI)
 
 
 class NtfError(RuntimeError):
