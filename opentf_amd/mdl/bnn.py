@@ -2,7 +2,7 @@
 Linear replaced by bayesian-torch's LinearFlipout (prior N(0,1), posterior init mu~N(0,0.1), rho~N(-3,0.1)),
 `KL/B` added to the loss (src/mdl/fnn.py:136,149) and `nmc` stochastic forwards averaged at test time
 (src/mdl/fnn.py:202-211).  bayesian-torch is not needed: its arithmetic is restated in the HIP kernels
-(parity against the library itself is unpinned)."""
+(its restatement is pinned distributionally on the 40 bayesian-torch checkpoints / .pred files the reference's authors committed (tests/test_bnn_committed.py, g12))."""
 from __future__ import annotations
 
 from collections import OrderedDict
