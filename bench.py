@@ -242,7 +242,7 @@ def main():
             reps_max = 5 if reps_allowed else 1
             order = rng.integers(0, data["N"], (warmup + steps * reps_max) * gB).astype(np.int64)   # the loader's shuffled row order
             if warmup: dp.train_epoch(order[: warmup * gB], gB)
-            e.kernel_times(enable=2)    # HIP events around the two output-layer kernels only inside the timed region (the roofline's kernels)
+            e.kernel_times(enable=0 if os.environ.get("NTF_BENCH_NO_EVENTS") else 2)    # HIP events around the two output-layer kernels only inside the timed region (the roofline's kernels)
             regions, mean_loss, off = [], None, warmup * gB
             while len(regions) < reps_max:
                 e.synchronize(); torch.cuda.synchronize()

@@ -134,10 +134,16 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 //   lds_dst = wave-uniform LDS byte address; lane l lands at lds_dst + l*size; gsrc = this lane's global source.
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p; }
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
     lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);   // wave-uniform by construction; hipcc cannot always prove it (a loop-carried stage index)
+#ifdef NTF_GLDS_KEEP_M0
+    uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
+    // M0 is DECLARED clobbered instead of saved and restored around every piece (two scalar instructions less per piece: 18 of a dW K block's ~300 issue slots):
+    // hipcc then keeps nothing in M0 across the statement (it warns that M0 is a reserved register; none of these kernels uses it otherwise)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+#endif
 }
 __device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
