@@ -355,6 +355,21 @@ def main():
         extra_configs = {"dblp_full": {"workload": workload_label(a, dsf, bayesian, False), "steps": 10, "ms_per_step": r["dt"] / 10 * 1e3, "value": 10 * a.batch / r["dt"], "unit": "teams/s",
                                        "mean_loss": r["mean_loss"]}}
         a.dataset = saved[0]
+        # the team-vector producer in front of this path when the input is doc2vec (src/mdl/emb/d2v.py:69-84): one PV-DM pass (d = 128, window 5, 5 negatives, gensim's
+        # defaults as the reference leaves them) over THIS dataset's teams as documents.  The reference's own log of that stage on dblp mt10.ts2
+        # (output/dblp/dblp.v12.json.mt10.ts2/prep.d2v.skill.log: gensim 4.3.3, 224 workers): 276 s per pass over 19 073 021 words, 100 passes = 7.7 h.
+        from opentf_amd.mdl.emb import d2v as d2v_host
+        d_ptr, d_idx = ds["skill"][0], ds["skill"][1]
+        keys, count, si, cum, wi = d2v_host.build_vocab(d_idx)
+        wv0, dv0 = d2v_host.initial_vectors(len(d_ptr) - 1, len(keys), a.d, 0)
+        net = libntf.Doc2Vec(d_ptr, wi, si, cum, wv0, dv0, seed=0, device=local)
+        prog = d2v_host.job_progress(d_ptr)
+        net.train_epoch(1, 5, 0.025, 0.001, 0, progress=prog)
+        ms = [net.train_epoch(1, 5, 0.025, 0.001, 1 + k, progress=prog, want_ms=True)[1] for k in range(3)]
+        net.close()
+        extra_configs["d2v_epoch"] = {"workload": f"doc2vec PV-DM pass (src/mdl/emb/d2v.py:76-84) over {len(d_ptr) - 1} teams as documents of their skills: {len(d_idx)} words, {len(keys)} distinct, d={a.d}, window 5, negative 5",
+                                      "ms_per_pass": float(np.median(ms)), "value": len(d_idx) / (float(np.median(ms)) * 1e-3), "unit": "words/s",
+                                      "reference_log": {"file": "output/dblp/dblp.v12.json.mt10.ts2/prep.d2v.skill.log", "s_per_pass": 276.4, "raw_words_per_s": 19073021 / 276.4, "workers": 224, "words": 19073021}}
 
     if rank != 0:
         if world > 1: dist.destroy_process_group()

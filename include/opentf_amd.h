@@ -250,6 +250,28 @@ int  ntf_n2v_train_batch(ntf_n2v* h, const int64_t* batch, int32_t B, int32_t wa
 int  ntf_n2v_get(ntf_n2v* h, int what /* 0 embedding.weight, 1 gradient */, float* host /* [num_nodes, d] */);
 int  ntf_n2v_edge_bce(ntf_n2v* h, const int64_t* src, const int64_t* dst, int64_t n, float* mean_bce);
 
+/* ---- doc2vec team-vector producer on the device                          src/mdl/emb/d2v.py:69-84 (gensim.models.Doc2Vec: build_vocab + train)
+ * gensim 4.3.3's PV-DM (dm = 1, mean of doc vector + shrunk-window word vectors) and PV-DBOW with dbow_words = 1 (dm = 0), negative sampling from the
+ * count^0.75 table, frequent-word subsampling, 1000-bin sigmoid table, |f| >= 6 skipped - as the reference's call leaves gensim's defaults (oracle/d2v_oracle.py
+ * restates the algorithm and lists what is pinned).  The host prepares what gensim's build_vocab prepares: documents as CSR over VOCABULARY indices
+ * (doc_ptr [n_docs+1] int64, words int32), sample_int [n_vocab] (keep a word iff sample_int >= a uniform uint32), cum_table [n_vocab] (uint32, last = 2^31 - 1),
+ * and the initial vectors (numpy default_rng(seed) / (seed + 7919), so that a seed gives gensim's initial table); syn1neg starts at zero.
+ * ntf_d2v_train_epoch = one pass over the documents (gensim train(epochs=1)), taken in `order` (nullable: 0..n_docs-1): the document of rank r trains at
+ * alpha_start - (alpha_start - alpha_end) * progress[r] (nullable: r / n_docs) - gensim fixes alpha per job of <= 10 000 words, the host passes the fraction of
+ * the pass at which the document's job was cut.  Random draws are Philox words keyed by (seed, epoch) and counted by (document, position, unit, slot).  serial != 0: one wave walks
+ * all documents in order - the oracle's sequential pass (parity tests); otherwise one wave per document, Hogwild through f32 atomic adds as gensim's worker threads
+ * are through plain stores.  mean_loss (nullable): mean -log sigmoid(+-f) over the pairs trained; device_ms (nullable): device time of the pass.
+ * ntf_d2v_get / ntf_d2v_set: what = 0 doc vectors [n_docs, d] (= Doc2Vec.dv.vectors, row i = team i), 1 word vectors [n_vocab, d], 2 syn1neg [n_vocab, d]. */
+typedef struct ntf_d2v ntf_d2v;
+int  ntf_d2v_create(int device, int64_t n_docs, int64_t n_vocab, int32_t d, const int64_t* doc_ptr, const int32_t* words, const uint32_t* sample_int,
+                    const uint32_t* cum_table, const float* init_wv, const float* init_dv, uint64_t seed, ntf_d2v** out);
+void ntf_d2v_destroy(ntf_d2v* h);
+const char* ntf_d2v_last_error(const ntf_d2v* h);
+int  ntf_d2v_train_epoch(ntf_d2v* h, int32_t dm, int32_t window, int32_t negative, double alpha_start, double alpha_end, uint64_t epoch, int32_t serial,
+                         const int64_t* order, const double* progress, double* mean_loss, double* device_ms);
+int  ntf_d2v_get(ntf_d2v* h, int what, float* host);
+int  ntf_d2v_set(ntf_d2v* h, int what, const float* host);
+
 /* device generators behind Flipout's eps / signs (dev_out = device pointers), for statistical tests */
 int ntf_k_fill_normal(void* stream, uint64_t seed, uint64_t step, int layer, int64_t n, float* dev_out);
 int ntf_k_fill_sign(void* stream, uint64_t seed, uint64_t step, int layer, int rows, int cols, float* dev_out);

@@ -2573,7 +2573,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3y(OutFwd6Args pp) {
         const int to_cur = buf ? STAGE : -STAGE;              // from the previous tile's stage to this tile's
         const uint2 w2 = sign_words(t);
         char* sb = smem + buf * STAGE;
-        char* sbp = smem + (buf ^ 1) * STAGE;                 // stage of tile t - 1 (tile t_beg again in the first iteration)
         const int c0 = t * BNT;
         const int tn = min(t + 1, t_end - 1);
         if (c0 + BNT > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias

@@ -98,6 +98,12 @@ SYMBOLS = {
     "ntf_n2v_train_batch": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _I64, _P, _I64, _I32, _P]),
     "ntf_n2v_get": (C.c_int, [_P, C.c_int, _P]),
     "ntf_n2v_edge_bce": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "ntf_d2v_create": (C.c_int, [C.c_int, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _U64, C.POINTER(_P)]),
+    "ntf_d2v_destroy": (None, [_P]),
+    "ntf_d2v_last_error": (C.c_char_p, [_P]),
+    "ntf_d2v_train_epoch": (C.c_int, [_P, _I32, _I32, _I32, C.c_double, C.c_double, _U64, _I32, _P, _P, _P, _P]),
+    "ntf_d2v_get": (C.c_int, [_P, C.c_int, _P]),
+    "ntf_d2v_set": (C.c_int, [_P, C.c_int, _P]),
     "ntf_k_gemm_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
     "ntf_k_fill_normal": (C.c_int, [_P, _U64, _U64, C.c_int, _I64, _P]),
     "ntf_k_fill_sign": (C.c_int, [_P, _U64, _U64, C.c_int, C.c_int, C.c_int, _P]),
@@ -552,3 +558,56 @@ class Node2Vec:
     def edge_bce(self, src, dst):
         s = np.ascontiguousarray(src, dtype=np.int64); t = np.ascontiguousarray(dst, dtype=np.int64); out = C.c_float()
         self._ck(lib().ntf_n2v_edge_bce(self._h, _ptr(s), _ptr(t), len(s), C.byref(out))); return out.value
+
+
+class Doc2Vec:
+    """gensim.models.Doc2Vec's tables (doc vectors, word vectors, syn1neg) resident on one MI355X and its negative-sampling trainer (include/opentf_amd.h ntf_d2v_*).
+    The documents come as CSR over vocabulary indices together with what build_vocab prepares (sample_int, cum_table) and the initial vectors."""
+
+    DV, WV, SYN1NEG = 0, 1, 2
+
+    def __init__(self, doc_ptr, words, sample_int, cum_table, init_wv, init_dv, seed=0, device=0):
+        self.doc_ptr = np.ascontiguousarray(doc_ptr, dtype=np.int64); self.words = np.ascontiguousarray(words, dtype=np.int32)
+        si = np.ascontiguousarray(sample_int, dtype=np.uint32); ct = np.ascontiguousarray(cum_table, dtype=np.uint32)
+        wv, dv = _f32(init_wv), _f32(init_dv)
+        self.n_docs, self.d = dv.shape
+        self.n_vocab = wv.shape[0]
+        if len(self.doc_ptr) != self.n_docs + 1 or len(si) != self.n_vocab or len(ct) != self.n_vocab or wv.shape[1] != self.d:
+            raise NtfError("doc_ptr / sample_int / cum_table / initial vectors do not fit together")
+        self._h = C.c_void_p()
+        rc = lib().ntf_d2v_create(int(device), self.n_docs, self.n_vocab, self.d, _ptr(self.doc_ptr), _ptr(self.words), _ptr(si), _ptr(ct), _ptr(wv), _ptr(dv),
+                                  int(seed) & (2**64 - 1), C.byref(self._h))
+        if rc != 0:
+            msg = lib().ntf_d2v_last_error(None); self._h = None
+            raise NtfError(f"ntf_d2v_create failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise NtfError(f"libopentf_amd d2v error {rc}: {lib().ntf_d2v_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ntf_d2v_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+    def train_epoch(self, dm, window, alpha_start, alpha_end, epoch, negative=5, serial=False, order=None, progress=None, want_loss=False, want_ms=False):
+        """one pass over the documents (gensim train(epochs=1)); returns (mean loss | None, device ms | None)"""
+        o = None if order is None else np.ascontiguousarray(order, dtype=np.int64)
+        pr = None if progress is None else np.ascontiguousarray(progress, dtype=np.float64)
+        loss, ms = C.c_double(), C.c_double()
+        self._ck(lib().ntf_d2v_train_epoch(self._h, int(dm), int(window), int(negative), float(alpha_start), float(alpha_end), int(epoch), int(bool(serial)),
+                                           _ptr(o) if o is not None else None, _ptr(pr) if pr is not None else None, C.byref(loss) if want_loss else None,
+                                           C.byref(ms) if want_ms else None))
+        return (loss.value if want_loss else None), (ms.value if want_ms else None)
+
+    def vectors(self, what=0):
+        out = np.empty((self.n_docs if what == 0 else self.n_vocab, self.d), dtype=np.float32)
+        self._ck(lib().ntf_d2v_get(self._h, int(what), _ptr(out))); return out
+
+    def set_vectors(self, what, values):
+        v = _f32(values)
+        assert v.shape == ((self.n_docs if what == 0 else self.n_vocab), self.d)
+        self._ck(lib().ntf_d2v_set(self._h, int(what), _ptr(v)))
