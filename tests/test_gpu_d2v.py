@@ -131,3 +131,40 @@ def test_epoch_of_the_dblp_corpus_shape():
     print(f"\nd2v epoch: {n} docs, {len(idx)} words, {ms:.1f} ms on the device = {words_per_s / 1e6:.1f} M words/s (reference log: 0.069 M raw words/s), loss {loss:.4f}")
     assert np.isfinite(net.vectors(0)).all() and ms < 2000
     net.close()
+
+
+def test_main_py_sequence_d2v_then_bnn(tmp_path):
+    """src/main.py:100-181 as the unmodified CLI runs the reference's committed `bnn_emb` example (output/dblp/toy.dblp.v12.json/splits.f3.r0.85/
+    d2v.d128.e100.w5.dm1.skill/bnn.b1000...): t2v.learn -> skill_vecs = t2v.get_dense_vecs(teamsvecs) -> teamsvecs['skill'] = skill_vecs ->
+    Bnn(t2v.output, ...).learn / .test.  The Bnn plugin must take the doc vectors as its dense input and write under the d2v directory."""
+    import random
+    import torch
+    from opentf_amd import libntf
+    from opentf_amd.mdl.bnn import Bnn
+    from test_gpu_n2v import Cfg, _toy
+    toy, teamsvecs, splits, n, S, M = _toy()
+    random.seed(0)
+    t2v = P.D2v(str(tmp_path), "cuda:0", 0, Cfg(embtype="skill", dm=1, w=5, d=128, e=20, lr=0.001, spe=10), "d2v")
+    t2v.learn(teamsvecs, splits)                                           # main.py:122
+    skill_vecs = t2v.get_dense_vecs(teamsvecs, vectype="skill")            # main.py:148
+    assert skill_vecs.shape[0] == teamsvecs["skill"].shape[0]              # main.py:149
+    teamsvecs["original_skill"] = teamsvecs["skill"]                       # main.py:152
+    teamsvecs["skill"] = skill_vecs                                        # main.py:153
+    mcfg = Cfg(b=8, e=2, ns=5, lr=0.001, es=5, h=[128], spe=0, l="bce", tpw=10, tnw=1, nsd="unigram_b", nmc=3)
+    seen = {}
+    orig = libntf.Engine.__init__
+    def spy(self, dims, *a, **k):
+        seen["input_mode"] = k.get("input_mode"); seen["dims"] = list(dims)
+        return orig(self, dims, *a, **k)
+    libntf.Engine.__init__ = spy
+    try:
+        m = Bnn(t2v.output, "cuda:0", 0, mcfg); m.learn(teamsvecs, splits, None)          # main.py:158,172,177 (output_ = t2v.output)
+    finally:
+        libntf.Engine.__init__ = orig
+    assert seen["input_mode"] == libntf.INPUT_DENSE and seen["dims"] == [128, 128, M]
+    assert m.output.startswith(f"{tmp_path}/d2v.d128.e20.w5.dm1.skill/bnn.b8.e2.ns5.lr0.001.es5.h[128]")
+    sd = torch.load(f"{m.output}/f0.pt", weights_only=False)["model_state_dict"]
+    assert list(sd)[:4] == ["layers.0.mu_weight", "layers.0.rho_weight", "layers.0.mu_bias", "layers.0.rho_bias"] and tuple(sd["layers.0.mu_weight"].shape) == (128, 128)
+    m.test(teamsvecs, splits, Cfg(on_train=False, per_epoch=False, topK=None))            # main.py:181
+    pred = torch.load(f"{m.output}/f0.test.pred", weights_only=False)
+    assert tuple(pred["y_pred"].shape) == (len(splits["test"]), M)
