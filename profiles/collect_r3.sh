@@ -17,13 +17,24 @@ python3 $B --no-gather-bench --steps 30 --warmup 5 --input multihot --nsd unigra
 python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset uspt --d 256 > $O/bench_n1_config4_uspt_d256.json 2>> $O/bench.err
 python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset gith > $O/bench_n1_config5_gith.json 2>> $O/bench.err
 # A/B of this round's changes, same box (each env switch restores the round-2 behaviour of one piece)
-for v in "NTF_FWD_KERNEL=1" "NTF_PREFETCH=0" "NTF_HEAD=0" "NTF_SIDE_BWD=0"; do
+for v in "NTF_FWD_KERNEL=1" "NTF_FWD_KERNEL=4" "NTF_PREFETCH=0" "NTF_HEAD=0" "NTF_SIDE_BWD=0"; do
   env $v python3 $B --no-gather-bench --steps 40 --warmup 10 > $O/ab_$v.json 2>> $O/bench.err
 done
 # expert-sharded multi-GPU path: what ONE rank of G runs, emulated on this GPU
 for G in 2 4 8; do python3 $R/bench.py --steps 20 --warmup 4 --ep-emulate $G --no-extra-configs > $O/bench_ep_rank_of_$G.json 2>> $O/bench.err; done
 # the forward kernel's phases (in-kernel s_memtime stamps, diagnostic build of the same kernel)
 NTF_FWD_ABL=9 python3 $B --no-gather-bench --steps 40 --warmup 10 > /dev/null 2> $O/fwd_stamps.err; grep "fwd stamps" $O/fwd_stamps.err > $O/fwd_stamps.txt
+# package power and shader clock while the step runs (rocm-smi every 2 s beside a 20 000-step run), and the forward kernel's own clock (clock64 against wall_clock64)
+python3 $B --no-gather-bench --steps 20000 --warmup 10 > $O/bench_long.json 2>> $O/bench.err &
+BP=$!
+rocm-smi --showmaxpower 2>/dev/null | grep "GPU\[" > $O/power_clocks.txt
+for n in $(seq 1 40); do
+  if ! kill -0 $BP 2>/dev/null; then break; fi
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | sed 's/.*: //' | tr '\n' ' ' >> $O/power_clocks.txt; echo >> $O/power_clocks.txt
+  sleep 2
+done
+wait $BP
+NTF_FWD_REPEAT=10 NTF_FWD_ABL=9 python3 $B --no-gather-bench --steps 40 --warmup 10 > /dev/null 2> $O/fwd_stamps_repeat10.err; grep "fwd stamps" $O/fwd_stamps_repeat10.err > $O/fwd_stamps_repeat10.txt
 # kernel trace (every dispatch: the step timeline) + stats of the default run
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --no-gather-bench --steps 20 --warmup 3 > $O/stats.log 2>&1
 # PMC passes (each on its own, no tracing)

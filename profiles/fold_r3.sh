@@ -12,3 +12,6 @@ mkdir -p profiles/r3_ep
 for f in $O/bench_ep_*.json; do [ -s $f ] && tail -1 $f > profiles/r3_ep/$(basename $f); done
 cp $O/fwd_stamps.txt profiles/r3_fwd_phase_stamps.txt
 ls -la profiles/r3_*
+cat $O/fwd_stamps_repeat10.txt >> profiles/r3_fwd_phase_stamps.txt 2>/dev/null || true
+[ -s $O/power_clocks.txt ] && cp $O/power_clocks.txt profiles/r3_power_clocks_samples.txt
+[ -s $O/bench_long.json ] && tail -1 $O/bench_long.json > profiles/r3_bench_n1_20000_steps.json
