@@ -179,7 +179,8 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
                  3: "fp16x3: operands * 2^k split into 2 fp16 values (22 bits), 3 fp16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 3"}[nprod]
         out.append({"bound": "mfma", "kernel": fam, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                     "traffic_source": src and f"per-launch mean of the separate rocprofv3 --pmc passes committed as profiles/{src} (FETCH_SIZE doubled per MI355X_MICROARCH.md), not counted in this run",
-                    "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[fam], "arithmetic": arith, "hw_mfma_tflops": ach * nprod})
+                    "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[fam], "arithmetic": arith, "hw_mfma_tflops": ach * nprod,
+                    "power_note": "peak is the nominal 2.4 GHz figure; at the 1400 W package limit a dense fp16 MFMA stream on changing random operands sustains 1.595 GHz = 0.66 of it (profiles/r3_power_and_clocks.md, measured once, not in this run)" if nprod > 1 else None})
     return (out[0] if out else None), (out[1] if len(out) > 1 else None)
 
 
