@@ -28,6 +28,7 @@ struct ntf_d2v {
     float *dv = nullptr, *wv = nullptr, *syn1neg = nullptr;
     int64_t* order = nullptr; double* progress = nullptr;
     double* d_loss = nullptr;     // [sum of -log terms, number of terms]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t seed = 0;
     std::string err;
 };
@@ -202,6 +203,8 @@ extern "C" void ntf_d2v_destroy(ntf_d2v* h) {
     if (h->st) hipStreamSynchronize(h->st);
     for (void* p : {(void*)h->doc_ptr, (void*)h->words, (void*)h->sample_int, (void*)h->cum_table, (void*)h->dv, (void*)h->wv, (void*)h->syn1neg, (void*)h->order, (void*)h->progress, (void*)h->d_loss})
         if (p) hipFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }
@@ -266,19 +269,18 @@ extern "C" int ntf_d2v_train_epoch(ntf_d2v* h, int32_t dm, int32_t window, int32
     // parallel: enough waves to fill the chip several times over, each striding through the documents
     const int64_t want = (h->n_docs + 3) / 4;
     const dim3 grid(serial ? 1u : (unsigned)std::min<int64_t>(want, 256 * 16)), block(serial ? 64 : 256);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (device_ms) { DCHK(h, hipEventCreate(&e0)); DCHK(h, hipEventCreate(&e1)); DCHK(h, hipEventRecord(e0, h->st)); }
+    if (device_ms) { if (!h->ev0) { DCHK(h, hipEventCreate(&h->ev0)); DCHK(h, hipEventCreate(&h->ev1)); } DCHK(h, hipEventRecord(h->ev0, h->st)); }
     switch (h->d / 64) {
         case 1: hipLaunchKernelGGL(k_d2v_epoch<1>, grid, block, 0, h->st, a, dm); break;
         case 2: hipLaunchKernelGGL(k_d2v_epoch<2>, grid, block, 0, h->st, a, dm); break;
         case 3: hipLaunchKernelGGL(k_d2v_epoch<3>, grid, block, 0, h->st, a, dm); break;
         default: hipLaunchKernelGGL(k_d2v_epoch<4>, grid, block, 0, h->st, a, dm); break;
     }
-    if (device_ms) DCHK(h, hipEventRecord(e1, h->st));
+    if (device_ms) DCHK(h, hipEventRecord(h->ev1, h->st));
     hipError_t s = hipGetLastError();
     if (s != hipSuccess) DFAIL(h, NTF_EHIP, std::string("d2v kernel launch: ") + hipGetErrorString(s));
     DCHK(h, hipStreamSynchronize(h->st));
-    if (device_ms) { float ms = 0.f; DCHK(h, hipEventElapsedTime(&ms, e0, e1)); *device_ms = ms; hipEventDestroy(e0); hipEventDestroy(e1); }
+    if (device_ms) { float ms = 0.f; DCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1)); *device_ms = ms; }
     if (mean_loss) {
         double l[2] = {0, 0};
         DCHK(h, hipMemcpy(l, h->d_loss, 16, hipMemcpyDeviceToHost));

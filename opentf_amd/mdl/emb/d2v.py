@@ -212,12 +212,14 @@ class D2v(T2v):
         wv0, dv0 = initial_vectors(n_teams, len(keys), d, seed)
         hyper = {"vector_size": d, "window": w, "dm": dm, "dbow_words": 1, "negative": NEGATIVE, "sample": SAMPLE, "ns_exponent": NS_EXPONENT, "min_alpha": min_alpha,
                  "alpha": ALPHA, "epochs": e, "seed": seed, "corpus_count": n_teams, "corpus_total_words": int(len(words)), "count": count}
+        order = None
+        if spe:                                                               # d2v.py:74-75 (on every rank: the ranks' `random` streams stay in step)
+            order = list(range(n_teams))
+            random.shuffle(order)                                             # random.shuffle(self.data): the same permutation of the documents
+            order = np.asarray(order, dtype=np.int64)
         if dist_rank() == 0:                                                  # one trainer; the other ranks of a torchrun job read its file
             net = libntf.Doc2Vec(doc_ptr, words_v, sample_int, cum_table, wv0, dv0, seed=seed, device=parse_devices(self.device)[0])
-            if spe:                                                           # d2v.py:74-83
-                order = list(range(n_teams))
-                random.shuffle(order)                                         # random.shuffle(self.data): the same permutation of the documents
-                order = np.asarray(order, dtype=np.int64)
+            if spe:                                                           # d2v.py:76-83
                 progress = job_progress(doc_ptr, order)
                 alpha = ALPHA
                 for epoch in range(e):
