@@ -1,0 +1,21 @@
+"""three doc2vec passes over the bench's dblp-shaped corpus (the program profiled for profiles/r3_d2v_kernel_stats.csv)"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from opentf_amd import libntf                      # noqa: E402
+from opentf_amd.mdl.emb import d2v as P            # noqa: E402
+from opentf_amd.synth import make_dataset          # noqa: E402
+
+ds = make_dataset("dblp", d=128, seed=0)
+ptr, idx = ds["skill"][0], ds["skill"][1]
+keys, count, si, cum, wi = P.build_vocab(idx)
+wv, dv = P.initial_vectors(len(ptr) - 1, len(keys), 128, 0)
+net = libntf.Doc2Vec(ptr, wi, si, cum, wv, dv, seed=0)
+prog = P.job_progress(ptr)
+for dm in (1, 1, 1, 0):
+    loss, ms = net.train_epoch(dm, 5, 0.025, 0.001, 0, progress=prog, want_loss=True, want_ms=True)
+    print(f"dm={dm}: {len(idx)} words, {ms:.1f} ms, mean pair loss {loss:.4f}")
+net.close()
