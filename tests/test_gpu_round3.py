@@ -185,6 +185,12 @@ def test_config4_full_size_step_against_the_oracle():
     _full_size_oracle_step(D=256, H=128, M=394_187, B=1000, S=6000, mean_s=6.29, mean_m=2.51, seed=12)
 
 
+def test_config5_full_expert_count_step_against_the_oracle():
+    """BASELINE config 5's expert axis at its size: gith unfiltered (M = 1 369 895, 1.37 skills / 5.53 members per team, S = 486) - with B = 200 rows so that the
+    oracle's dense [B, M] tensors stay at 1.1 GB each"""
+    _full_size_oracle_step(D=128, H=128, M=1_369_895, B=200, S=486, mean_s=1.37, mean_m=5.53, seed=14)
+
+
 def test_config3_full_size_step_against_the_oracle():
     """BASELINE config 3 at its size: dblp mt10.ts2 with the MULTI-HOT input (D = S = 90 671: the first layer is a CSR gather-sum of W0 columns), negatives drawn by
     the reference's unigram rule"""
