@@ -228,3 +228,41 @@ def test_sixteen_row_wave_forward_equals_the_default_kernel(bayesian, M, B, monk
         # leaky_relu' kink flips (|z| within rounding of 0 landing on the other side in another summation order) move one expert's gradient row each
         assert int((d > 2e-5 * scale).sum()) <= 64 * 128, (k, int((d > 2e-5 * scale).sum()))
         assert float(d.max()) <= 2e-2 * scale, (k, float(d.max()), scale)
+
+
+# ------------------------------------------------------------------------------------------ inference (Fnn.test, src/mdl/fnn.py:172-219) at BASELINE config 2's expert count
+@pytest.mark.parametrize("bayesian", [True, False])
+def test_config2_full_size_inference_against_the_oracle(bayesian):
+    """the test() path at M = 233 629 (256 teams per call so that the oracle's [nmc, B, M] tensor stays at 0.7 GB): MC-mean probabilities of the fused PROBS-mode kernel,
+    predictive entropy and mutual information against oracle/ntf_oracle.py with every MC pass's noise injected; the device top-K (K = 100) against a stable sort of
+    the engine's own probabilities for the deterministic model"""
+    import torch
+    from conftest import draw_noise
+    from oracle import ntf_oracle as O
+    from opentf_amd import libntf
+    D, H, M, B, S, nmc = 128, 128, 233_629, 256, 4000, 3
+    torch.manual_seed(21)
+    rng = np.random.default_rng(21)
+    sd = O.bnn_init(D, [H], M) if bayesian else O.fnn_init(D, [H], M)
+    if not bayesian: nmc = 1
+    table = rng.standard_normal((S, D)).astype(np.float32)
+    nnz = 1 + rng.poisson(7.57, B)
+    s_ip = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int64)
+    s_ix = np.concatenate([np.sort(rng.choice(S, k, replace=False)) for k in nnz]).astype(np.int32)
+    X = torch.from_numpy(O.gather_meanpool_fast(s_ip, s_ix, table))
+    m_ip = np.arange(B + 1, dtype=np.int64); m_ix = rng.integers(0, M, B).astype(np.int32)
+    e = libntf.Engine([D, H, M], bayesian=bayesian, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", tpw=10.0, tnw=1.0, lr=1e-3)
+    e.set_skill_table(table); e.set_skill_csr((s_ip, s_ix)); e.set_member((m_ip, m_ix)); e.load_state_dict(sd)
+    noises = [draw_noise(sd, B) for _ in range(nmc)] if bayesian else None
+    injs = [{"eps_w": [n["eps_w"] for n in nz], "eps_b": [n["eps_b"] for n in nz], "s_in": [n["s_in"] for n in nz], "s_out": [n["s_out"] for n in nz]} for nz in noises] if bayesian else None
+    mc = O.predict(sd, X, nmc, noises).numpy()
+    mc = mc if mc.ndim == 3 else mc[None]
+    probs, pu, mu = e.forward(np.arange(B), nmc=nmc, injects=injs, uncertainty=True)
+    np.testing.assert_allclose(probs, mc.mean(0), rtol=1e-5, atol=2e-7)
+    np.testing.assert_allclose(pu, O.predictive_entropy(mc), rtol=1e-4, atol=1e-4)
+    if bayesian: np.testing.assert_allclose(mu, O.mutual_information(mc), rtol=1e-3, atol=2e-4)
+    else:
+        vals, idx = e.forward_topk(np.arange(B), 100, nmc=1)
+        order = np.argsort(-probs, axis=1, kind="stable")[:, :100]
+        assert np.array_equal(idx, order) and np.array_equal(vals, np.take_along_axis(probs, order, axis=1))
+    e.close()
