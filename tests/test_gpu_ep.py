@@ -272,3 +272,27 @@ def test_inference_on_expert_shards_gives_the_whole_models_columns():
     p, z = np.concatenate(got_p, axis=1), np.concatenate(got_z, axis=1)
     assert p.shape == p_full.shape
     assert np.array_equal(z, z_full) and np.array_equal(p, p_full)
+
+
+def test_expert_shards_at_config2_full_size_equal_the_whole_model():
+    """BASELINE config 2's own shapes ([128, 128, 233 629], B = 1000) cut into 8 expert shards - what `--parallel ep` runs on an 8-GPU node, here on one GPU:
+    the first update of the output layer equals the whole-model engine's (whose step is checked against the oracle at this size in test_gpu_round3.py) to 1 ulp,
+    the hidden layer's to rounding of the d(hidden) sum"""
+    ds = make_dataset("dblp", d=128, seed=0, n_rows=20_000)
+    dims = [128, 128, ds["M"]]
+    assert ds["M"] == 233_629
+    order = np.random.default_rng(3).permutation(ds["N"])[:2000].astype(np.int64)
+    shards = expert_shards(ds["M"], 8)
+    full = _mk(ds, dims, True, 1000, "uniform")
+    eng = [_mk(ds, dims, True, 1000, "uniform", shard=s, world=8) for s in shards]
+    l_full, l_ep = _full_epoch(full, order[:1000], 1000), _ep_epoch(eng, order[:1000], 1000)
+    assert abs(l_ep - l_full) <= 2e-6 * abs(l_full)
+    a, b = _gathered(eng), full.state_dict()
+    for k in b:
+        # a shard's 114 expert tiles do not fill the chip: its dW kernel splits the K (batch) range over two workgroups per tile - another summation order (1 ulp in 2 % of mu);
+        # Adam's first step is lr * g / (|g| + eps): where |g| ~ eps a rounding difference of g moves the update by up to 2 lr
+        d = np.abs(a[k] - b[k])
+        assert float((d > 1e-5 * np.abs(b[k]) + 2e-6).mean()) <= 1e-3 and float(d.max()) <= 2.1e-3, (k, float((d > 1e-5 * np.abs(b[k]) + 2e-6).mean()), float(d.max()))
+    l_full2, l_ep2 = _full_epoch(full, order[1000:], 1000), _ep_epoch(eng, order[1000:], 1000)       # a second step: on prefetched operands in every shard
+    assert abs(l_ep2 - l_full2) <= 1e-5 * abs(l_full2)
+    for e in eng + [full]: e.close()
