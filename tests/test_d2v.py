@@ -143,3 +143,25 @@ def test_keyed_vectors_surface():
     kv = P.KeyedVectors(["m3", "s10", "s2", "s1"], np.arange(16, dtype=np.float32).reshape(4, 4))
     assert np.array_equal(P.D2v.natsortvecs(kv), kv.vectors[[0, 3, 2, 1]])        # d2v.py:100-106: ['m3', 's1', 's2', 's10']
     assert kv.most_similar([kv["s2"]], topn=1)[0][0] == "s2" and len(kv) == 4
+
+
+def test_infer_vec_lands_among_the_documents_of_its_topic():
+    """D2v.infer_vec (src/mdl/emb/d2v.py:96-98: gensim's infer_vector + docvecs.most_similar) on tables trained by the oracle: a held-out document of a topic is
+    inferred next to that topic's training documents"""
+    rng = np.random.default_rng(9)
+    ptr, words, topic = _clustered(rng, n_docs=400, topics=4, per_topic=12, L=6)
+    v = D.prepare_vocab(ptr, words, sample=0)
+    wi = np.asarray([v["index_of"][int(w)] for w in words], dtype=np.int64)
+    wv, dv, s1 = D.init_vectors(len(ptr) - 1, len(v["keys"]), 64, 1)
+    sch, _ = D.alpha_schedule(8, 0.001, spe=None, alpha=0.05)
+    for ep, (a0, a1) in enumerate(sch): D.train_epoch(ptr, wi, v, wv, dv, s1, 1, 5, a0, a1, 1, ep)
+    t = P.D2v.__new__(P.D2v)
+    t.model = P.Doc2VecTables(dv, wv, s1, [f"s{int(k)}" for k in v["keys"]],
+                              {"vector_size": 64, "window": 5, "dm": 1, "negative": 5, "ns_exponent": 0.75, "min_alpha": 0.001, "alpha": 0.025, "epochs": 20, "count": v["count"]})
+    hits = 0
+    for tp in range(4):
+        doc = [f"s{12 * tp + j}" for j in (0, 3, 5, 7, 9, 11)]
+        iv, near = t.infer_vec(doc)
+        assert iv.shape == (64,) and len(near) == 10
+        hits += sum(topic[int(k)] == tp for k, _ in near)
+    assert hits >= 30, hits          # 40 neighbours in all, 25 % would be chance
