@@ -12,8 +12,8 @@ weights) are resident in HBM before the timed region; nothing is skipped inside 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel (HIP
 events recorded on the engine's stream during the timed region; the other output-layer kernel under
 `roofline_other`) and `cpu_baseline` (the oracle's reference-shaped dense step, timed on this box's host cores,
-N=1 only).  A timed region shorter than 0.3 s is repeated five times: `ms_per_step` is the median region,
-`ms_per_step_spread` = (max - min) / median.
+N=1 only).  Timed regions of --steps steps are repeated until 2 s have been timed: `ms_per_step` is the median region / steps,
+`ms_per_step_spread` = (max - min) / median over the regions.
 
 N > 1 (`--parallel auto`, the default) times, in the same processes, the three ways a node shares a step:
   headline `value`  data parallel, b = 1000 teams per GPU (weak scaling) - rows split over the GPUs, gradients reduce-scattered / parameters
@@ -104,15 +104,21 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
     for _ in range(steps):
         O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], sample_rows), member, cfg)
     dt = time.perf_counter() - t0
-    model = ""
+    model, phys = "", set()
     try:
+        pid = cid = None
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"): model = line.split(":", 1)[1].strip(); break
+            if line.startswith("model name") and not model: model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"): pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"): cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None: phys.add((pid, cid))
+                pid = cid = None
     except OSError:
         pass
-    return {"value": steps * sample_rows / dt, "unit": "teams/s", "cores": cores, "threads_used": cores, "cores_total": ncpu, "cpu_model": model, "kind": "port",
+    return {"value": steps * sample_rows / dt, "unit": "teams/s", "cores": cores, "threads_used": cores, "physical_cores": len(phys) or None, "logical_cpus": ncpu, "cpu_model": model, "kind": "port",
             "sample": f"{steps} steps of B={sample_rows} at full M={ds['M']} (oracle/ntf_oracle.py reference_shaped_step, torch {torch.__version__} CPU)",
-            "note": "cores = the torch thread count a short probe found fastest (cores_total = os.cpu_count()).  Calibration (tests/golden/calibrate_cpu_port.py, build container, 8 threads, "
+            "note": "cores = threads_used = the torch thread count a short probe found fastest; physical_cores = distinct (physical id, core id) pairs of /proc/cpuinfo, logical_cpus = os.cpu_count().  Calibration (tests/golden/calibrate_cpu_port.py, build container, 8 threads, "
                     "Fnn, M = 20 000, B = 1000): this port runs 1.62 x the rate of the imported reference Fnn.learn (1696 teams/s) - it skips the per-team NtfDataset.__getitem__ + collate "
                     "of src/mdl/ntf.py:22-24; BASELINE.md section 3"}
 
@@ -120,12 +126,12 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
 def pmc_traffic(family, a, ds):
     """HBM bytes per launch of an output-layer kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
     as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
-    names = {"f32": ["r1_c_pmc_traffic_and_sq.json"], "bf16x6": ["r1_d_pmc_traffic_and_sq.json"]}.get(a.mfma, ["r3_pmc_traffic_and_sq.json", "r2_pmc_traffic_and_sq.json"])
+    names = {"f32": ["r1_c_pmc_traffic_and_sq.json"], "bf16x6": ["r1_d_pmc_traffic_and_sq.json"]}.get(a.mfma, ["r4_pmc_traffic_and_sq.json", "r3_pmc_traffic_and_sq.json", "r2_pmc_traffic_and_sq.json"])
     path = next((os.path.join(ROOT, "profiles", n) for n in names if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if not (path and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
             and a.input == "meanpool" and not a.rows and not a.experts):
         return None, None
-    key = {"out_fused_fwd_loss_dh": "k_out_fwd", "out_fused_dw_adam": "k_out_dw_p2"}.get(family)
+    key = {"out_fused_fwd_loss_dh": "k_out_fwd", "out_fused_dw_adam": "k_out_dw_"}.get(family)
     if not key:
         return None, None
     best = None
@@ -140,6 +146,10 @@ def workload_label(a, ds, bayesian, multihot):
     return (f"{names.get(a.dataset, a.dataset)} N={ds['N']} S={ds['S']} M={ds['M']}; {a.model}{' (Flipout)' if bayesian else ''} on " +
             (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
             f"h=[{a.hidden}], b={a.batch}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3")
+
+
+class LegSkipped(RuntimeError):
+    """an extra leg of an N > 1 run that the ranks agreed not to enter (some rank could not build its engine)"""
 
 
 def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
@@ -158,10 +168,11 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
         fused_adam = fam == "out_fused_dw_adam" and a.fuse_adam == 1 and not a.no_fused and a.mfma != "f32"
         if fused_adam:
             # dW + Adam (+ the next step's operands) in one kernel: HBM-bound.  Algorithmic bytes: the packed dz read once (4 B per row and expert of
-            # the padded [256-expert tile, 128-row block] grid) + per weight 28 B read (mu, rho, sigma*eps, four Adam moments) + 24 B written (mu, rho, moments) + 12 B of
-            # next-step operands (sigma*eps' f32, the fp16 planes of it and of mu) for Flipout; 12 + 12 B for Fnn
+            # the padded [256-expert tile, 128-row block] grid) + per weight 24 B read (mu, rho, four Adam moments) + 24 B written (mu, rho, moments) + 8 B of
+            # next-step operands (the fp16 planes of sigma*eps' and of mu') for Flipout; 12 + 12 B for Fnn.  (Round 3: + 4 B read and 4 B written for an f32 copy of sigma*eps.)
             Bpad = (eB + 127) // 128 * 128; Mpad = (Mloc + 255) // 256 * 256
-            per_w = 64 if bayesian else 24
+            lean = os.environ.get("NTF_LEAN", "1") != "0"      # round 4: no f32 copy of sigma * eps is written or read (eps drawn again in the epilogue)
+            per_w = (56 if lean else 64) if bayesian else 24
             nbytes = 4.0 * Bpad * Mpad + per_w * H * Mloc
             out.append({"bound": "hbm", "kernel": fam, "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": src and f"per-launch mean of the separate rocprofv3 --pmc passes committed as profiles/{src} (FETCH_SIZE doubled per MI355X_MICROARCH.md), not counted in this run",
@@ -202,8 +213,32 @@ def main():
         if a.force_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ["NTF_DP_FORCE_ALLREDUCE"] = "1"; os.environ["NTF_EP_FORCE_EXCHANGE"] = "1"
-        if a.validate_on_one_gpu: dist.init_process_group("gloo")
-        else: dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        import datetime
+        nccl_to = datetime.timedelta(seconds=float(os.environ.get("NTF_BENCH_COLLECTIVE_TIMEOUT_S", "180")))
+        if a.validate_on_one_gpu: dist.init_process_group("gloo", timeout=nccl_to)
+        else: dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), timeout=nccl_to)
+        os.environ.setdefault("NTF_COLLECTIVE_TIMEOUT_S", "120")      # opentf_amd/dp.py, ep.py: bounded waits that name the collective they are stuck behind
+    # control plane of the extra legs (N > 1): a gloo group of its own - "did every rank get through this leg" must stay answerable when RCCL is not
+    ctl = None
+    if world > 1:
+        import datetime
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+
+    def all_ok(ok):
+        """AND over the ranks of `ok`; a control plane that cannot be reached counts as a failure"""
+        if world == 1: return bool(ok)
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32)
+        try:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+            return int(t.item()) == 0
+        except Exception:
+            return False
+
+    def inject_failure(leg, stage):
+        """NTF_BENCH_FAIL_LEG=<leg>:<build|run>[:rank] (tests): a Python exception inside that leg"""
+        spec = os.environ.get("NTF_BENCH_FAIL_LEG", "").split(":")
+        if len(spec) >= 2 and spec[0] == leg and spec[1] == stage and (len(spec) < 3 or int(spec[2]) == rank):
+            raise RuntimeError(f"injected failure in leg {leg} ({stage}) on rank {rank}")
 
     from opentf_amd import libntf
     from opentf_amd.dp import DataParallel
@@ -225,22 +260,35 @@ def main():
     n_params = int(sum(v.size for v in sd0.values()))
     rng = np.random.default_rng(7)
 
-    def run_mode(par, gB, steps, warmup, reps_allowed=True, breakdown=True, data=ds, model_dims=dims, params=sd0):
-        """build an engine for this way of sharing a step (par = dp | ep, gB = the global minibatch), warm up, time `steps` steps between barriers; returns a dict"""
+    def run_mode(par, gB, steps, warmup, reps_allowed=True, breakdown=True, data=ds, model_dims=dims, params=sd0, leg=None, agree=None):
+        """build an engine for this way of sharing a step (par = dp | ep, gB = the global minibatch), warm up, time `steps` steps between barriers; returns a dict.
+        agree (extra legs at N > 1): called with this rank's "my engine is built" - the leg goes on only when every rank's is (no rank enters a collective alone)"""
         ep = par == "ep"
         shard = expert_shards(model_dims[-1], G)[0 if a.ep_emulate else rank] if ep else None
         eB = gB if ep else -(-gB // (1 if a.ep_emulate else world))     # rows one engine steps: under ep every rank steps the whole global minibatch
         with torch.cuda.stream(stream):
-            e = libntf.Engine(model_dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=eB, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
-                              lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
-                              fuse_adam=a.fuse_adam if (world == 1 or ep) else 0, mfma=a.mfma, expert_shard=shard, ep_world=G if ep else 1)
-            if not multihot: e.set_skill_table(data["table"])
-            e.set_skill_csr(data["skill"]); e.set_member(data["member"])
-            e.load_state_dict(params)
-            if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
-                e.set_unigram(np.bincount(data["member"][1], minlength=data["M"]) / data["N"])
-            dp = ExpertParallel(e, two_phase=bool(a.ep_emulate)) if ep else DataParallel(e)
-            reps_max = 5 if reps_allowed else 1
+            e, built_err = None, None
+            try:
+                if leg: inject_failure(leg, "build")
+                e = libntf.Engine(model_dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=eB, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
+                                  lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
+                                  fuse_adam=a.fuse_adam if (world == 1 or ep) else 0, mfma=a.mfma, expert_shard=shard, ep_world=G if ep else 1)
+                if not multihot: e.set_skill_table(data["table"])
+                e.set_skill_csr(data["skill"]); e.set_member(data["member"])
+                e.load_state_dict(params)
+                if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
+                    e.set_unigram(np.bincount(data["member"][1], minlength=data["M"]) / data["N"])
+                dp = ExpertParallel(e, two_phase=bool(a.ep_emulate)) if ep else DataParallel(e)
+            except Exception as ex:
+                if agree is None: raise
+                built_err = f"{type(ex).__name__}: {ex}"
+            if agree is not None and not agree(built_err is None):
+                if e is not None: e.close()
+                raise LegSkipped(built_err or "another rank could not build its engine")
+            if leg: inject_failure(leg, "run")
+            # timed regions of `steps` steps are repeated until >= 2 s of GPU time have been timed (the driver's --steps 20 is a 30 ms region: 5 of them were 0.15 s
+            # of a 90 s process - too short for an outside sampler to see the GPU busy, VERDICT r3); ms_per_step = the median region / steps
+            reps_max = 96 if reps_allowed else 1
             order = rng.integers(0, data["N"], (warmup + steps * reps_max) * gB).astype(np.int64)   # the loader's shuffled row order
             if warmup: dp.train_epoch(order[: warmup * gB], gB)
             e.kernel_times(enable=0 if os.environ.get("NTF_BENCH_NO_EVENTS") else 2)    # HIP events around the two output-layer kernels only inside the timed region (the roofline's kernels)
@@ -255,7 +303,7 @@ def main():
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
                 if world > 1: dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank sees the same region time, hence takes the same decision below
                 regions.append(float(t.item())); off += steps * gB
-                if regions[0] >= 0.3: break                                  # a region of >= 0.3 s is timed once
+                if sum(regions) >= float(os.environ.get("NTF_BENCH_MIN_TIMED_S", "2.0")): break                                # every rank sees the same (max-reduced) times, hence takes the same decision
             times = e.kernel_times(enable=False)
             bd, k3 = None, 0
             if breakdown:   # per-family breakdown from a SEPARATE short pass (events around every family perturb the step by a few per cent)
@@ -296,7 +344,7 @@ def main():
             t = ms / calls * 1e-3
             gather = {"bound": "hbm", "achieved_algorithmic": bytes_per_team * n / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "bytes_per_team": bytes_per_team, "teams": n, "ms": ms / calls}
-            pm = next((os.path.join(ROOT, "profiles", f) for f in ("r3_pmc_gather.json", "r2_pmc_gather.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+            pm = next((os.path.join(ROOT, "profiles", f) for f in ("r4_pmc_gather.json", "r3_pmc_gather.json", "r2_pmc_gather.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
             if pm:
                 for name, v in json.load(open(pm))["kernels"].items():
                     if "k_gather_pool" in name and "hbm_bytes" in v: gather["traffic"] = v["hbm_bytes"]; gather["traffic_source"] = "profiles/" + os.path.basename(pm)
@@ -312,20 +360,94 @@ def main():
                               "exceeds the HBM peak because ~80 % of the table-row reads are served by the XCDs' L2s and the Infinity Cache (MI355X_MICROARCH.md, Indexed rows: 8.6 TB/s on-die)")
         e.close()
 
-    # ---- N > 1, --parallel auto: the other two ways of sharing a step, same processes
+    # ---- the JSON line (rank 0), assembled from the headline BEFORE anything else runs: whatever happens in a later leg, this much is printed
     extra_modes = {}
+    state = {"exact_f32": None, "extra_configs": None, "cpu_baseline": None, "printed": False}
+
+    def emit(final):
+        if rank != 0 or state["printed"]: return
+        state["printed"] = True
+        B, H, M = a.batch, a.hidden, ds["M"]
+        ep = head["ep"]; dt = head["dt"]
+        roof, roof_other = rooflines(head["times"], a, bayesian, head["eB"], H, head["Mloc"], ds, ep)
+        spread = (max(head["regions"]) - min(head["regions"])) / dt if len(head["regions"]) > 1 else None
+        devices = [torch.cuda.get_device_name(local)]
+        out = {
+            "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_spread": spread, "timed_regions": len(head["regions"]),
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"f32": "f32", "bf16x6": "f32 (bf16x6 split products, f32 accumulate)"}.get(a.mfma, "f32 (fp16x3 split products, f32 accumulate)"), "data": "synthetic",
+            "config": {"workload": workload_label(a, ds, bayesian, multihot), "global_batch": gB,
+                       "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else
+                                       f"dp{world}" + (": rows split over the GPUs, gradients reduce-scattered / parameters all-gathered over RCCL, Adam on the owned 1/N shard" if world > 1 else ""))},
+            "roofline": roof, "roofline_other": roof_other, "cpu_baseline": state["cpu_baseline"], "exact_f32_mfma": state["exact_f32"], "mean_loss": head["mean_loss"],
+            "kernel_ms_per_step": head["breakdown"], "kernel_ms_note": "separate pass of %d steps with events around every kernel family (side-stream families overlap the big kernels: the column does not sum to the step); the timed region carries events around the two output-layer kernels only" % head["k3"],
+            "rccl_ranks": world if world > 1 else 1, "rank0_device": f"cuda:{local} {devices[0]}",
+            "rccl_payload_bytes_per_step": head["rccl_payload_bytes_per_step"],
+        }
+        out.update(extra_modes)
+        if not final: out["cut_off"] = "printed by rank 0's watchdog: an extra leg did not return"
+        if state["extra_configs"]: out["extra_configs"] = state["extra_configs"]
+        if gather: out["roofline_gather"] = gather
+        if a.validate_on_one_gpu: out["validation_only"] = "all ranks on cuda:0 over gloo: code-path check, not a measurement"
+        if a.ep_emulate:
+            # one rank of G: it processed the whole global minibatch on 1/G of the experts, i.e. 1/G of the job
+            shard = expert_shards(dims[-1], G)[0]
+            out["metric"] += f" [one rank of {G} under --parallel ep, emulated on one GPU without the exchange]"
+            out["value"] = a.steps * a.batch / dt; out["n_gpus"] = 1
+            out["ep_emulation"] = {"G": G, "experts": [int(shard[0]), int(shard[1])], "rows_per_step": gB, "ms_per_step": dt / a.steps * 1e3,
+                                   "projected_teams_per_s_at_G_gpus": a.steps * gB / dt, "note": "projection = G * this rank's rate; excludes the 4*B*h[-1]-byte all-reduce per step"}
+        sys.stdout.flush(); sys.stderr.flush()
+        print(json.dumps(out), file=real_stdout, flush=True)
+
+    # ---- N > 1, --parallel auto: the other two ways of sharing a step, same processes
     if world > 1 and a.parallel == "auto" and not a.ep_emulate:
         def brief(r, scaling):
             return {"parallelism": r["par"], "scaling": scaling, "global_batch": r["gB"], "rows_per_rank": r["eB"], "ms_per_step": r["dt"] / a.steps * 1e3,
                     "value": a.steps * r["gB"] / r["dt"], "unit": "teams/s", "rccl_payload_bytes_per_step": r["rccl_payload_bytes_per_step"], "mean_loss": r["mean_loss"]}
+        # The headline is measured; nothing below may lose it.  Each extra leg: (1) every rank builds its engine, the ranks agree over the gloo control group, and the
+        # leg is skipped everywhere unless all succeeded; (2) a Python exception inside the leg becomes {"error": ...} under its key on all ranks (agreed the same way);
+        # (3) once a leg has failed while running, the collectives' state is unknown: the remaining legs are skipped; (4) a leg that does not come back at all is cut
+        # off by rank 0's watchdog, which prints the line with what there is and leaves (a fresh exit, never a re-exec).
+        broken = [None]
+
+        def guarded(name, par, gB_leg, scaling, what):
+            if broken[0]:
+                extra_modes[name] = {"error": f"skipped: an earlier leg failed while running ({broken[0]})"}
+                return
+            err, r = None, None
+            try:
+                r = run_mode(par, gB_leg, a.steps, a.warmup, breakdown=False, leg=name, agree=all_ok)
+                r["engine"].close()
+            except LegSkipped as ex:
+                extra_modes[name] = {"error": f"skipped before any collective: {ex}"}
+                return
+            except Exception as ex:
+                err = f"{type(ex).__name__}: {ex}"
+            if not all_ok(err is None):
+                broken[0] = name
+                extra_modes[name] = {"error": err or "another rank failed inside this leg"}
+                return
+            extra_modes[name] = brief(r, scaling)
+            extra_modes[name]["what"] = what
+
+        watchdog = None
+        if rank == 0:
+            import threading
+            budget = float(os.environ.get("NTF_BENCH_LEG_BUDGET_S", "150")) * 2
+
+            def cut_off():
+                for k in ("ep_weak", "strong_b1000"):
+                    extra_modes.setdefault(k, {"error": f"no result within {budget:.0f} s of the extra legs (a hang?): cut off by rank 0's watchdog"})
+                emit(final=False)
+                os._exit(0)
+            watchdog = threading.Timer(budget, cut_off); watchdog.daemon = True; watchdog.start()
         if shardable:
-            r = run_mode("ep", a.batch * world, a.steps, a.warmup, breakdown=False); r["engine"].close()
-            extra_modes["ep_weak"] = brief(r, "weak")
-            extra_modes["ep_weak"]["what"] = "output layer split along the expert axis; every GPU steps the global minibatch of b x N teams on 1/N of the experts; only d(hidden) is all-reduced"
+            guarded("ep_weak", "ep", a.batch * world, "weak",
+                    "output layer split along the expert axis; every GPU steps the global minibatch of b x N teams on 1/N of the experts; only d(hidden) is all-reduced")
         spar = "ep" if can_shard(dims, world) and not a.no_fused else "dp"      # opentf_amd/mdl/fnn.py::_parallel_mode
-        r = run_mode(spar, a.batch, a.steps, a.warmup, breakdown=False); r["engine"].close()
-        extra_modes["strong_b1000"] = brief(r, "strong")
-        extra_modes["strong_b1000"]["what"] = f"the plugin under torchrun: the reference's global minibatch of cfg.b = {a.batch} teams, shared as _parallel_mode picks ({spar})"
+        guarded("strong_b1000", spar, a.batch, "strong", f"the plugin under torchrun: the reference's global minibatch of cfg.b = {a.batch} teams, shared as _parallel_mode picks ({spar})")
+        if watchdog is not None: watchdog.cancel()
 
     exact_f32 = None
     if world == 1 and a.mfma == "default" and not a.no_f32_line and not a.no_fused and not a.ep_emulate:
@@ -373,43 +495,20 @@ def main():
                                       "reference_log": {"file": "output/dblp/dblp.v12.json.mt10.ts2/prep.d2v.skill.log", "s_per_pass": 276.4, "raw_words_per_s": 19073021 / 276.4, "workers": 224, "words": 19073021}}
 
     if rank != 0:
-        if world > 1: dist.destroy_process_group()
+        if world > 1 and not any("error" in v for v in extra_modes.values() if isinstance(v, dict)): dist.destroy_process_group()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0) if world > 1 else None      # (N > 1: no interpreter teardown over process groups whose state an abandoned leg may have left undefined)
         return
     if a.force_dist and world == 1: dist.destroy_process_group()
-    B, H, M = a.batch, a.hidden, ds["M"]
-    ep = head["ep"]; dt = head["dt"]
-    roof, roof_other = rooflines(head["times"], a, bayesian, head["eB"], H, head["Mloc"], ds, ep)
-    spread = (max(head["regions"]) - min(head["regions"])) / dt if len(head["regions"]) > 1 else None
-    devices = [torch.cuda.get_device_name(local)]
-    out = {
-        "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_spread": spread, "timed_regions": len(head["regions"]),
-        "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"f32": "f32", "bf16x6": "f32 (bf16x6 split products, f32 accumulate)"}.get(a.mfma, "f32 (fp16x3 split products, f32 accumulate)"), "data": "synthetic",
-        "config": {"workload": workload_label(a, ds, bayesian, multihot), "global_batch": gB,
-                   "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else
-                                   f"dp{world}" + (": rows split over the GPUs, gradients reduce-scattered / parameters all-gathered over RCCL, Adam on the owned 1/N shard" if world > 1 else ""))},
-        "roofline": roof, "roofline_other": roof_other, "cpu_baseline": None, "exact_f32_mfma": exact_f32, "mean_loss": head["mean_loss"],
-        "kernel_ms_per_step": head["breakdown"], "kernel_ms_note": "separate pass of %d steps with events around every kernel family (side-stream families overlap the big kernels: the column does not sum to the step); the timed region carries events around the two output-layer kernels only" % head["k3"],
-        "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1), "rank0_device": f"cuda:{local} {devices[0]}",
-        "rccl_payload_bytes_per_step": head["rccl_payload_bytes_per_step"],
-    }
-    out.update(extra_modes)
-    if extra_configs: out["extra_configs"] = extra_configs
-    if gather: out["roofline_gather"] = gather
-    if a.validate_on_one_gpu: out["validation_only"] = "all ranks on cuda:0 over gloo: code-path check, not a measurement"
-    if a.ep_emulate:
-        # one rank of G: it processed the whole global minibatch on 1/G of the experts, i.e. 1/G of the job
-        shard = expert_shards(dims[-1], G)[0]
-        out["metric"] += f" [one rank of {G} under --parallel ep, emulated on one GPU without the exchange]"
-        out["value"] = a.steps * a.batch / dt; out["n_gpus"] = 1
-        out["ep_emulation"] = {"G": G, "experts": [int(shard[0]), int(shard[1])], "rows_per_step": gB, "ms_per_step": dt / a.steps * 1e3,
-                               "projected_teams_per_s_at_G_gpus": a.steps * gB / dt, "note": "projection = G * this rank's rate; excludes the 4*B*h[-1]-byte all-reduce per step"}
+    state["exact_f32"], state["extra_configs"] = exact_f32, extra_configs
     if world == 1 and not a.no_cpu_baseline and not multihot and not a.ep_emulate:   # the CPU leg times the headline (mean-pool) configuration only
-        out["cpu_baseline"] = cpu_baseline(ds, dims, bayesian, cfg)
-    if world > 1: dist.destroy_process_group()   # before the JSON line: RCCL prints its version banner when the group goes away
-    sys.stdout.flush(); sys.stderr.flush()
-    print(json.dumps(out), file=real_stdout, flush=True)
+        state["cpu_baseline"] = cpu_baseline(ds, dims, bayesian, cfg)
+    clean = not any("error" in v for v in extra_modes.values() if isinstance(v, dict))
+    if world > 1 and clean: dist.destroy_process_group()   # before the JSON line: RCCL prints its version banner when the group goes away
+    emit(final=True)
+    if world > 1:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

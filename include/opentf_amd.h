@@ -113,6 +113,9 @@ int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int64_t count)
 /* d loss / d z [B, M] of the output layer (z = its pre-activation) as the last backward / train step left it: what autograd holds for
  * `y_` of src/mdl/fnn.py:132 before leaky_relu.  The fused kernels' only dense product, exposed so that it can be checked element-wise. */
 int ntf_get_dlogits(ntf_engine* e, float* host, int64_t count);
+/* The sampled negatives [B, ns] (GLOBAL expert ids) of the last step: `topk_indices` of src/mdl/fnn.py:48-76 as the device samplers drew them (or as they were injected).
+ * Exposed so that the samplers can be checked draw by draw over a sequence of steps (batch support, distinctness, frequencies), not only through the loss. */
+int ntf_get_negatives(ntf_engine* e, int64_t* host, int64_t count);
 int ntf_reset_optimizer(ntf_engine* e);                  /* fresh Adam per fold, src/mdl/fnn.py:104 */
 int ntf_set_lr(ntf_engine* e, float lr);                 /* ReduceLROnPlateau result, fnn.py:105,163 */
 int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step);
@@ -195,6 +198,10 @@ int ntf_gather_meanpool(ntf_engine* e, const int64_t* rows, int64_t n, float* ou
 /* ---- raw device views for RCCL (torch.distributed) and measurement */
 int ntf_grad_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
 int ntf_param_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats);
+/* A caller that WRITES parameters through the view above (an all-gather, a broadcast: torch.optim's `p.data.copy_`, src/mdl/fnn.py:104) says so before the next
+ * step: operands a fused train step prepared for its successor from the old values (eps, sigma eps, split planes, KL) are dropped and made again.
+ * ntf_param_buffer itself also drops what is pending at the time of the call; ntf_set_param / ntf_apply_ranges / ntf_set_seed do it on their own. */
+int ntf_params_touched(ntf_engine* e);
 /* Adam's first / second moments (torch.optim.Adam's exp_avg / exp_avg_sq, src/mdl/fnn.py:104), same flat layout as the parameters: an expert-sharded
  * run re-broadcasts the replicated hidden layers' parameters AND moments once per epoch (opentf_amd/ep.py) */
 int ntf_moment_buffers(ntf_engine* e, void** dev_m1, void** dev_v2, int64_t* n_floats);

@@ -129,6 +129,18 @@ __device__ __forceinline__ void bce_terms(float z, float& sp, float& sg, float& 
     sg = (l >= 0.f) ? inv : e * inv;
 }
 
+// One Adam step of one element (torch.optim.Adam defaults, src/mdl/fnn.py:104,139: exp_avg.lerp_, exp_avg_sq.mul_().addcmul_, p.addcdiv_(exp_avg, sqrt(exp_avg_sq) /
+// sqrt(bc2) + eps, -lr / bc1)).  EVERY Adam kernel of the engine calls this one (the flat kernel, the range kernel, the dW epilogues), so the paths agree bit for bit.
+// Round 4: the square root and the two divisions on the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences (~10 instructions per division,
+// ~12 per square root: a third of the fused dW epilogue's vector instructions).  The update term lr / bc1 * m / denom is then good to ~3e-7 relative, i.e. ~3e-10
+// absolute at lr = 1e-3 - below half an ulp of any parameter larger than 5e-3; a subnormal exp_avg_sq (sqrt < 1e-19) vanishes beside eps = 1e-8 either way.
+__device__ __forceinline__ void adam_step(float& p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float inv_bc2_sqrt) {
+    m = m + (1.f - b1) * (g - m);
+    v = v * b2 + (1.f - b2) * g * g;
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, eps);
+    p = p - (lr_over_bc1 * m) * __builtin_amdgcn_rcpf(denom);
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

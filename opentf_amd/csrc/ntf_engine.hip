@@ -77,6 +77,8 @@ struct ntf_engine {
     float* gemm_slab = nullptr;       // split-K partial sums of the generic GEMM
     double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
     int fwd_kernel = -1;
+    int lean = 1;                     // NTF_LEAN=0: the dW epilogue also writes the f32 copy of the next step's sigma * eps (round 3's 64 B per pair; A/B runs)
+    int dw_kernel = 1;                // NTF_DW_KERNEL=0: k_out_dw_p2 (one 256-expert workgroup per CU) instead of k_out_dw_q (A/B runs)
     int dw_ksplit = 0;                // 0: automatic (few expert tiles -> split the dW kernel's K range), else forced (NTF_DW_KSPLIT)
     int32_t* d_range = nullptr;       // fp16x3 range guard (lives behind d_kl[0]): [0] raised for the current step, [1] steps that fell back to the f32 kernels
     int64_t range_fallbacks_host = 0; // inference calls redone on the generic path for the same reason
@@ -200,6 +202,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->seed = cfg->seed;
     if (const char* fk = getenv("NTF_FWD_KERNEL")) e->fwd_kernel = atoi(fk);
     if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
+    if (const char* dk = getenv("NTF_DW_KERNEL")) e->dw_kernel = atoi(dk);
+    if (const char* ln = getenv("NTF_LEAN")) e->lean = atoi(ln);
     if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
@@ -266,6 +270,10 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
     if (e->st) hipStreamSynchronize(e->st);
+    // the side streams are drained and destroyed BEFORE any buffer their kernels may still touch is freed
+    if (e->st4) { hipStreamSynchronize(e->st4); hipStreamDestroy(e->st4); hipEventDestroy(e->ev_aux); }
+    if (e->st3) { hipStreamSynchronize(e->st3); hipStreamDestroy(e->st3); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); }
+    if (e->st2) { hipStreamSynchronize(e->st2); hipStreamDestroy(e->st2); hipEventDestroy(e->ev_chunk); hipEventDestroy(e->ev_side); }
     dfree(e->P); dfree(e->G); dfree(e->M1); dfree(e->V2);
     dfree(e->m_indptr); dfree(e->m_indices); dfree(e->s_indptr); dfree(e->s_indices); dfree(e->table); dfree(e->Xall);
     dfree(e->al_prob); dfree(e->al_alias); dfree(e->al_weight);
@@ -280,8 +288,6 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
     for (int k = 0; k < 2; ++k) { if (e->ub_host[k]) hipHostFree(e->ub_host[k]); if (e->ub_dev[k]) hipFree(e->ub_dev[k]); if (e->ub_ev[k]) hipEventDestroy(e->ub_ev[k]); }
-    if (e->st3) { hipStreamSynchronize(e->st3); hipStreamDestroy(e->st3); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); }
-    if (e->st2) { hipStreamSynchronize(e->st2); hipStreamDestroy(e->st2); hipEventDestroy(e->ev_chunk); hipEventDestroy(e->ev_side); }
     if (e->own_stream && e->st) hipStreamDestroy(e->st);
     delete e;
 }
@@ -806,7 +812,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             a.rows = c.rows_dev; a.s_indptr = e->s_indptr; a.s_indices = e->s_indices; a.table = e->table; a.Xall = e->Xall;
             a.mu0 = e->P + l0.off[NTF_P_WEIGHT]; a.b0 = e->P + l0.off[NTF_P_BIAS];
             a.X = e->act[0]; a.act1 = e->act[1]; a.hz = wp.hz; a.hs = wp.hs; a.sinbits = wp.sinbits;
-            a.hb = (c.train && e->cfg.mfma != NTF_MFMA_F32) ? wp.hb : nullptr;
+            a.hb = (c.train && e->cfg.mfma != NTF_MFMA_F32) ? wp.hb : nullptr; a.sinT = wp.sinT;
             a.h_scale = f.h_scale;
             const bool guard = f.np == 2 && f.rflag != nullptr;
             a.h_limit = guard ? 65504.f / f.h_scale : 0.f; a.rflag = guard ? f.rflag : nullptr;
@@ -839,6 +845,13 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
+        if (use_pre && e->lean) {
+            // this step's operands came from the previous step's dW epilogue, which (lean) left no f32 copy of sigma * eps: only a step that falls back to the exact-f32 kernels
+            // reads one, and makes it here - a capped grid that exits at once unless the range flag is raised (behind the head: k_head may still raise it)
+            Scope t(e, F_FLIPOUT_OPERAND);
+            launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, nullptr,
+                                   nullptr, nullptr, nullptr, 0, 3, 1.f, nullptr, range_ptr(e));
+        }
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
         nslots = fused_loss_slots(M);
@@ -899,6 +912,7 @@ backward:
             f.np = mfma_np(e); f.a_scale = dz_scale16(e, c.global_B); f.h_scale = kH16Scale; f.rflag = range_ptr(e);
             f.dz_packed = f.bf16x6 && f.np == 2 && li.in == 128 && e->pl_mu != nullptr;   // the fp16x3 forward kernels (H = 128) store packed plane pairs
             e->last_dz_packed_scale = f.dz_packed ? f.a_scale : 0.f;
+            f.kernel = e->dw_kernel;
             if (f.dz_packed && !c.defer_dw && !(c.fuse_adam && e->cfg.fuse_adam == 2)) {
                 // few expert tiles (a narrow expert shard under a wide minibatch, or a small model) leave most CUs idle at one workgroup per 256 experts:
                 // split every tile's K (batch) range over several workgroups.  Scratch: the dense-logits buffer of the generic path, idle in a fused step.
@@ -908,7 +922,7 @@ backward:
                 if (ks > 1) { f.ksplit = ks; f.part = e->Zout; }
             }
             // (launch_fused_prep_planes - the h planes and the transposed s_out words this kernel reads - ran in the step's head)
-            if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)out_nw * (float)c.global_B); }
+            if (e->cfg.bayesian) { f.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; f.wp = e->Wp[l]; f.klw = kl_share / ((float)out_nw * (float)c.global_B); f.cur_eps = normal_spec(e, c, l, T_EPS_W); }
             if (c.defer_dw) {
                 const int tile = fused_dw_tile(), total = (M + tile - 1) / tile;
                 e->pend = f; e->pend_valid = true; e->pend_chunks = (total + 255) / 256;
@@ -950,7 +964,7 @@ backward:
                 if (e->prefetch && e->cfg.bayesian && f.dz_packed && e->pl_wp && e->pl_mu && range_ptr(e)) {
                     // the Adam epilogue holds the updated mu / rho: it is also the operand producer of step + 1 (FusedDw.produce)
                     StepCtx nx; nx.step = c.step + 1;
-                    f.produce = 1; f.nx_eps = normal_spec(e, nx, l, T_EPS_W); f.nx_wp = e->Wp[l]; f.nx_pl_wp = e->pl_wp; f.nx_pl_mu = e->pl_mu; f.nx_pscale = kW16Scale;
+                    f.produce = 1; f.lean = e->lean; f.nx_eps = normal_spec(e, nx, l, T_EPS_W); f.nx_wp = e->Wp[l]; f.nx_pl_wp = e->pl_wp; f.nx_pl_mu = e->pl_mu; f.nx_pscale = kW16Scale;
                     f.nx_klw = 1.0 / out_nw; f.nx_kl = e->d_kl + 2; f.nx_rflag = e->d_range + 4;
                     e->pre_valid = true; e->pre_step = c.step + 1;
                 }
@@ -1031,8 +1045,11 @@ static int apply_adam(ntf_engine* e) {
     int64_t rg[6]; int fin[3] = {0, 0, 0}; int n = 0;
     rg[2 * n] = 0; rg[2 * n + 1] = w0; ++n;
     if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS];
-        rg[2 * n] = w1; rg[2 * n + 1] = r0; fin[n] = e->fin_pend ? 1 : 0; ++n; rg[2 * n] = r1; rg[2 * n + 1] = e->n_params; fin[n] = e->fin_pend ? 2 : 0; ++n; }
-    else { rg[2 * n] = w1; rg[2 * n + 1] = e->n_params; ++n; }
+        // the live lo.out floats of the two bias segments, not their 256-byte padding: a finalised range would push the KL gradient into the padding of rho_bias
+        // (p = 0, g = 0 there) and read an injected eps_b past its lo.out floats
+        (void)r0;
+        rg[2 * n] = w1; rg[2 * n + 1] = w1 + lo.out; fin[n] = e->fin_pend ? 1 : 0; ++n; rg[2 * n] = r1; rg[2 * n + 1] = r1 + lo.out; fin[n] = e->fin_pend ? 2 : 0; ++n; }
+    else { rg[2 * n] = w1; rg[2 * n + 1] = w1 + lo.out; ++n; }
     const bool rotate = e->cfg.bayesian && e->pre_valid && e->pre_step == e->step;   // this step's dW epilogue left the next step's KL / range flag behind the current ones
     launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2), fin, &e->fin_eps, e->fin_klw,
                        rotate ? e->d_kl : nullptr);
@@ -1323,6 +1340,18 @@ extern "C" int ntf_logits(ntf_engine* e, const int64_t* rows, int32_t B, const n
     return NTF_OK;
 }
 
+extern "C" int ntf_get_negatives(ntf_engine* e, int64_t* host, int64_t count) {
+    if (!e || !host) return NTF_EINVAL;
+    const int B = e->last_B, ns = e->cfg.ns;
+    if (B < 1 || ns < 1 || e->cfg.nsd == NTF_NSD_NONE) FAIL(e, NTF_ESTATE, "negatives: no step with sampled negatives has run");
+    if (count != (int64_t)B * ns) FAIL(e, NTF_EINVAL, "negatives: count != B * ns of the last step");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (e->st4) HIPCHK(e, hipStreamSynchronize(e->st4));
+    HIPCHK(e, hipMemcpyAsync(host, e->d_neg, (size_t)count * 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    return NTF_OK;
+}
+
 // d loss / d z of the output layer as the last backward left it (fused path: transposed dzT; generic path: [B, M]) -> host [B, M]
 extern "C" int ntf_get_dlogits(ntf_engine* e, float* host, int64_t count) {
     if (!e || !host) return NTF_EINVAL;
@@ -1486,7 +1515,14 @@ extern "C" int ntf_grad_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats)
     if (!e || !dev_ptr || !n_floats) return NTF_EINVAL; *dev_ptr = e->G; *n_floats = e->n_params; return NTF_OK;
 }
 extern "C" int ntf_param_buffer(ntf_engine* e, void** dev_ptr, int64_t* n_floats) {
-    if (!e || !dev_ptr || !n_floats) return NTF_EINVAL; *dev_ptr = e->P; *n_floats = e->n_params; return NTF_OK;
+    if (!e || !dev_ptr || !n_floats) return NTF_EINVAL; *dev_ptr = e->P; *n_floats = e->n_params;
+    e->pre_valid = false;   // whoever takes the raw view may write through it: the next step runs the stand-alone operand producer
+    return NTF_OK;
+}
+extern "C" int ntf_params_touched(ntf_engine* e) {
+    if (!e) return NTF_EINVAL;
+    e->pre_valid = false;
+    return NTF_OK;
 }
 extern "C" int ntf_moment_buffers(ntf_engine* e, void** dev_m1, void** dev_v2, int64_t* n_floats) {
     if (!e || !dev_m1 || !dev_v2 || !n_floats) return NTF_EINVAL;

@@ -9,7 +9,7 @@ struct FusedOut {
     int B = 0, H = 0, M = 0, bayes = 0, train = 0;
     const float* h = nullptr;                       // [B, H] leaky_relu output of the last hidden layer
     const float *mu = nullptr, *mu_b = nullptr;     // [M, H], [M]
-    const float *wp = nullptr, *bp = nullptr;       // flipout perturbation operands sigma*eps [M, H], [M]
+    const float *wp = nullptr, *bp = nullptr;       // flipout perturbation operands sigma*eps [M, H], [M] (wp: read by the exact-f32 / bf16x6 kernels only; the fp16x3 step reads wp_pl)
     SignSpec s_in, s_out;
     float tnw = 1.f, tpw = 1.f, inv_B = 1.f;
     float* dzT = nullptr;                           // out: d loss / d z, TRANSPOSED [M, ldb], ldb = fused_ldb(B)
@@ -56,6 +56,7 @@ struct FusedDw {
     int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the expert tiles [wg_begin, wg_begin + wg_count) of fused_dw_tile() experts each
     int* rflag = nullptr;                           // fp16x3 range guard, see FusedOut
     int dz_packed = 0;                              // np = 2, H = 128: dzT holds the forward kernel's packed fp16 plane pairs (see pack_planes)
+    int kernel = 1;                                 // dz_packed, unsplit K: 1 = k_out_dw_q (two 128-expert workgroups per CU, epilogue beside main loop), 0 = k_out_dw_p2
     int ksplit = 1; float* part = nullptr;          // dz_packed path, whole-layer launch: split every expert tile's K (batch) range over ksplit workgroups; part = scratch
                                                     // of fused_dw_part_floats(M, H, ksplit) floats.  For few expert tiles (a narrow expert shard under a wide minibatch).
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
@@ -63,6 +64,9 @@ struct FusedDw {
     // produce != 0 (adam, bayes, H = 128, fp16x3 planes): the Adam epilogue also writes the NEXT step's operands from the updated parameters - eps' (nx_eps: the
     // generator of step + 1), Wp' (f32, nx_wp), the split planes of Wp' and mu' (nx_pl_*, scale nx_pscale), KL' * nx_klw added to *nx_kl, *nx_rflag raised when an
     // operand leaves the fp16 window - what k_flipout_perturb would do in its own pass at the head of that step
+    NormalSpec cur_eps;                             // Flipout: THIS step's eps generator - the rho gradient's eps is drawn again (or read from the injected tensor), never recovered as wp / sigma
+    int lean = 0;                                   // with produce: do not write the f32 copy of the next step's sigma * eps (nx_wp) - every reader of that step takes the planes, and a step that
+                                                    // falls back to the exact-f32 kernels makes the copy itself (launch_flipout_perturb(only_if)): 56 instead of 64 B of HBM traffic per mu / rho pair
     int produce = 0; NormalSpec nx_eps; float* nx_wp = nullptr; uint16_t *nx_pl_wp = nullptr, *nx_pl_mu = nullptr; float nx_pscale = 1.f; double nx_klw = 0.0;
     double* nx_kl = nullptr; int* nx_rflag = nullptr;
 };
@@ -72,7 +76,7 @@ int fused_loss_slots(int M);
 int64_t fused_dh_slab_floats(int B, int H, int M);
 size_t fused_workspace_bytes(int B, int H, int M);
 // where phase 1 of launch_fused_out_fwd and launch_fused_prep_planes leave their images in the workspace (the one-kernel head, ntf_head.hip, writes the same ones)
-struct FusedWsPtrs { float *hz, *hs; uint32_t* sinbits; uint16_t* hb; int Bpad; };
+struct FusedWsPtrs { float *hz, *hs; uint32_t* sinbits; uint16_t* hb; uint32_t* sinT; int Bpad; };
 FusedWsPtrs fused_ws_ptrs(void* ws, int B, int H, int M);
 int fused_ldb(int B);
 int64_t fused_planes_elems(int M, int H);   // uint16 elements of one matrix's split planes

@@ -59,7 +59,7 @@ static Geom geom(int B, int M) {
 }
 int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)2 * NCG_MAX * BM * H; }   // x2: k_out_fwd_rs writes one slab set per role
 
-struct WsLayout { size_t sbits, sbitsT, sinbits, hs, hz, lossp, hb, total; };
+struct WsLayout { size_t sbits, sbitsT, sinbits, sinT, hs, hz, lossp, hb, total; };
 static WsLayout ws_layout(int Bmax, int H, int M) {
     const int Bpad = rup(Bmax, BM), nCB = rup((M + 31) / 32, 2);
     WsLayout w; size_t o = 0;
@@ -67,6 +67,7 @@ static WsLayout ws_layout(int Bmax, int H, int M) {
     w.sbits = take((size_t)Bpad * nCB * 4);
     w.sbitsT = take((size_t)rup(M, DW_TC) * (Bpad / 32) * 4);   // [expert tile of 256][K block of 32 rows][256 experts]: word = s_out signs of the 32 rows
     w.sinbits = take((size_t)Bpad * (H / 32) * 4);
+    w.sinT = take((size_t)(Bpad / 32) * H * 4);   // [K block][hidden unit]: s_in signs of the block's 32 rows (k_sin_words_T)
     w.hs = take((size_t)Bpad * H * 4);
     w.hz = take((size_t)Bpad * H * 4);
     w.lossp = take((size_t)Bpad * NCG_MAX * 4);
@@ -78,7 +79,7 @@ size_t fused_workspace_bytes(int B, int H, int M) { return ws_layout(B, H, M).to
 FusedWsPtrs fused_ws_ptrs(void* ws_, int B, int H, int M) {
     const WsLayout w = ws_layout(B, H, M); char* ws = static_cast<char*>(ws_);
     FusedWsPtrs r; r.hz = reinterpret_cast<float*>(ws + w.hz); r.hs = reinterpret_cast<float*>(ws + w.hs); r.sinbits = reinterpret_cast<uint32_t*>(ws + w.sinbits);
-    r.hb = reinterpret_cast<uint16_t*>(ws + w.hb); r.Bpad = rup(B, BM);
+    r.hb = reinterpret_cast<uint16_t*>(ws + w.hb); r.sinT = reinterpret_cast<uint32_t*>(ws + w.sinT); r.Bpad = rup(B, BM);
     return r;
 }
 
@@ -471,6 +472,7 @@ struct SpecialArgs {
     float dz_pack_scale;   // > 0: dzT holds packed fp16 plane pairs of dz * scale (fp16x3 step) ... unless *rflag is raised (the f32 kernels ran)
     const int* rflag;
     int c_lo;              // expert shard: labels and negatives name GLOBAL expert ids, this launch owns [c_lo, c_lo + M)
+    const uint16_t* wp_pl; float wp_inv_scale;   // fp16x3 step: sigma * eps as the two fp16 planes the forward kernel multiplied with (k_out_fwd_h3x's tile layout); null: the f32 copy `wp`
 };
 
 // One wave per team.  H = 128: the wave works as FOUR quarter-waves of 16 lanes x 8 consecutive hidden units, each quarter taking every fourth
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
     const int q = QUAD ? (lane >> 4) : 0, l = QUAD ? (lane & 15) : lane;
     auto hidx = [&](int k) { return QUAD ? 8 * l + k : l + 64 * k; };      // this lane's k-th hidden unit
     const bool packed = p.dz_pack_scale > 0.f && !(p.rflag && *p.rflag);
+    const bool wp_planes = BAYES && QUAD && p.wp_pl != nullptr && !(p.rflag && *p.rflag);   // (a step that fell back to the f32 kernels: its planes are saturated, the f32 copy was made for it)
     float rl = 0.f;
     for (int cg = lane; cg < p.NCG; cg += 64) rl += p.lossp[(int64_t)i * p.NCG + cg];
     rl = wave_reduce_sum(rl);
@@ -531,7 +534,16 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
         for (int k = 0; k < NV; ++k) {
             const int j = hidx(k);
             mu_r[k] = 0.f; wp_r[k] = 0.f;
-            if (j < H) { mu_r[k] = p.mu[(int64_t)cc * H + j]; d1 += hr[k] * mu_r[k]; if (BAYES) { wp_r[k] = p.wp[(int64_t)cc * H + j]; d2 += hsr[k] * wp_r[k]; } }
+            if (j < H) { mu_r[k] = p.mu[(int64_t)cc * H + j]; d1 += hr[k] * mu_r[k]; if (BAYES && !wp_planes) { wp_r[k] = p.wp[(int64_t)cc * H + j]; d2 += hsr[k] * wp_r[k]; } }
+        }
+        if constexpr (BAYES && QUAD) {
+            if (wp_planes) {   // the lane's 8 consecutive hidden units of row cc: 16 bytes from each plane; value = (hi + lo) / scale - exactly what the dense pass multiplied with
+                typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+                const uint16_t* r0 = p.wp_pl + ((int64_t)(cc >> 5) * 64 + (cc & 31)) * H + 8 * l;     // [tile of 32 rows][plane][row][H]
+                const h8_t hi = *reinterpret_cast<const h8_t*>(r0), lo = *reinterpret_cast<const h8_t*>(r0 + 32 * H);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) { wp_r[k] = ((float)hi[k] + (float)lo[k]) * p.wp_inv_scale; d2 += hsr[k] * wp_r[k]; }
+            }
         }
         d1 = group_sum(d1);
         float z = d1 + p.mu_b[cc];
@@ -601,6 +613,7 @@ struct DwArgs {
     int wg_begin;   // first expert tile of this launch (the expert range can be launched in chunks)
     int* rflag; int rmode;   // fp16x3 range guard, see OutFwdArgs
     const uint32_t* sT;      // k_sign_words_T image (fp16x3 packed path)
+    const uint32_t* sinT;    // k_sin_words_T image: s_in signs of (K block, hidden unit) over the block's 32 rows (k_out_dw_q)
     int ablate;              // diagnostics (NTF_DW_ABLATE): 1 no epilogue memory traffic, 2 no MFMAs, 4 no DMA after the first K block, 8 no barrier waits on DMA
     const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
@@ -613,8 +626,14 @@ struct DwArgs {
     // eps' (Philox keyed by step + 1), Wp' = softplus(rho') eps' (f32, in place over this step's Wp), the fp16 split planes of Wp' and mu' that the forward kernel
     // streams, the layer's KL' and fp16 range flag of the next step.  Saves k_flipout_perturb's own pass over the layer (0.72 GB, 0.12 ms at config 2) and takes
     // it off the path between two steps: what it would read is in registers here.
+    NormalSpec cur_eps; int lean;   // see FusedDw
     int produce; NormalSpec nx_eps; float* nx_wp; uint16_t *nx_pl_wp, *nx_pl_mu; float nx_pscale; double nx_klw; double* nx_kl; int* nx_rflag;
 };
+
+// f(integral_constant<int, I>) for I = I0 .. N - 1: an unrolled loop by construction
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 // N consecutive floats (N = 1, 2, 4) as one access
 template <int N> __device__ __forceinline__ void ld_vec(const float* p, float (&v)[N]) {
@@ -629,9 +648,8 @@ template <int N> __device__ __forceinline__ void st_vec(float* p, const float (&
 }
 
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
-    m = m + (1.f - b1) * (g - m);
-    v = v * b2 + (1.f - b2) * g * g;
-    return p - lr_over_bc1 * (m / (sqrtf(v) / bc2_sqrt + eps));
+    adam_step(p, g, m, v, lr_over_bc1, b1, b2, eps, __builtin_amdgcn_rcpf(bc2_sqrt));   // ntf_device.h: the one Adam expression of every kernel
+    return p;
 }
 
 // 32x32 bit-matrix transpose across the 32 lanes of a half-wave (lane l holds row l): five butterfly stages of masked
@@ -663,7 +681,7 @@ __device__ __forceinline__ void dw_produce_next(const DwArgs& p, int64_t idx0, c
         ov[j] = sigma * z[j];
         kl += -ls + 0.5f * (sigma * sigma + mu4[j] * mu4[j]) - 0.5f;
     }
-    *reinterpret_cast<float4*>(p.nx_wp + idx0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (!p.lean) *reinterpret_cast<float4*>(p.nx_wp + idx0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
     const int64_t row = idx0 >> 7; const int j = (int)(idx0 & 127);      // H = 128
     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(mu4[0]), fabsf(mu4[1])), fmaxf(fabsf(mu4[2]), fabsf(mu4[3]))));
@@ -1099,38 +1117,51 @@ __global__ __launch_bounds__(256) void k_sign_words_T(const uint32_t* __restrict
 
 // Epilogue of the output layer's dW for N consecutive hidden units of one expert (idx0 = expert * H + first unit), from the finished sums s1 = dz^T h and
 // s2 = (dz s_out)^T (h s_in): Flipout chain rule for rho (eps recovered as Wp / sigma) + the KL terms, then either the gradients or, with ADAM, the update in place.
+// operands of that epilogue for one run of N hidden units: what it reads from memory, so that a caller can have the next runs' loads in flight (k_out_dw_q)
+template <int N> struct DwOps { float rho[N], mu[N], m1[N], v1[N], m2[N], v2[N]; };
 template <bool BAYES, bool ADAM, int N>
-__device__ __forceinline__ void dw_finish_vec(const DwArgs& p, int64_t idx0, const float (&s1)[N], const float (&s2)[N], float& nx_kl, float& nx_amax) {
-    float v_rho[N], v_mu[N], v_wp[N], o_mu[N], o_rho[N];
-    if (BAYES) { ld_vec<N>((ADAM ? p.w_rho : p.rho) + idx0, v_rho); ld_vec<N>((ADAM ? p.w_mu : p.mu) + idx0, v_mu); ld_vec<N>(p.wp + idx0, v_wp); }
-    else if (ADAM) ld_vec<N>(p.w_mu + idx0, v_mu);
-    float a_m1[N], a_v1[N], a_m2[N], a_v2[N];
-    if (ADAM) { ld_vec<N>(p.m_mu + idx0, a_m1); ld_vec<N>(p.v_mu + idx0, a_v1); if (BAYES) { ld_vec<N>(p.m_rho + idx0, a_m2); ld_vec<N>(p.v_rho + idx0, a_v2); } }
+__device__ __forceinline__ void dw_ops_load(const DwArgs& p, int64_t idx0, DwOps<N>& o) {
+    if (BAYES) { ld_vec<N>((ADAM ? p.w_rho : p.rho) + idx0, o.rho); ld_vec<N>((ADAM ? p.w_mu : p.mu) + idx0, o.mu); }
+    else if (ADAM) ld_vec<N>(p.w_mu + idx0, o.mu);
+    if (ADAM) { ld_vec<N>(p.m_mu + idx0, o.m1); ld_vec<N>(p.v_mu + idx0, o.v1); if (BAYES) { ld_vec<N>(p.m_rho + idx0, o.m2); ld_vec<N>(p.v_rho + idx0, o.v2); } }
+}
+template <bool BAYES, bool ADAM, int N>
+__device__ __forceinline__ void dw_finish_ops(const DwArgs& p, int64_t idx0, const float (&s1)[N], const float (&s2)[N], DwOps<N>& o, float& nx_kl, float& nx_amax) {
+    static_assert(N == 4, "one Philox quad per call");
+    float o_mu[N], o_rho[N], z[4] = {0.f, 0.f, 0.f, 0.f};
+    // d(sigma eps)/d rho = eps sigmoid(rho): eps of THIS step drawn again from its counter (or read from the injected tensor) - round 3 recovered it as wp / sigma from an
+    // f32 copy of sigma eps that every step wrote (4 B) and read (4 B) per element for this one use
+    if (BAYES) normal4(p.cur_eps, idx0 >> 2, idx0, INT64_MAX, z);
 #pragma unroll
     for (int jt = 0; jt < N; ++jt) {
         float gm = s1[jt], gr = 0.f, pm = 0.f, rh = 0.f;
         if (BAYES) {
-            rh = v_rho[jt];
-            pm = v_mu[jt];
-            const float w = v_wp[jt];
+            rh = o.rho[jt];
+            pm = o.mu[jt];
             const float e = __builtin_amdgcn_exp2f(fminf(rh, 80.f) * 1.44269504f), t = 1.f + e;
             const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
             const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
             gm += p.klw * pm;
-            gr = s2[jt] * (w * isig) * sg + p.klw * (sigma - isig) * sg;
-        } else if (ADAM) pm = v_mu[jt];
+            gr = s2[jt] * z[jt] * sg + p.klw * (sigma - isig) * sg;
+        } else if (ADAM) pm = o.mu[jt];
         o_mu[jt] = gm; o_rho[jt] = gr;
         if (ADAM) {   // in place: the updated parameter goes where the gradient would have gone
-            o_mu[jt] = adam_update(pm, gm, a_m1[jt], a_v1[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
-            if (BAYES) o_rho[jt] = adam_update(rh, gr, a_m2[jt], a_v2[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+            o_mu[jt] = adam_update(pm, gm, o.m1[jt], o.v1[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
+            if (BAYES) o_rho[jt] = adam_update(rh, gr, o.m2[jt], o.v2[jt], p.lr_over_bc1, p.b1, p.b2, p.eps, p.bc2_sqrt);
         }
     }
     if (!ADAM) { st_vec<N>(p.g_mu + idx0, o_mu); if (BAYES) st_vec<N>(p.g_rho + idx0, o_rho); }
     else {
-        st_vec<N>(p.w_mu + idx0, o_mu); st_vec<N>(p.m_mu + idx0, a_m1); st_vec<N>(p.v_mu + idx0, a_v1);
-        if (BAYES) { st_vec<N>(p.w_rho + idx0, o_rho); st_vec<N>(p.m_rho + idx0, a_m2); st_vec<N>(p.v_rho + idx0, a_v2); }
+        st_vec<N>(p.w_mu + idx0, o_mu); st_vec<N>(p.m_mu + idx0, o.m1); st_vec<N>(p.v_mu + idx0, o.v1);
+        if (BAYES) { st_vec<N>(p.w_rho + idx0, o_rho); st_vec<N>(p.m_rho + idx0, o.m2); st_vec<N>(p.v_rho + idx0, o.v2); }
         if constexpr (BAYES && N == 4) { if (p.produce) dw_produce_next(p, idx0, o_mu, o_rho, nx_kl, nx_amax); }
     }
+}
+template <bool BAYES, bool ADAM, int N>
+__device__ __forceinline__ void dw_finish_vec(const DwArgs& p, int64_t idx0, const float (&s1)[N], const float (&s2)[N], float& nx_kl, float& nx_amax) {
+    DwOps<N> o;
+    dw_ops_load<BAYES, ADAM, N>(p, idx0, o);
+    dw_finish_ops<BAYES, ADAM, N>(p, idx0, s1, s2, o, nx_kl, nx_amax);
 }
 
 // split-K dW: sum of the K ranges' partial slabs, then the epilogue (one thread per four hidden units; the first M threads also finish the bias gradients)
@@ -1356,6 +1387,239 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     stamp(3);
     if (STAMP && p.stamps && lane == 0) { for (int q = 0; q < 4; ++q) p.stamps[((int64_t)blockIdx.x * DW_WAVES + wave) * 4 + q] = st_sum[q]; }
     if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
+}
+
+// ------------------------------------------------------------------------------------------------
+// s_in sign words of the dW kernel k_out_dw_q: sinT[K block ib][hidden unit j] = the signs of (batch rows 32 ib .. 32 ib + 31, j), in the bit order that kernel's B
+// fragments take their masks from - the fragment (k step ks, lane half hf) of a hidden unit holds rows 8 g .. 8 g + 7, g = 2 ks + hf, dword q = rows 8 g + 2 q (low
+// fp16) and 8 g + 2 q + 1 (high): row 8 g + 2 q sits at bit 4 g + 3 - q, row 8 g + 2 q + 1 at bit 16 + 4 g + 3 - q, so that (word << (12 - 4 g + q)) & 0x80008000
+// is the XOR mask of dword q.
+__host__ __device__ __forceinline__ int sin_word_bit(int r) { const int g = r >> 3, q = (r & 7) >> 1, o = r & 1; return 16 * o + 4 * g + 3 - q; }
+__global__ void k_sin_words_T(const uint32_t* __restrict__ sinbits, int Bpad, uint32_t* __restrict__ sinT) {   // sinbits[i][4]: bit j & 31 of word j >> 5 (k_prep_h)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (Bpad >> 5) * 128) return;
+    const int ib = t >> 7, j = t & 127;
+    uint32_t w = 0u;
+    for (int r = 0; r < 32; ++r) w |= ((sinbits[(int64_t)(ib * 32 + r) * 4 + (j >> 5)] >> (j & 31)) & 1u) << sin_word_bit(r);
+    sinT[t] = w;
+}
+
+// dW + Adam (+ the next step's operands) of the fp16x3 training step, second form (round 4).  k_out_dw_p2's tile is a main loop (LDS-fed MFMAs, HBM a quarter used)
+// followed by an HBM-bound epilogue (64 B per mu / rho pair, the matrix pipe idle), and with one 130 KB-LDS workgroup per CU neither hides the other: 0.33 + 0.32 ms.
+// Here a workgroup is HALF of that tile - 4 waves x 32 experts, the same 32-row K blocks, the same MFMA sequence per accumulator (bit-identical sums) - and its LDS
+// stage is 33 KB instead of 65: the A half (16 KB of packed dz), the h planes (16 KB) and two 512-B sign images; the planes of h * s_in are NOT staged - the
+// signed B fragment is the plain one XOR a mask made from the transposed s_in words (k_sin_words_T: 2 vector instructions per mask dword), which also halves the
+// LDS bytes a wave reads per MFMA (20 KB instead of 36 KB per K block).  Two such workgroups fit a CU (2 x 66 KB of LDS, 2 x 4 waves x 256 registers); the second
+// one of every CU starts half a tile late (p.stagger), so that from then on one is in its main loop while the other streams its epilogue: matrix pipe and HBM at
+// the same time.  (A workgroup that exits is replaced at once, which keeps the offset.)  The epilogue keeps the operand rows of DW_EPI_PD accumulator rows in flight
+// ahead of the row it works on: four waves must sustain what eight did.
+#ifndef DW_EPI_PD
+#define DW_EPI_PD 1
+#endif
+#ifndef DWQ_PRIO
+#define DWQ_PRIO 2    // s_setprio of the main loop (0: 0.634, 2: 0.604 ms on one box; 3 = 2)
+#endif
+#ifndef DWQ_BRING
+#define DWQ_BRING 2
+#endif
+#ifndef DWQ_PPG
+#define DWQ_PPG 3     // DMA pieces of the next K block per half-group of 3 MFMAs (with DWQ_PRIO 2, relative to k_out_dw_p2 on the same box: 1 -5.0 %, 2 -5.6 %, 3 -6.7 %)
+#endif
+constexpr int QW = 4;            // waves per workgroup
+constexpr int QTC = 32 * QW;     // experts per workgroup
+template <bool BAYES, bool ADAM, bool STAMP = false>
+__global__ __launch_bounds__(64 * QW, 2) void k_out_dw_q(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = 128, NJT = 4, NP = 2;
+    constexpr int TA = QTC * 32 * 4;              // packed dz [128 experts][32 rows] dwords, 16-byte chunks XOR-swizzled ((row>>1)&7)
+    constexpr int PLANE = H * 64;                 // [H slots][32 rows] fp16
+    constexpr int TB = NP * PLANE;                // the two planes of h
+    constexpr int SRC_TB = (BAYES ? 2 : 1) * TB;  // hb holds the planes of h * s_in behind them (k_out_dw_p2's operands)
+    constexpr int TW = BAYES ? 1024 : 0;          // s_out words of the tile's experts (512 B), s_in words of the hidden units (512 B)
+    constexpr int STAGE = TA + TB + TW;
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
+    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) return;   // the step runs in exact f32: the kernel launched behind this one
+    const int c0 = (p.wg_begin + (int)blockIdx.x) * QTC;
+    const int crow = wave * 32 + il, c = c0 + crow;
+    const int nib = p.Bpad / 32;
+    const uint32_t smem_base = lds_addr(smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* hb = reinterpret_cast<const char*>(p.hb);
+    unsigned long long st_t[4] = {0, 0, 0, 0};
+    if (STAMP) st_t[0] = __builtin_amdgcn_s_memrealtime();
+    uint32_t lds_base = 0u;
+    if (STAMP || (p.stagger > 0 && (int)blockIdx.x < p.ntile)) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC, 0, 8)" : "=s"(lds_base));
+    if (p.stagger > 0 && (int)blockIdx.x < p.ntile) {
+        // first round of workgroups: the one that shares its CU with an earlier one (its LDS allocation does not start at 0) starts late
+        if (lds_base != 0u) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)p.stagger) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+
+    const h2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+    constexpr int NA = TA / 1024 / QW, NB = TB / 1024 / QW;   // DMA pieces per wave and K block: 4 of the dz tile, 4 of the planes (+ the sign words with the last one)
+    const float* dz_tile = p.dzT + (int64_t)(c0 >> 8) * nib * 8192 + ((c0 & 255) << 5);
+    const uint32_t* sw_src = BAYES ? (half == 0 ? p.sT + (int64_t)(c0 >> 8) * nib * 256 + (c0 & 255) + il * 4 : p.sinT + il * 4) : nullptr;
+    const int sw_step = half == 0 ? 256 : 128;    // words per K block in the two images
+    auto stage_piece = [&](int ib, int buf, int n) {
+        const uint32_t sb = smem_base + buf * STAGE;
+        if (n < NA) {
+            const int inst = wave_u * NA + n;
+            const int row = inst * 8 + (lane >> 3), pch = lane & 7;
+            const int q = pch ^ ((row >> 1) & 7);
+            glds16(dz_tile + (int64_t)ib * 8192 + row * 32 + 4 * q, sb + inst * 1024);
+        } else {
+            const char* src = hb + (size_t)ib * SRC_TB;
+            const int inst = wave_u * NB + (n - NA);
+            const int pos = inst * 1024 + lane * 16;
+            const int j = (pos % PLANE) >> 6, cd = (pos >> 4) & 3;
+            glds16(src + (pos & ~63) + 16 * (cd ^ ((j >> 2) & 3)), sb + TA + inst * 1024);
+            // the K block's sign words, 1 KiB: fetched by EVERY wave (the same bytes to the same place; a wave-uniform branch would split the K block's body)
+            if (BAYES && n == NA + NB - 1) glds16(sw_src + (int64_t)ib * sw_step, sb + TA + TB);
+        }
+    };
+    float nx_kl = 0.f, nx_amax = 0.f;
+    unsigned long long st_c[3] = {0, 0, 0}, c_prev = 0;     // STAMP: shader-clock sums over the K blocks - body, DMA wait, barrier
+    auto cyc = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+#pragma unroll
+    for (int n = 0; n < NA + NB; ++n) stage_piece(0, 0, n);
+    f32x16 acc1[NJT], acc2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
+    float sum1 = 0.f, sum2 = 0.f;
+    const int shl0 = 12 - 4 * half, shl1 = 4 - 4 * half;      // mask shifts of k step 0 / 1 (fragment row group g = 2 ks + half)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto k_block = [&](int ib, auto more_c) {
+        constexpr bool MORE = decltype(more_c)::value;
+        const int buf = ib & 1;
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + TA;
+        uint32_t word = 0u;
+        u32x4 iw = {0u, 0u, 0u, 0u};
+        if (BAYES) { word = *reinterpret_cast<const uint32_t*>(sA + TA + TB + crow * 4); iw = *reinterpret_cast<const u32x4*>(sA + TA + TB + 512 + il * 16); }
+        constexpr int NG = 2 * NJT;                 // (ks, jt) groups: one B fragment each, used plain and (Flipout) signed
+        const char* bbase = sB + il * 64;
+        const int swz = (il >> 2) & 3;
+        auto load_b = [&](int g, u32x4 (&dst)[3]) {
+            const int ks = g / NJT, jt = g % NJT;
+            const char* bp = bbase + jt * 2048 + 16 * ((2 * ks + half) ^ swz);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) dst[q] = *reinterpret_cast<const u32x4*>(bp + q * PLANE);
+            dst[2] = u32x4{0u, 0u, 0u, 0u};
+        };
+        u32x4 a[2][3], as[2][3];
+        auto prep_a = [&](int ks) {      // rows 16 ks + 8 half .. + 7 of this lane's expert: 8 packed dwords -> the hi and the lo plane fragment (k_out_dw_p2)
+            const int ch = 4 * ks + 2 * half, sw = (crow >> 1) & 7;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(sA + crow * 128 + 16 * (ch ^ sw));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(sA + crow * 128 + 16 * ((ch + 1) ^ sw));
+            const uint32_t x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const uint32_t w8 = word >> (ks * 16 + half * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t p1 = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x05040100u), p2 = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x07060302u);
+                a[ks][0][q] = p1; a[ks][1][q] = p2; a[ks][2][q] = 0u;
+                sum1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, p1), ones, sum1, false);
+                sum1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, p2), ones, sum1, false);
+                if (BAYES) {
+                    const uint32_t m = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+                    const uint32_t s1 = p1 ^ m, s2 = p2 ^ m;
+                    as[ks][0][q] = s1; as[ks][1][q] = s2; as[ks][2][q] = 0u;
+                    sum2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, s1), ones, sum2, false);
+                    sum2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, s2), ones, sum2, false);
+                }
+            }
+        };
+        constexpr int BR = DWQ_BRING;           // B fragments in flight: the fragment of group g + BR - 1 is fetched while group g's MFMAs run
+        u32x4 bq[BR][3], bs[3];
+#pragma unroll
+        for (int g = 0; g < BR - 1; ++g) load_b(g, bq[g]);
+        prep_a(0);
+        int piece = 0;
+        auto dma = [&]() {
+            if (MORE) {
+#pragma unroll
+                for (int q = 0; q < DWQ_PPG; ++q) { if (piece < NA + NB) stage_piece(ib + 1, buf ^ 1, piece); ++piece; }
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + BR - 1 < NG) load_b(g + BR - 1, bq[(g + BR - 1) % BR]);
+            asm volatile("" ::: "memory");
+            const int ks = g / NJT, jt = g % NJT;
+            acc1[jt] = mfma_np<NP>(a[ks], bq[g % BR], acc1[jt]);
+            dma();
+            if (BAYES) {
+                const uint32_t v = iw[jt] << (ks ? shl1 : shl0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t m = (v << q) & 0x80008000u;
+                    bs[0][q] = bq[g % BR][0][q] ^ m; bs[1][q] = bq[g % BR][1][q] ^ m;
+                }
+                bs[2] = u32x4{0u, 0u, 0u, 0u};
+                acc2[jt] = mfma_np<NP>(as[ks], bs, acc2[jt]);
+                dma();
+            }
+            if (g == 0) prep_a(1);
+        }
+        if (STAMP) { st_c[0] += cyc() - c_prev; c_prev = cyc(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STAMP) { st_c[1] += cyc() - c_prev; c_prev = cyc(); }
+        __syncthreads();
+        if (STAMP) { st_c[2] += cyc() - c_prev; c_prev = cyc(); }
+    };
+    if (STAMP) { st_t[1] = __builtin_amdgcn_s_memrealtime(); c_prev = cyc(); }
+    if (DWQ_PRIO) __builtin_amdgcn_s_setprio(DWQ_PRIO);   // the main loop is the latency-bound one of a SIMD's two waves (one in-order MFMA stream); its partner streams an epilogue
+    for (int ib = 0; ib < nib - 1; ++ib) k_block(ib, std::true_type{});
+    k_block(nib - 1, std::false_type{});
+    if (DWQ_PRIO) __builtin_amdgcn_s_setprio(0);
+    if (STAMP) st_t[2] = __builtin_amdgcn_s_memrealtime();
+    sum1 += __shfl_xor(sum1, 32, 64);
+    sum2 += __shfl_xor(sum2, 32, 64);
+    const float inv_a = 1.f / p.a_scale;
+    if (half == 0 && c < p.M) { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
+
+    // epilogue: accumulator row r of lane (il, half) = expert c0 + 32 wave + rowmap(r, half), hidden units 4 il .. 4 il + 3
+    constexpr int PD = DW_EPI_PD;
+    DwOps<NJT> ops[PD + 1];
+    auto row_idx = [&](int r, int64_t& idx0) -> bool {
+        const int cr = c0 + wave * 32 + rowmap(r, half);
+        idx0 = (int64_t)cr * H + NJT * il;
+        return cr < p.M;
+    };
+    static_for<0, PD>([&](auto rc) { constexpr int r = decltype(rc)::value; int64_t idx0; if (row_idx(r, idx0)) dw_ops_load<BAYES, ADAM, NJT>(p, idx0, ops[r % (PD + 1)]); });
+    static_for<0, 16>([&](auto rc) {      // (a compile-time r: left as a loop hipcc keeps it rolled and indexes the operand sets through scratch)
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r + PD < 16) { int64_t idn; if (row_idx(r + PD, idn)) dw_ops_load<BAYES, ADAM, NJT>(p, idn, ops[(r + PD) % (PD + 1)]); }
+        int64_t idx0;
+        if (row_idx(r, idx0)) {
+            float s1[NJT], s2[NJT];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) { s1[jt] = acc1[jt][r] * p.unscale; s2[jt] = acc2[jt][r] * p.unscale; }
+            dw_finish_ops<BAYES, ADAM, NJT>(p, idx0, s1, s2, ops[r % (PD + 1)], nx_kl, nx_amax);
+        }
+    });
+    if (STAMP && p.stamps && lane == 0) {   // diagnostics (NTF_DW_STAMP): per wave - entry, main loop begin / end, exit (100 MHz ticks), where it ran, its LDS base
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_t[3] = __builtin_amdgcn_s_memrealtime();
+        uint32_t hw_id, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = p.stamps + ((int64_t)blockIdx.x * QW + wave) * 10;
+        o[0] = st_t[0]; o[1] = st_t[1]; o[2] = st_t[2]; o[3] = st_t[3]; o[4] = ((unsigned long long)xcc << 32) | hw_id; o[5] = lds_base;
+        o[6] = st_c[0]; o[7] = st_c[1]; o[8] = st_c[2]; o[9] = 0;
+    }
+    if (BAYES && ADAM && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), QW);   // (scratch behind the stages)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2986,6 +3250,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     s.dz_pack_scale = (f.train && f.bf16x6 && f.H == 128 && f.np == 2) ? f.dz_scale : 0.f; s.rflag = f.rflag; s.c_lo = f.c_lo;
+    s.wp_pl = (f.bayes && f.bf16x6 && f.H == 128 && f.np == 2 && f.wp_pl) ? f.wp_pl : nullptr; s.wp_inv_scale = 1.f / f.w_scale;
     const int grid = g.NRB * g.NCG;
     if (f.bf16x6 && f.H == 128) {
         const int np = f.np == 2 ? 2 : 3;
@@ -3123,6 +3388,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
     a.rflag = f.rflag; a.rmode = 0;
     a.produce = (f.produce && f.adam && f.bayes && f.H == 128) ? 1 : 0;
+    a.cur_eps = f.cur_eps; a.lean = (a.produce && f.lean) ? 1 : 0;
     a.nx_eps = f.nx_eps; a.nx_wp = f.nx_wp; a.nx_pl_wp = f.nx_pl_wp; a.nx_pl_mu = f.nx_pl_mu; a.nx_pscale = f.nx_pscale; a.nx_klw = f.nx_klw; a.nx_kl = f.nx_kl; a.nx_rflag = f.nx_rflag;
     { static const int abl = getenv("NTF_DW_ABLATE") ? atoi(getenv("NTF_DW_ABLATE")) : 0; a.ablate = abl; }
     a.ntile = 0; a.stagger = 0; a.stamps = nullptr;
@@ -3144,6 +3410,42 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
 #undef NTF_DWS
             if (!guard) return;
             a.rmode = 2; a.ksplit = 1;
+            goto exact_f32;
+        }
+        if (f.kernel == 1) {   // two half-tile workgroups per CU, the epilogue of one beside the main loop of the other (k_out_dw_q)
+            a.sinT = reinterpret_cast<const uint32_t*>(ws + w.sinT);
+            const int total_q = (f.M + QTC - 1) / QTC, qb = f.wg_count > 0 ? 2 * f.wg_begin : 0;
+            const int qgrid = f.wg_count > 0 ? std::min(2 * f.wg_count, total_q - qb) : total_q;
+            const int wg256 = a.wg_begin;
+            a.wg_begin = qb;
+            static int n_cu = 0;
+            if (!n_cu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+            static const int stagger_q = getenv("NTF_DW_STAGGER") ? atoi(getenv("NTF_DW_STAGGER")) : -1;   // 10 ns ticks; default: half of a tile's main loop + epilogue
+            const int nib = g.Bpad / 32;
+            a.ntile = 2 * n_cu;
+            a.stagger = (f.adam && qgrid > n_cu) ? (stagger_q >= 0 ? stagger_q : (nib * 140 + 4500) / 2) : 0;
+            const size_t ldsq = 2 * ((size_t)QTC * 128 + 2 * 128 * 64 + (f.bayes ? 1024 : 0)) + 64;
+#define NTF_DWQ(BY, AD) do { auto kf = k_out_dw_q<BY, AD>;                                                                     \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq);     \
+            hipLaunchKernelGGL(kf, dim3(qgrid), dim3(64 * QW), ldsq, st, a); } while (0)
+            static const char* stamp_file = getenv("NTF_DW_STAMP_FILE");   // diagnostics: the 30th launch's per-wave stamps, raw (10 x u64 per wave), to this file
+            if (stamp_file && f.bayes && f.adam) {
+                static unsigned long long* d_st = nullptr; static int n_launch = 0;
+                if (!d_st) hipMalloc(&d_st, (size_t)qgrid * QW * 10 * 8);
+                a.stamps = d_st;
+                auto kf = k_out_dw_q<true, true, true>;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq);
+                hipLaunchKernelGGL(kf, dim3(qgrid), dim3(64 * QW), ldsq, st, a);
+                if (++n_launch == 30) {
+                    std::vector<unsigned long long> hst((size_t)qgrid * QW * 10);
+                    hipStreamSynchronize(st); hipMemcpy(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost);
+                    if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(hst.data(), 8, hst.size(), fp); fclose(fp); }
+                }
+            }
+            else if (f.bayes) { if (f.adam) NTF_DWQ(true, true); else NTF_DWQ(true, false); } else { if (f.adam) NTF_DWQ(false, true); else NTF_DWQ(false, false); }
+#undef NTF_DWQ
+            if (!guard) return;
+            a.rmode = 2; a.wg_begin = wg256; a.ntile = 0; a.stagger = 0;   // the exact-f32 kernel behind it runs only when the range flag is raised
             goto exact_f32;
         }
         const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0)) + 64;
@@ -3220,6 +3522,8 @@ void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, vo
     const int n = g.Bpad * H;
     hipLaunchKernelGGL(k_prep_planes_T, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(ws + w.hz), reinterpret_cast<const float*>(ws + w.hs),
                        bayes, g.Bpad, H, np == 2 ? 2 : 3, h_scale, reinterpret_cast<uint16_t*>(ws + w.hb));
+    if (bayes && H == 128 && np == 2)   // k_out_dw_q rebuilds the planes of h * s_in from these words
+        hipLaunchKernelGGL(k_sin_words_T, dim3((g.Bpad / 32 * 128 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(ws + w.sinbits), g.Bpad, reinterpret_cast<uint32_t*>(ws + w.sinT));
 }
 
 }  // namespace ntf

@@ -14,6 +14,7 @@ struct HeadArgs {
     double klw_w0 = 0.0, klw_b0 = 0.0; double* kl = nullptr;
     // outputs: act[0] (X), act[1] (h), and what k_prep_h / k_prep_planes_T leave in the fused workspace
     float *X = nullptr, *act1 = nullptr, *hz = nullptr, *hs = nullptr; uint32_t* sinbits = nullptr; uint16_t* hb = nullptr;   // hb null: no planes (no dW kernel follows)
+    uint32_t* sinT = nullptr;           // with hb: the s_in words of this K block in k_out_dw_q's bit order (k_sin_words_T)
     SignSpec si1;                       // the OUTPUT layer's s_in keys (h * s_in, s_in words)
     float h_scale = 1.f, h_limit = 0.f; int* rflag = nullptr;
     // operand producer of the output layer's bias (extra workgroups): bp1 = softplus(rho_b1) eps_b1, KL * klw_b1

@@ -233,6 +233,12 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
                 tile[(2 * HH + slot) * 16 + rp] = pq[0]; tile[(3 * HH + slot) * 16 + rp] = pq[1];
             }
         }
+        if (BAYES && p.sinT && tid < HH) {   // k_sin_words_T for this K block: bit order of k_out_dw_q's fragment masks
+            uint32_t w = 0u;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) w |= ((SW[r * 4 + (tid >> 5)] >> (tid & 31)) & 1u) << (16 * (r & 1) + 4 * (r >> 3) + 3 - ((r & 7) >> 1));
+            p.sinT[(size_t)blockIdx.x * HH + tid] = w;
+        }
     }
 }
 

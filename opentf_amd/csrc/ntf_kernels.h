@@ -57,7 +57,8 @@ void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out,
                             uint16_t* planes_w = nullptr, uint16_t* planes_mu = nullptr, const float* pmu = nullptr, int H = 0,
                             int np = 3 /*3: bf16 three-way planes, 2: fp16 two-way planes of value * pscale*/, float pscale = 1.f,
-                            int* rflag = nullptr /*np = 2: raised when a plane operand leaves the fp16 window*/);
+                            int* rflag = nullptr /*np = 2: raised when a plane operand leaves the fp16 window*/,
+                            const int* only_if = nullptr /*device flag: the launch does nothing unless it is non-zero (the f32 sigma * eps of a step on prefetched operands that falls back to the exact-f32 kernels)*/);
 // g_rho = gWp * eps * sigmoid(rho) + kl' ; g_mu += kl'   (KL of N(mu, sigma^2) against N(0,1), mean over n, times klw)
 void launch_flipout_grad_finalize(hipStream_t st, const float* mu, const float* rho, float* g_mu, float* g_rho /*in: gWp*/,
                                   int64_t n, NormalSpec eps, float klw);

@@ -254,7 +254,8 @@ void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict__ rho, const float* __restrict__ mu, int64_t n, NormalSpec eps,
                                                          float* __restrict__ out, double w, double* kl_out, uint16_t* __restrict__ planes_w,
                                                          uint16_t* __restrict__ planes_mu, const float* __restrict__ pmu, int H, int np, float pscale,
-                                                         int* __restrict__ rflag) {
+                                                         int* __restrict__ rflag, const int* __restrict__ only_if) {
+    if (only_if && __builtin_nontemporal_load(only_if) == 0) return;   // (the f32 copy of sigma * eps for a step that fell back to the exact-f32 kernels, see launch_flipout_perturb)
     const int64_t quads = (n + 3) / 4;
     float kl = 0.f, amax = 0.f;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -302,11 +303,11 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
     }
 }
 void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out,
-                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale, int* rflag) {
+                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale, int* rflag, const int* only_if) {
     if (n <= 0) return;
     const int64_t quads = (n + 3) / 4;
-    const int blocks = (int)std::min<int64_t>((quads + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale, (planes_w && np == 2) ? rflag : nullptr);
+    const int blocks = (int)std::min<int64_t>((quads + 255) / 256, only_if ? 1024 : 2048);
+    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale, (planes_w && np == 2) ? rflag : nullptr, only_if);
 }
 
 __global__ void k_flipout_grad_finalize(const float* __restrict__ mu, const float* __restrict__ rho, float* __restrict__ g_mu,
@@ -681,9 +682,7 @@ void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, i
 // Adam (torch.optim.Adam defaults, src/mdl/fnn.py:104,139) over the flat parameter buffer
 // =====================================================================================
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
-    m = m + (1.f - b1) * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * b2 + (1.f - b2) * g * g;               // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    p = p - lr_over_bc1 * (m / (sqrtf(v) / bc2_sqrt + eps));
+    adam_step(p, g, m, v, lr_over_bc1, b1, b2, eps, __builtin_amdgcn_rcpf(bc2_sqrt));   // (ntf_device.h; the reciprocal of the uniform bc2_sqrt is hoisted out of the callers' loops)
 }
 // 16-byte accesses (the segments of the flat buffers are 256-byte aligned and a multiple of 4 floats long up to a scalar tail): a quarter of
 // the memory instructions, which matters when this kernel runs on the side stream beside the dW kernel and competes for issue slots

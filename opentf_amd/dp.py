@@ -26,7 +26,10 @@ The engine argument is duck-typed (`stage_order`, `step_staged`, `apply`, `grad_
 """
 from __future__ import annotations
 
+import collections
+import datetime
 import os
+import time
 
 import numpy as np
 import torch
@@ -49,7 +52,63 @@ def shard_range(lo: int, hi: int, world: int):
 
 
 class _Done:
-    def wait(self): pass
+    def wait(self, timeout=None): pass
+    def is_completed(self): return True
+
+
+class CollectiveTimeout(RuntimeError):
+    """a collective (or the device work queued behind it) did not finish within NTF_COLLECTIVE_TIMEOUT_S: the caller must leave with a non-zero exit code"""
+
+
+def collective_timeout_s():
+    return float(os.environ.get("NTF_COLLECTIVE_TIMEOUT_S", "120"))
+
+
+class CollectiveTrace:
+    """Every collective a step issues, by name, in a short ring: a bounded wait that expires says which one completed last and which one it is stuck behind
+    (a hang on xGMI would otherwise be a silent `torch.cuda.synchronize()` that never returns).  RCCL's `Work.wait()` only orders streams - the host runs ahead by
+    design - so the waits that can be bounded on the host are the gloo ones and the device synchronisation at the end of a phase (`sync`)."""
+
+    def __init__(self, who):
+        self.who, self.ring, self.issued = who, collections.deque(maxlen=256), 0
+
+    def add(self, label, work):
+        self.issued += 1
+        self.ring.append((self.issued, label, work))
+        return work
+
+    def describe(self):
+        done = next((f"#{n} {lab}" for n, lab, w in reversed(self.ring) if _completed(w)), "none of the last %d" % len(self.ring))
+        stuck = next((f"#{n} {lab}" for n, lab, w in self.ring if not _completed(w)), "none (device work behind them)")
+        return f"last completed collective: {done}; first incomplete: {stuck}; issued: {self.issued}"
+
+    def wait(self, work):
+        try:
+            work.wait(timeout=datetime.timedelta(seconds=collective_timeout_s()))
+        except TypeError:
+            work.wait()
+        except RuntimeError as ex:
+            raise CollectiveTimeout(f"{self.who}: {type(ex).__name__}: {ex} [{self.describe()}]") from ex
+
+    def sync(self, what):
+        """host waits for everything queued on the current stream, at most NTF_COLLECTIVE_TIMEOUT_S"""
+        if not torch.cuda.is_available():
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        deadline, pause = time.monotonic() + collective_timeout_s(), 5e-5
+        while not ev.query():
+            if time.monotonic() > deadline:
+                raise CollectiveTimeout(f"{self.who}: {what} did not finish within {collective_timeout_s():.0f} s [{self.describe()}]")
+            time.sleep(pause)
+            pause = min(pause * 2, 2e-3)
+
+
+def _completed(work):
+    try:
+        return bool(work.is_completed())
+    except Exception:
+        return False
 
 
 class DataParallel:
@@ -71,13 +130,16 @@ class DataParallel:
         # gloo (the CPU tests) has no reduce-scatter: there it is an all-reduce of which this rank keeps its part - same result
         self._native_rs = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._pending = []   # parameter all-gathers of the previous step
+        self.trace = CollectiveTrace(f"DataParallel rank {self.rank}/{self.world}")
+        self._step_no = 0
         if self._grad.is_cuda and (self.world > 1 or self.force_allreduce) and hasattr(engine, "stream_handle"):
             assert engine.stream_handle is not None and torch.cuda.current_stream().cuda_stream == engine.stream_handle, \
                 "DataParallel must run under torch.cuda.stream(s) with the engine created on s: kernels and collectives are ordered through that one stream"
 
     # ---- collectives on [lo, hi) of the flat buffers
     def _all_reduce(self, lo, hi):
-        return dist.all_reduce(self._grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return self.trace.add(f"step {self._step_no} all_reduce grad[{lo}:{hi}]",
+                              dist.all_reduce(self._grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _reduce_scatter(self, lo, hi, owned, works):
         """sum over ranks of grad[lo:hi): this rank ends up with the reduced values of ITS part (and of the tail); records the part in
@@ -86,7 +148,8 @@ class DataParallel:
         if part:
             mine = (lo + self.rank * part, lo + (self.rank + 1) * part)
             if self._native_rs:
-                works.append(dist.reduce_scatter_tensor(self._grad[mine[0]:mine[1]], self._grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                works.append(self.trace.add(f"step {self._step_no} reduce_scatter grad[{lo}:{tail}]",
+                                            dist.reduce_scatter_tensor(self._grad[mine[0]:mine[1]], self._grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
             else:
                 works.append(self._all_reduce(lo, tail))
             owned.append(mine)
@@ -99,10 +162,11 @@ class DataParallel:
         if not part:
             return _Done()
         mine = self._param[lo + self.rank * part: lo + (self.rank + 1) * part]
+        label = f"step {self._step_no} all_gather param[{lo}:{tail}]"
         if self._native_rs:
-            return dist.all_gather_into_tensor(self._param[lo:tail], mine, group=self.group, async_op=True)
+            return self.trace.add(label, dist.all_gather_into_tensor(self._param[lo:tail], mine, group=self.group, async_op=True))
         parts = [self._param[lo + r * part: lo + (r + 1) * part] for r in range(self.world)]
-        return dist.all_gather(parts, mine.clone(), group=self.group, async_op=True)
+        return self.trace.add(label, dist.all_gather(parts, mine.clone(), group=self.group, async_op=True))
 
     def _skip(self, zero_grad=True):
         """this rank's shard of the global minibatch is empty (a last batch smaller than the world size): contribute a zero gradient and
@@ -113,13 +177,17 @@ class DataParallel:
             self.engine.skip_step()
 
     def _finish_gathers(self):
+        touched = bool(self._pending)
         for w in self._pending:
-            w.wait()
+            self.trace.wait(w)
         self._pending = []
+        if touched and hasattr(self.engine, "params_touched"):
+            self.engine.params_touched()      # the all-gather wrote the parameters through the raw view (include/opentf_amd.h: ntf_params_touched)
 
     def _train_step(self, goff, gB, lo, hi):
         """backward of this rank's shard of the batch + gradient exchange + Adam for one global minibatch"""
         e, have_rows = self.engine, hi > lo
+        self._step_no += 1
         self._finish_gathers()            # the parameters this step reads are complete
         works, owned, gathered = [], [], []
         reduce = (lambda a, b: self._reduce_scatter(a, b, owned, works)) if self.shard else (lambda a, b: works.append(self._all_reduce(a, b)))
@@ -144,7 +212,7 @@ class DataParallel:
             n = self._grad.numel()
             reduce(0, n); gathered.append((0, n))
         for w in works:
-            w.wait()
+            self.trace.wait(w)
         if not self.shard:
             e.apply()
             return
@@ -174,10 +242,13 @@ class DataParallel:
             else:
                 self._skip(zero_grad=False)
         self._finish_gathers()
+        if collective and self._grad.is_cuda:
+            self.trace.sync("the phase's kernels and collectives")      # bounded: the loss read-back below would wait for ever behind a hung collective
         s, _ = self.engine.epoch_loss()  # sum over steps of this rank's share of each batch loss
         t = torch.tensor([s], dtype=torch.float64, device=self._grad.device if self._grad.is_cuda else "cpu")
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.trace.wait(self.trace.add("phase loss all_reduce", dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            if t.is_cuda: self.trace.sync("the loss all_reduce")
         return float(t.item()) / max(steps, 1)
 
     def train_epoch(self, order, global_B):

@@ -27,6 +27,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .dp import CollectiveTrace
+
 TILE = 256  # experts: fused_dw_tile() of the engine
 
 
@@ -61,6 +63,8 @@ class ExpertParallel:
         # NTF_EP_FORCE_EXCHANGE=1: run the two-phase step and the all-reduce even at world_size 1 (exercises RCCL on a 1-GPU box)
         # two_phase: the two-phase step without any process group (bench.py --ep-emulate: one rank's compute on a 1-GPU box)
         self.force = bool(two_phase) or (dist.is_initialized() and os.environ.get("NTF_EP_FORCE_EXCHANGE", "0") == "1")
+        self.trace = CollectiveTrace(f"ExpertParallel rank {self.rank}/{self.world}")   # bounded waits that name the collective a hang sits behind (dp.py)
+        self._step_no = 0
         if self._dh is not None and self._dh.is_cuda and (self.world > 1 or self.force) and hasattr(engine, "stream_handle"):
             assert engine.stream_handle is not None and torch.cuda.current_stream().cuda_stream == engine.stream_handle, \
                 "ExpertParallel must run under torch.cuda.stream(s) with the engine created on s: kernels and the all-reduce are ordered through that one stream"
@@ -78,23 +82,29 @@ class ExpertParallel:
             B = min(global_B, n - off)
             steps += 1
             if train and exchange:
+                self._step_no += 1
                 e.step_staged_ep(off, B, 1)        # forward, loss, fix-up: this shard's partial d(hidden)
                 work = None
                 if self._dh is not None and dist.is_initialized():   # the one exchange; RCCL moves it on its own stream ...
-                    work = dist.all_reduce(self._dh[: B * self._H], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    work = self.trace.add(f"step {self._step_no} all_reduce d(hidden)[{B} x {self._H}]",
+                                          dist.all_reduce(self._dh[: B * self._H], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 e.step_staged_ep(off, B, 2)        # ... while this shard's output-layer backward (+ its Adam) runs
                 if work is not None:
-                    work.wait()                    # stream-ordered: the engine's stream waits, the host does not
+                    self.trace.wait(work)          # stream-ordered under RCCL: the engine's stream waits, the host does not (gloo: bounded host wait)
                 e.step_staged_ep(off, B, 3)        # hidden layers' backward + Adam, identical on every rank
             else:
                 e.step_staged(off, B, train=train, apply=train)   # evaluation needs no exchange: the loss shares are summed below
+        on_gpu = self._dh is not None and self._dh.is_cuda
+        if exchange and on_gpu:
+            self.trace.sync("the phase's kernels and all-reduces")      # bounded: everything below would wait for ever behind a hung collective
         if train and self.world > 1:
             self._resync_replicas()
         s, _ = e.epoch_loss()      # sum over steps of this shard's share of each batch loss
-        dev = self._dh.device if (self._dh is not None and self._dh.is_cuda) else ("cuda" if (dist.is_initialized() and dist.get_backend(self.group) == "nccl") else "cpu")
+        dev = self._dh.device if on_gpu else ("cuda" if (dist.is_initialized() and dist.get_backend(self.group) == "nccl") else "cpu")
         t = torch.tensor([s], dtype=torch.float64, device=dev)
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.trace.wait(self.trace.add("phase loss all_reduce", dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            if t.is_cuda: self.trace.sync("the loss all_reduce")
         return float(t.item()) / max(steps, 1)
 
     def _resync_replicas(self):
@@ -109,9 +119,11 @@ class ExpertParallel:
         end, _ = e.param_segment(e.L - 1, P_WEIGHT)     # segments are laid out layer by layer: [0, end) = the hidden layers
         if end > 0:
             src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
-            dist.broadcast(e.param_tensor()[:end], src=src, group=self.group)
+            self.trace.wait(self.trace.add("epoch-end broadcast of the replicated parameters", dist.broadcast(e.param_tensor()[:end], src=src, group=self.group, async_op=True)))
             if hasattr(e, "moment_tensors"):     # ... and Adam's moments of those layers: replicas that keep their own would drift apart again at once
-                for t in e.moment_tensors(): dist.broadcast(t[:end], src=src, group=self.group)
+                for t in e.moment_tensors():
+                    self.trace.wait(self.trace.add("epoch-end broadcast of the replicated Adam moments", dist.broadcast(t[:end], src=src, group=self.group, async_op=True)))
+            if hasattr(e, "params_touched"): e.params_touched()
 
     def train_epoch(self, order, global_B):
         return self._phase(order, global_B, True)

@@ -60,6 +60,7 @@ SYMBOLS = {
     "ntf_range_fallbacks": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_prefetched_steps": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_get_dlogits": (C.c_int, [_P, _P, _I64]),
+    "ntf_get_negatives": (C.c_int, [_P, _P, _I64]),
     "ntf_train_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_eval_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_backward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
@@ -84,6 +85,7 @@ SYMBOLS = {
     "ntf_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "ntf_moment_buffers": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_I64)]),
     "ntf_param_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "ntf_params_touched": (C.c_int, [_P]),
     "ntf_synchronize": (C.c_int, [_P]),
     "ntf_kernel_times": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     "ntf_rank_metrics": (C.c_int, [C.c_int, _P, _I64, _I32, _P, _P, _I64, _P, _P, _I32, _P]),
@@ -303,6 +305,12 @@ class Engine:
         self._ck(lib().ntf_get_dlogits(self._h, _ptr(out), out.size))
         return out
 
+    def negatives(self, B):
+        """the last step's sampled negatives [B, ns] (global expert ids)"""
+        out = np.empty((int(B), int(self.ns)), dtype=np.int64)
+        self._ck(lib().ntf_get_negatives(self._h, _ptr(out), out.size))
+        return out
+
     # ---- steps
     def _inject(self, inject, B):
         if not inject:
@@ -351,6 +359,10 @@ class Engine:
         """torch tensor aliasing the flat parameter buffer in HBM (what the sharded step all-gathers)"""
         import torch
         return torch.as_tensor(self.param_view(), device=f"cuda:{torch.cuda.current_device()}")
+
+    def params_touched(self):
+        """after writing parameters through param_tensor() / param_view(): drop operands a fused step prepared from the old values"""
+        self._ck(lib().ntf_params_touched(self._h))
 
     def moment_tensors(self):
         """torch tensors aliasing Adam's exp_avg / exp_avg_sq buffers (flat, the parameters' layout)"""

@@ -149,8 +149,8 @@ class KeyedVectors:
 class Doc2VecTables:
     """what `self.model` is after learn(): .dv / .docvecs (doc tags '0'..'N-1'), .wv (words), .syn1neg and the hyper-parameters"""
 
-    def __init__(self, dv, wv, syn1neg, word_keys, hyper):
-        self.dv = self.docvecs = KeyedVectors([str(i) for i in range(len(dv))], dv)
+    def __init__(self, dv, wv, syn1neg, word_keys, hyper, doc_keys=None):
+        self.dv = self.docvecs = KeyedVectors(doc_keys if doc_keys is not None else [str(i) for i in range(len(dv))], dv)
         self.wv = KeyedVectors(word_keys, wv)
         self.syn1neg = syn1neg
         for k, v in hyper.items(): setattr(self, k, v)
@@ -170,9 +170,16 @@ class D2v(T2v):
 
     def _load(self, path, n_teams):
         import torch
+        from . import gensim_reader
+        if gensim_reader.is_pickle(path):
+            # a file the REFERENCE trained (src/mdl/emb/d2v.py:58-63 loads it with gensim's Doc2Vec.load and skips training): read without gensim, same vectors
+            g = gensim_reader.read_doc2vec(path)
+            assert g["dv"].shape[0] == n_teams, f"Incorrect number of embeddings per team! {g['dv'].shape[0]} != {n_teams}"
+            self.model = Doc2VecTables(g["dv"], g["wv"], g["syn1neg"], g["wv_keys"], g["hyper"], doc_keys=g["dv_keys"])
+            return self
         ck = torch.load(path, map_location="cpu", weights_only=False)
         if not isinstance(ck, dict) or ck.get("format") != FORMAT:
-            raise RuntimeError(f"{path} was not written by opentf_amd.mdl.emb.d2v (a gensim Doc2Vec pickle?): remove it to retrain the vectors on the device")
+            raise RuntimeError(f"{path} is not a gensim Doc2Vec file and was not written by opentf_amd.mdl.emb.d2v: remove it to retrain the vectors on the device")
         dv = ck["dv"].numpy()
         assert dv.shape[0] == n_teams, f"Incorrect number of embeddings per team! {dv.shape[0]} != {n_teams}"
         self.model = Doc2VecTables(dv, ck["wv"].numpy(), ck["syn1neg"].numpy(), ck["word_keys"], ck["hyper"])

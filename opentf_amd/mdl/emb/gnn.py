@@ -80,6 +80,27 @@ def _barrier():
         dist.barrier()
 
 
+def _sync_torch_rng():
+    """rank 0's torch CPU generator state on every rank (a collective: also orders the ranks behind rank 0's file writes)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    box = [torch.get_rng_state() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if dist.get_rank() != 0: torch.set_rng_state(box[0])
+
+
+def _rank0_says(flag):
+    """rank 0's value of a bool on every rank (file-system checks that must come out the same job-wide)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(flag)
+    box = [bool(flag)]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 class Gnn(T2v):
     def __init__(self, output, device, seed, cfg, model):
         super().__init__(output, device, seed, cfg, model)
@@ -110,9 +131,7 @@ class Gnn(T2v):
         os.makedirs(self.output, exist_ok=True)
         skill = teamsvecs.get("original_skill", teamsvecs["skill"]) if hasattr(teamsvecs, "get") else teamsvecs["skill"]
         member = teamsvecs["member"]
-        d, b, lr = int(cfg_get(m, "d")), int(cfg_get(m, "b")), float(cfg_get(m, "lr"))
-        wl, ctx, wn, ns = int(cfg_get(m, "wl")), int(cfg_get(m, "w")), int(cfg_get(m, "wn")), int(cfg_get(m, "ns"))
-        spe = cfg_get(m, "spe")
+        d = int(cfg_get(m, "d"))
         w = None
         for foldidx in splits["folds"].keys():
             drop = np.concatenate([np.asarray(splits["test"]), np.asarray(splits["folds"][foldidx]["valid"])])
@@ -121,53 +140,66 @@ class Gnn(T2v):
             init = torch.nn.Embedding(n, d).weight.detach().numpy()       # the draw Node2Vec's constructor makes (gnn.py:153-160)
             path = f"{self.output}/f{foldidx}.pt"
             _barrier()                                                     # torchrun: nobody looks for the file while rank 0 may still be writing the previous one
-            if os.path.exists(path):                                       # gnn.py:402-405: a trained table is loaded, not retrained
-                ck = torch.load(path, map_location="cpu", weights_only=False)
-                # only tables THIS plugin saved: the rows are sliced as [skills | members | teams] (stm_graph).  The reference orders its node stores by iterating a Python
-                # set (src/mdl/emb/gnn.py:29-47: the order depends on PYTHONHASHSEED and lives in its pickled graph) - such a file would be sliced wrong without an error
-                if ck.get("node_order") != NODE_ORDER or tuple(ck.get("node_offsets", ())) != (off["skill"], off["member"], off["team"], n):
-                    raise RuntimeError(f"{path} was not written by opentf_amd.mdl.emb.gnn (no / another node order): remove it to retrain the table on the device")
-                log.info(f"Loading the model {path} ...")
-                self.model = ck["model_state_dict"]["embedding.weight"].numpy()
-                continue
-            if w is None: w = self.writer(log_dir=f"{self.output}/logs4tboard/run_{int(time.time())}")
-            val_src, val_dst = member_team_edges(member, splits["folds"][foldidx]["valid"], off)
-            assert len(val_src), "Empty valid member-team edge set!"
-            net = libntf.Node2Vec(rowptr, col, init, seed=int(self.seed or 0) + 7919 * int(foldidx), device=parse_devices(self.device)[0])
-            scheduler = PlateauLR(lr, factor=0.1, patience=2)
-            earlystopping = EarlyStopping(patience=int(cfg_get(m, "es")), verbose=True, delta=0, trace_func=log.info)
-            cur_lr, e, t_loss, v_loss = lr, -1, 0.0, 0.0
-            for e in range(int(cfg_get(m, "e"))):
-                order = index_order(n, b, True)                            # DataLoader(range(num_nodes), batch_size=b, shuffle=True)
-                nb, t_loss = 0, 0.0
-                for o in range(0, n, b):
-                    t_loss += net.train_batch(order[o:o + b], wl, ctx, wn, ns, cur_lr); nb += 1
-                t_loss /= nb
-                v_loss = net.edge_bce(val_src, val_dst) / len(val_src)     # the reference divides the mean once more (gnn.py:433)
-                w.add_scalar(tag=f"{foldidx}_t_loss", scalar_value=t_loss, global_step=e)
-                w.add_scalar(tag=f"{foldidx}_v_loss", scalar_value=v_loss, global_step=e)
-                log.info(f"Fold {foldidx}/{len(splits['folds']) - 1}, Epoch {e}, Train Loss: {t_loss:.4f}, Valid Loss: {v_loss:.4f}")
-                if spe and (e == 0 or ((e + 1) % spe) == 0):
-                    self._save(net.weight(), foldidx, e, t_loss, v_loss, f"{self.output}/f{foldidx}.e{e}.pt")
-                cur_lr = scheduler.step(v_loss)
-                if earlystopping(v_loss, None).early_stop:
-                    log.info(f"Early stopping triggered at epoch: {e}")
-                    break
-            self.model = net.weight()
-            net.close()
-            self._save(self.model, foldidx, e, t_loss, v_loss, path)
+            if not _rank0_says(os.path.exists(path)):                      # gnn.py:402-405: a trained table is loaded, not retrained (rank 0 decides for the job)
+                # ONE trainer (as d2v.py): the table's gradient sums are f32 atomics - run per rank, losses, early-stop epochs and tables would differ between
+                # the ranks - and no collective sits inside a loop whose trip count a rank decides for itself; the other ranks wait below and read rank 0's file
+                if dist_rank() == 0:
+                    if w is None: w = self.writer(log_dir=f"{self.output}/logs4tboard/run_{int(time.time())}")
+                    self._train_fold(libntf, rowptr, col, init, n, member, splits, foldidx, off, m, w, path)
+                _sync_torch_rng()                                          # (also the barrier) the trainer's loader shuffles consumed torch's CPU generator: the next fold's initial draw stays job-wide
+            self.model = self._load_fold(path, off, n)
         if w is not None: w.close()
 
-    def _save(self, weight, foldidx, e, t_loss, v_loss, path):
+    def _train_fold(self, libntf, rowptr, col, init, n, member, splits, foldidx, off, m, w, path):
+        """`_train_rw` (gnn.py:401-453) for one fold on this rank's device; writes f{k}.e{e}.pt / f{k}.pt"""
+        b, lr = int(cfg_get(m, "b")), float(cfg_get(m, "lr"))
+        wl, ctx, wn, ns = int(cfg_get(m, "wl")), int(cfg_get(m, "w")), int(cfg_get(m, "wn")), int(cfg_get(m, "ns"))
+        spe = cfg_get(m, "spe")
+        val_src, val_dst = member_team_edges(member, splits["folds"][foldidx]["valid"], off)
+        assert len(val_src), "Empty valid member-team edge set!"
+        net = libntf.Node2Vec(rowptr, col, init, seed=int(self.seed or 0) + 7919 * int(foldidx), device=parse_devices(self.device)[0])
+        scheduler = PlateauLR(lr, factor=0.1, patience=2)
+        earlystopping = EarlyStopping(patience=int(cfg_get(m, "es")), verbose=True, delta=0, trace_func=log.info)
+        cur_lr, e, t_loss, v_loss = lr, -1, 0.0, 0.0
+        for e in range(int(cfg_get(m, "e"))):
+            order = index_order(n, b, True)                            # DataLoader(range(num_nodes), batch_size=b, shuffle=True)
+            nb, t_loss = 0, 0.0
+            for o in range(0, n, b):
+                t_loss += net.train_batch(order[o:o + b], wl, ctx, wn, ns, cur_lr); nb += 1
+            t_loss /= nb
+            v_loss = net.edge_bce(val_src, val_dst) / len(val_src)     # the reference divides the mean once more (gnn.py:433)
+            w.add_scalar(tag=f"{foldidx}_t_loss", scalar_value=t_loss, global_step=e)
+            w.add_scalar(tag=f"{foldidx}_v_loss", scalar_value=v_loss, global_step=e)
+            log.info(f"Fold {foldidx}/{len(splits['folds']) - 1}, Epoch {e}, Train Loss: {t_loss:.4f}, Valid Loss: {v_loss:.4f}")
+            if spe and (e == 0 or ((e + 1) % spe) == 0):
+                self._save(net.weight(), foldidx, e, t_loss, v_loss, f"{self.output}/f{foldidx}.e{e}.pt")
+            cur_lr = scheduler.step(v_loss)
+            if earlystopping(v_loss, None).early_stop:
+                log.info(f"Early stopping triggered at epoch: {e}")
+                break
+        weight = net.weight()
+        net.close()
+        self._save(weight, foldidx, e, t_loss, v_loss, path)
+
+    def _load_fold(self, path, off, n):
         import torch
-        if dist_rank() == 0:   # keys and order of gnn.py:445,453, + the node order the rows are sliced by; written whole, then moved into place
-            off = self.offsets
-            tmp = f"{path}.tmp.{os.getpid()}"
-            torch.save({"model_state_dict": {"embedding.weight": torch.from_numpy(np.ascontiguousarray(weight))}, "cfg": self.cfg, "f": foldidx, "e": e,
-                        "t_loss": t_loss, "v_loss": v_loss, "node_order": NODE_ORDER,
-                        "node_offsets": (off["skill"], off["member"], off["team"], int(weight.shape[0]))}, tmp)
-            os.replace(tmp, path)
-        _barrier()
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        # only tables THIS plugin saved: the rows are sliced as [skills | members | teams] (stm_graph).  The reference orders its node stores by iterating a Python
+        # set (src/mdl/emb/gnn.py:29-47: the order depends on PYTHONHASHSEED and lives in its pickled graph) - such a file would be sliced wrong without an error
+        if ck.get("node_order") != NODE_ORDER or tuple(ck.get("node_offsets", ())) != (off["skill"], off["member"], off["team"], n):
+            raise RuntimeError(f"{path} was not written by opentf_amd.mdl.emb.gnn (no / another node order): remove it to retrain the table on the device")
+        log.info(f"Loading the model {path} ...")
+        return ck["model_state_dict"]["embedding.weight"].numpy()
+
+    def _save(self, weight, foldidx, e, t_loss, v_loss, path):
+        """keys and order of gnn.py:445,453, + the node order the rows are sliced by; written whole, then moved into place.  Called by the training rank only: no collective"""
+        import torch
+        off = self.offsets
+        tmp = f"{path}.tmp.{os.getpid()}"
+        torch.save({"model_state_dict": {"embedding.weight": torch.from_numpy(np.ascontiguousarray(weight))}, "cfg": self.cfg, "f": foldidx, "e": e,
+                    "t_loss": t_loss, "v_loss": v_loss, "node_order": NODE_ORDER,
+                    "node_offsets": (off["skill"], off["member"], off["team"], int(weight.shape[0]))}, tmp)
+        os.replace(tmp, path)
 
     def _node_emb(self, teamsvecs, node_type):
         if self.model is None:

@@ -165,3 +165,35 @@ def test_infer_vec_lands_among_the_documents_of_its_topic():
         assert iv.shape == (64,) and len(near) == 10
         hits += sum(topic[int(k)] == tp for k, _ in near)
     assert hits >= 30, hits          # 40 neighbours in all, 25 % would be chance
+
+
+def test_a_doc2vec_file_the_reference_trained_is_loaded_without_gensim(tmp_path):
+    """src/mdl/emb/d2v.py:58-63: an existing `{output}/{modelstr}/{modelstr}.pt` is `Doc2Vec.load`ed and training is skipped.  The fixture is the file the reference's
+    authors committed for toy dblp (output/dblp/toy.dblp.v12.json/splits.f3.r0.85/d2v.d128.e100.w5.dm1.skill/, a gensim 4.3.3 pickle): the plugin reads it with its own
+    restricted unpickler (no gensim here) and hands `main.py` the committed team vectors bit for bit"""
+    import pickle
+    import shutil
+    here = os.path.dirname(__file__)
+    stem = "d2v.d128.e100.w5.dm1.skill"
+    os.makedirs(tmp_path / stem)
+    shutil.copy(os.path.join(here, "golden", f"ref_toy_dblp_{stem}.pt"), tmp_path / stem / f"{stem}.pt")
+    toy = np.load(os.path.join(here, "golden", "toy_dblp.npz"))
+    n, S, M = [int(v) for v in toy["shape"]]
+    tv = {"skill": scipy.sparse.csr_matrix((np.ones(len(toy["skill_indices"]), np.uint8), toy["skill_indices"], toy["skill_indptr"]), shape=(n, S)).tolil(),
+          "member": scipy.sparse.csr_matrix((np.ones(len(toy["member_indices"]), np.uint8), toy["member_indices"], toy["member_indptr"]), shape=(n, M)).tolil()}
+    cfg = {"embtype": "skill", "dm": 1, "w": 5, "d": 128, "e": 100, "lr": 0.001, "spe": 10}
+    t = P.D2v(str(tmp_path), "cuda:0", 0, cfg, "d2v").learn(tv, None)          # (no device is touched: the file is found)
+    assert t.output == f"{tmp_path}/{stem}"
+    X = t.get_dense_vecs(tv, "skill")
+    assert X.dtype == np.float32 and np.array_equal(X, Z["dblp_final_dv"])
+    assert np.array_equal(t.model.wv.vectors, Z["dblp_final_wv"]) and np.array_equal(t.model.syn1neg, Z["dblp_final_syn1neg"])
+    assert t.model.wv.index_to_key == [f"s{k}" for k in Z["dblp_keys"]] and t.model.alpha == float(Z["dblp_final_alpha"])
+    assert t.model.vector_size == 128 and t.model.window == 5 and t.model.dm == 1 and t.model.negative == 5
+    assert P.D2v.natsortvecs(t.model.wv).shape == (len(Z["dblp_keys"]), 128)
+    v, near = t.infer_vec(["s1", "s5"])                                          # d2v.py:96-98 on the loaded tables
+    assert v.shape == (128,) and len(near) > 0
+    # the reader resolves numpy + a few builtins + inert stand-ins for gensim's classes, nothing else
+    from opentf_amd.mdl.emb import gensim_reader
+    evil = tmp_path / "evil.pt"
+    with open(evil, "wb") as f: f.write(b"\x80\x02cos\nsystem\n(S'true'\ntR.")        # a pickle that would call os.system
+    with pytest.raises(pickle.UnpicklingError, match="refusing"): gensim_reader.read_doc2vec(str(evil))

