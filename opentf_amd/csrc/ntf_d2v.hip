@@ -40,7 +40,8 @@ static thread_local std::string g_d2v_create_error;
 extern "C" const char* ntf_d2v_last_error(const ntf_d2v* h) { return h ? h->err.c_str() : g_d2v_create_error.c_str(); }
 
 namespace {
-constexpr int D2V_MAXK = 1024;      // kept words of one document a wave holds (gensim's own cap is 10 000 words per document); longer documents are cut there
+constexpr int D2V_RING = 1024;      // kept words of a document a wave holds at a time: a ring filled on demand, 64 raw words per step, just ahead of the window it is read through
+constexpr int D2V_MAX_DOC = 10000;  // gensim's cap (doc2vec_inner.pyx MAX_DOCUMENT_LEN): the words of a document that survive the subsampling are collected up to this many
 constexpr float D2V_MAX_EXP = 6.f;
 enum { SLOT_KEEP = 0, SLOT_WINDOW = 1, SLOT_NEG0 = 2, SLOT_NEG1 = 3 };
 
@@ -102,11 +103,9 @@ __device__ __forceinline__ void d2v_unit(const D2vArgs& a, const float (&x)[NV],
 
 template <int NV>
 __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
-    __shared__ int s_kept[4][D2V_MAXK];
-    __shared__ unsigned char s_win[4][D2V_MAXK];
+    __shared__ int s_kept[4][D2V_RING];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     int* kept = s_kept[wv_id];
-    unsigned char* bwin = s_win[wv_id];
     const int64_t first = a.serial ? 0 : (int64_t)blockIdx.x * 4 + wv_id;
     const int64_t stride = a.serial ? 1 : (int64_t)gridDim.x * 4;
     if (a.serial && (blockIdx.x != 0 || wv_id != 0)) return;
@@ -116,25 +115,29 @@ __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
         const float alpha = (float)(a.alpha_start - (a.alpha_start - a.alpha_end) * (a.progress ? a.progress[rank] : (double)rank / (double)a.n_docs));
         const int64_t p0 = a.doc_ptr[doc];
         const int L = (int)(a.doc_ptr[doc + 1] - p0);
-        // ---- words that survive the frequent-word subsampling (sample_int >= draw), in order
-        int K = 0;
-        for (int base = 0; base < L && K < D2V_MAXK; base += 64) {
-            const int p = base + lane;
-            int wd = 0; bool keep = false;
-            if (p < L) { wd = a.words[p0 + p]; keep = a.sample_int[wd] >= d2v_draw(a, doc, p, 0, SLOT_KEEP).x; }
-            const unsigned long long m = __ballot(keep);
-            const int at = K + __popcll(m & ((1ull << lane) - 1ull));
-            if (keep && at < D2V_MAXK) kept[at] = wd;
-            K = min(K + (int)__popcll(m), D2V_MAXK);
-        }
-        for (int i = lane; i < K; i += 64) bwin[i] = (unsigned char)(d2v_draw(a, doc, i, 0, SLOT_WINDOW).x % (uint32_t)a.window);
-        __builtin_amdgcn_wave_barrier();
+        // ---- words that survive the frequent-word subsampling (sample_int >= draw), in order: compacted by ballot into a RING, 64 raw words per step, filled just
+        //      far enough ahead of position i for its window (i + window) - a document of any length needs 1 024 slots (round 3 held the whole kept list in LDS and
+        //      silently cut documents at 1 024 kept words; gensim's cap is 10 000: embtype member / skillmember on gith, uspt)
+        int K = 0, base = 0;               // kept words compacted so far (<= D2V_MAX_DOC), raw words scanned so far
         float dreg[NV];
         float* drow = a.dv + doc * a.d;
 #pragma unroll
         for (int q = 0; q < NV; ++q) dreg[q] = drow[lane + 64 * q];
-        for (int i = 0; i < K; ++i) {
-            const int b = bwin[i], word = kept[i];
+        for (int i = 0;; ++i) {
+            while (K < i + a.window + 1 && base < L && K < D2V_MAX_DOC) {
+                const int p = base + lane;
+                int wd = 0; bool keep = false;
+                if (p < L) { wd = a.words[p0 + p]; keep = a.sample_int[wd] >= d2v_draw(a, doc, p, 0, SLOT_KEEP).x; }
+                const unsigned long long m = __ballot(keep);
+                const int at = K + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && at < D2V_MAX_DOC) kept[at & (D2V_RING - 1)] = wd;         // (slots older than i - window are dead: K - (i - window) <= 2 window + 64 < D2V_RING)
+                K = min(K + (int)__popcll(m), D2V_MAX_DOC);
+                base += 64;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (i >= K) break;
+            const int b = (int)(d2v_draw(a, doc, i, 0, SLOT_WINDOW).x % (uint32_t)a.window), word = kept[i & (D2V_RING - 1)];
+            // (K is final here whenever it bounds the window: K < i + window + 1 only once every raw word has been scanned or the cap is reached)
             const int lo = max(0, i - a.window + b), hi = min(K, i + a.window + 1 - b);
             float work[NV];
             if (dm) {
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
                 for (int q = 0; q < NV; ++q) l1[q] = dreg[q];
                 for (int m = lo; m < hi; ++m) {
                     if (m == i) continue;
-                    const float* r = a.wv + (int64_t)kept[m] * a.d;
+                    const float* r = a.wv + (int64_t)kept[m & (D2V_RING - 1)] * a.d;
 #pragma unroll
                     for (int q = 0; q < NV; ++q) l1[q] += d2v_ld(r + lane + 64 * q);
                 }
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
                 for (int q = 0; q < NV; ++q) dreg[q] += work[q];
                 for (int m = lo; m < hi; ++m) {
                     if (m == i) continue;
-                    float* r = a.wv + (int64_t)kept[m] * a.d;
+                    float* r = a.wv + (int64_t)kept[m & (D2V_RING - 1)] * a.d;
 #pragma unroll
                     for (int q = 0; q < NV; ++q) unsafeAtomicAdd(r + lane + 64 * q, work[q]);
                 }
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
                 int u = 0;
                 for (int m = lo; m < hi; ++m) {
                     if (m == i) continue;
-                    float* r = a.wv + (int64_t)kept[m] * a.d;
+                    float* r = a.wv + (int64_t)kept[m & (D2V_RING - 1)] * a.d;
                     float x[NV];
 #pragma unroll
                     for (int q = 0; q < NV; ++q) x[q] = d2v_ld(r + lane + 64 * q);

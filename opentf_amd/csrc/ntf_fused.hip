@@ -36,7 +36,7 @@ static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 int fused_ldb(int B) { return rup(B, BM); }
 int fused_dw_tile() { return DW_TC; }
 int64_t fused_dw_part_floats(int M, int H, int ksplit) { return (int64_t)ksplit * 2 * ((int64_t)rup(M, DW_TC) * (H + 1)); }
-int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 63) / 64 * 64 * H * 3; }   // rows padded to the 64-expert tile of k_out_fwd_h3w
+int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 63) / 64 * 64 * H * 3; }   // rows padded to the 64-expert tile of k_out_fwd_h3x
 bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
 int fused_loss_slots(int) { return 0; }
 
@@ -57,7 +57,7 @@ static Geom geom(int B, int M) {
     g.nCB = rup((M + 31) / 32, 2);
     return g;
 }
-int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)2 * NCG_MAX * BM * H; }   // x2: k_out_fwd_rs writes one slab set per role
+int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)NCG_MAX * BM * H; }
 
 struct WsLayout { size_t sbits, sbitsT, sinbits, sinT, hs, hz, lossp, hb, total; };
 static WsLayout ws_layout(int Bmax, int H, int M) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct SpecialArgs {
     int B, M, Bpad, NCG, nCB, ns;
-    int nslab;   // dh slabs to sum (NCG, or 2 NCG behind k_out_fwd_rs)
+    int nslab;   // dh slabs to sum (NCG)
     const float *h, *hs, *mu, *mu_b, *wp, *bp, *slab, *lossp, *h_mask;
     const uint32_t *sbits, *sinbits;
     const int64_t *rows, *m_indptr, *neg; const int32_t* m_indices;
@@ -614,13 +614,12 @@ struct DwArgs {
     int* rflag; int rmode;   // fp16x3 range guard, see OutFwdArgs
     const uint32_t* sT;      // k_sign_words_T image (fp16x3 packed path)
     const uint32_t* sinT;    // k_sin_words_T image: s_in signs of (K block, hidden unit) over the block's 32 rows (k_out_dw_q)
-    int ablate;              // diagnostics (NTF_DW_ABLATE): 1 no epilogue memory traffic, 2 no MFMAs, 4 no DMA after the first K block, 8 no barrier waits on DMA
     const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
     // split-K (k_out_dw_p2 only): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
     // contiguous part of the K blocks into part[(split * 2 + matrix) * slab ..] (bias sums behind the slabs); k_out_dw_finish adds the parts and runs the epilogue
     int ksplit; float* part; int64_t slab;
-    unsigned long long* stamps;   // diagnostics (k_out_dw_p2<.., STAMP>)
+    unsigned long long* stamps;   // diagnostics (k_out_dw_q<.., STAMP>, NTF_DW_STAMP_FILE)
     int ntile, stagger;   // k_out_dw_p2, unsplit: expert tiles of this launch (walked by persistent workgroups), start delay of every second workgroup (100 MHz ticks)
     // produce != 0 (fused Adam, Flipout, fp16x3 planes): the epilogue holds the UPDATED mu' / rho' of its elements - it also is the next step's operand producer:
     // eps' (Philox keyed by step + 1), Wp' = softplus(rho') eps' (f32, in place over this step's Wp), the fp16 split planes of Wp' and mu' that the forward kernel
@@ -1024,28 +1023,18 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_b6(DwArgs p) {   //
             if (hg + 1 < NHG) load_b(hg + 1, bq[(hg + 1) & 1]);
             asm volatile("" ::: "memory");   // keep the prefetch above this half-group's MFMAs
             const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
-            if (p.ablate & 2) {   // scalar elements only: the host pass parses this body too
-                asm volatile("" :: "v"(bq[hg & 1][0][0]), "v"(bq[hg & 1][1][3]), "v"(a[ks][0][0]), "v"(a[ks][1][3]));
-                if (BAYES) asm volatile("" :: "v"(as[ks][0][0]), "v"(as[ks][1][3]));
-            }
-            else if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
+            if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
             else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
             if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);   // before the first k-step-1 half-group; its vector work runs in the shadow of the following MFMAs
             // next K block: DMA issue + sign words in the middle of the MFMA phase, not in front of it — the two waves of a SIMD leave
             // every barrier in phase, and vector work bunched at the top of the iteration would meet the partner's vector work there
-            if (hg == (NP == 2 ? 0 : NHG / 2) && ib + 1 < nib) { if (!(p.ablate & 4)) stage(ib + 1, buf ^ 1); if (BAYES && !p.so_inj) word_next = sign_col_word(ib + 1); }   // fp16x3: the K block is short, give the DMA all of it
+            if (hg == (NP == 2 ? 0 : NHG / 2) && ib + 1 < nib) { stage(ib + 1, buf ^ 1); if (BAYES && !p.so_inj) word_next = sign_col_word(ib + 1); }   // fp16x3: the K block is short, give the DMA all of it
         }
         if (BAYES && p.so_inj && ib + 1 < nib) word_next = sign_col_word(ib + 1);   // injected signs (tests): a visible load, kept out of the MFMA phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next K block (DMA) has landed
         __syncthreads();
     }
 
-    if (p.ablate & 1) {   // keep the accumulators alive, touch no memory
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) { asm volatile("" :: "v"(acc1[jt][0]), "v"(acc1[jt][15])); asm volatile("" :: "v"(acc2[jt][0]), "v"(acc2[jt][15])); }
-        if (sum1 == 123.456f) p.g_b[0] = sum2;
-        return;
-    }
     // each half of the wave summed its 8 of every 16 batch rows
     sum1 += __shfl_xor(sum1, 32, 64);
     sum2 += __shfl_xor(sum2, 32, 64);
@@ -1202,8 +1191,9 @@ __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
 // ds_read_b128 + eight v_perm_b32 instead of an f32 split (the round-1 kernel spent a third of its time on that vector work: with MFMAs, DMA and
 // epilogue ablated it still took 0.20 of 0.63 ms); the s_out words come transposed from k_sign_words_T (one ds_read_b32 per K block instead of a
 // hash + five shuffle stages); the bias gradients are v_dot2_f32_f16 sums over the plane registers.
-// STAMP (diagnostics, NTF_DW_STAMP): s_memtime sums per wave - K-block bodies, their end-of-block DMA wait + barrier, the epilogue - written to p.stamps
-template <bool BAYES, bool ADAM, bool STAMP = false>
+// Since round 4 the unsplit launch of a whole step runs k_out_dw_q (below); this kernel stays as its A/B form (NTF_DW_KERNEL=0) and as the split-K kernel of narrow
+// expert shards.  (Round 3's persistent-grid / staggered-start / phase-stamp variants of it measured no gain and are gone: DESIGN.md section 4.)
+template <bool BAYES, bool ADAM>
 __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128, NJT = 4, NP = 2;
@@ -1218,28 +1208,18 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     const bool split = p.ksplit > 1;
     if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) {
         // the step runs in exact f32 (see k_out_fwd_h3x): the f32 kernel's body for this tile, here; the split-K form leaves it to the launch behind the finish kernel
-        if (!split && p.ntile == (int)gridDim.x) { DwArgs q = p; q.rmode = 0; out_dw_f32_body<128, BAYES, ADAM>(q, smem); }
+        if (!split) { DwArgs q = p; q.rmode = 0; out_dw_f32_body<128, BAYES, ADAM>(q, smem); }
         return;
     }
-    // Unsplit: workgroups walk the launch's expert tiles with stride gridDim.x (default grid = the tile count: one tile each).  A tile is a main loop followed by
-    // an HBM-bound epilogue (Adam in place + the next step's operands: 64 B per mu / rho pair), and with every workgroup in the same phase at the same time
-    // neither hides the other.  Round 3 tried the obvious cure - persistent workgroups (NTF_DW_PGRID=256), every second one of an XCD starting p.stagger ticks
-    // late (NTF_DW_STAGGER, 10 ns ticks per K block), the next tile's first K block issued before the epilogue - and measured NO gain (persistent: same time;
-    // staggered: +2 % per 75 ticks): a workgroup's epilogue keeps 8 waves x 7 KB of loads in flight = 22 GB/s per CU at ~2.5 us latency, which is 5.6 TB/s with
-    // all 256 CUs in it and still 22 GB/s per CU with half of them.  Kept as an option; the default is one tile per workgroup.
-    const int ntile = split ? (int)gridDim.x / p.ksplit : p.ntile;
+    const int ntile = split ? (int)gridDim.x / p.ksplit : (int)gridDim.x;
     const int ksi = split ? (int)blockIdx.x / ntile : 0;                  // which K range (the splits of one tile sit ntile workgroups apart)
-    const int tile0 = split ? (int)blockIdx.x % ntile : (int)blockIdx.x, tstride = split ? ntile : (int)gridDim.x;
+    const int tile = split ? (int)blockIdx.x % ntile : (int)blockIdx.x;
     const int crow = wave * 32 + il;
     const int nib = p.Bpad / 32;
     const int ib0 = split ? (int)((int64_t)ksi * nib / p.ksplit) : 0, ib1 = split ? (int)((int64_t)(ksi + 1) * nib / p.ksplit) : nib;
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char* hb = reinterpret_cast<const char*>(p.hb);
-    if (!split && p.stagger > 0 && (((int)blockIdx.x >> 3) & 1)) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)p.stagger) __builtin_amdgcn_s_sleep(32);
-    }
 
     const h2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
     constexpr int NA = TA / 1024 / DW_WAVES, NB = (TB / 1024 + DW_WAVES - 1) / DW_WAVES;   // DMA pieces per wave: 4 of the dz tile, 2 or 4 of the planes
@@ -1266,20 +1246,9 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
 #pragma unroll
         for (int n = 0; n < NA + NB; ++n) stage_piece(c0, ib, buf, n);
     };
-    unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0;
-    auto stamp = [&](int slot) {
-        if (!STAMP) return;
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long tnow;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (slot >= 0) st_sum[slot] += tnow - st_prev;
-        st_prev = tnow;
-    };
     float nx_kl = 0.f, nx_amax = 0.f;
-    if (tile0 < ntile) stage((p.wg_begin + tile0) * DW_TC, ib0, 0);
-    for (int tile = tile0; tile < ntile; tile += tstride) {
     const int c0 = (p.wg_begin + tile) * DW_TC;
+    stage(c0, ib0, 0);
     const int c = c0 + crow;
     f32x16 acc1[NJT], acc2[NJT];
 #pragma unroll
@@ -1350,16 +1319,11 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
                 }
             }
         }
-        stamp(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(1);
         __syncthreads();
-        stamp(2);
     };
-    stamp(-1);
     for (int ib = ib0; ib < ib1 - 1; ++ib) k_block(ib, std::true_type{});
     k_block(ib1 - 1, std::false_type{});
-    if (tile + tstride < ntile) stage((p.wg_begin + tile + tstride) * DW_TC, ib0, 0);   // both stages are dead: the next tile's first K block lands under the epilogue
     sum1 += __shfl_xor(sum1, 32, 64);
     sum2 += __shfl_xor(sum2, 32, 64);
     const float inv_a = 1.f / p.a_scale;
@@ -1383,9 +1347,6 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + idx0, s2);
         } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
-    }
-    stamp(3);
-    if (STAMP && p.stamps && lane == 0) { for (int q = 0; q < 4; ++q) p.stamps[((int64_t)blockIdx.x * DW_WAVES + wave) * 4 + q] = st_sum[q]; }
     if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
 }
 
@@ -1946,275 +1907,20 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
 }
 
 // ------------------------------------------------------------------------------------------------
-// Training forward (loss + dz + dh) in fp16x3 with 64-expert tiles: two 32-expert sub-tiles u per tile give every stretch of vector
-// work a stretch of independent MFMAs to run under — the schedule the f32 kernel (k_out_fwd) was built on:
-//   zT(u=0) | zT(u=1) + epilogue(u=0) + split(u=0) | dh(u=0) + epilogue(u=1) + split(u=1) | dh(u=1)
-// Two LDS stages of 2 matrices x 2 planes x [64 rows][256 B] (+ biases) = 2 x 64.5 KiB; everything else as in k_out_fwd_b6<.., NP = 2>.
-// ------------------------------------------------------------------------------------------------
-template <bool BAYES, bool INJ>
-__global__ __launch_bounds__(256, 1) void k_out_fwd_h3w(OutFwd6Args pp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const OutFwdArgs& p = pp.a;
-    constexpr int H = 128, NJT = 4, NKS = H / 16, NP = 2, BNT = 64;
-    constexpr int PLANE = BNT * H * 2;          // 16 KiB
-    constexpr int TM = NP * PLANE;              // one matrix of a tile
-    constexpr int NMAT = BAYES ? 2 : 1;
-    constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    if (range_guard_skip(p.rflag, p.rmode, false)) return;
-
-    int bid = blockIdx.x;
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int cg = bid / p.NRB, rb = bid % p.NRB;
-    const int t_beg = (int)((int64_t)cg * p.T / p.NCG), t_end = (int)((int64_t)(cg + 1) * p.T / p.NCG);   // p.T = 64-expert tiles
-    const int i0 = rb * BM + wave * 32;
-    const int i = i0 + il;
-    const bool row_ok = i < p.B;
-
-    u32x4 hp[NKS][3];
-    uint32_t sinw[NJT];
-#pragma unroll
-    for (int w = 0; w < NJT; ++w)
-        sinw[w] = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) : 0u;
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
-        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t pq[3];
-            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
-            hp[s][0][q] = pq[0]; hp[s][1][q] = pq[1]; hp[s][2][q] = 0u;
-        }
-    }
-    const float rmask = row_ok ? 1.f : 0.f;
-    const float rscale = row_ok ? p.tnw * p.inv_B : 0.f;
-
-    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
-    int troff[2][NJT];                              // transposed read (rr, jt): rows 8*rr + 4*half + q (+ 16 per k-step, 32 per sub-tile as immediates)
-    {
-        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                const int row = 8 * rr + 4 * half + q;
-                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
-                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
-            }
-    }
-
-    f32x16 Y1[NJT], Y2[NJT];
-#pragma unroll
-    for (int j = 0; j < NJT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
-    LossAcc lacc;
-
-    const uint32_t smem_base = lds_addr(smem);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto stage_tile = [&](int t, int buf) {
-        const uint32_t sb = smem_base + buf * STAGE;
-        constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
-#pragma unroll
-        for (int n = 0; n < PER_WAVE; ++n) {
-            const int inst = wave_u * PER_WAVE + n;
-            const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row (0..63), physical chunk
-            const int plane = pos / PLANE, row = (pos >> 8) & 63, chp = (pos >> 4) & 15;
-            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
-            // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
-            const size_t src = ((size_t)(2 * t + (row >> 5)) * (32 * NP) + plane * 32 + (row & 31)) * 256 + 16 * ch;
-            glds16(reinterpret_cast<const char*>(pp.mu_pl) + src, sb + inst * 1024);
-            if (BAYES) glds16(reinterpret_cast<const char*>(pp.wp_pl) + src, sb + TM + inst * 1024);
-        }
-        const int c0 = t * BNT;
-        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TM);
-        if (BAYES && wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TM + 256);
-    };
-    auto sign_words = [&](int t) -> uint2 {         // s_out signs of (row i, experts 64t .. 64t+63)
-        if (!BAYES || !row_ok) return make_uint2(0u, 0u);
-        if (INJ) return *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);
-        return make_uint2(sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t)), sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t + 1)));
-    };
-    if (t_beg < t_end) stage_tile(t_beg, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = t_beg; t < t_end; ++t) {
-        const int buf = (t - t_beg) & 1;
-        const uint2 w2 = sign_words(t);
-        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
-        char* sb = smem + buf * STAGE;
-        const uint32_t sbase = lds_addr(sb);
-        const int c0 = t * BNT;
-        if (c0 + BNT > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
-            if (tid < BNT && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -1e30f;
-            __syncthreads();
-        }
-        f32x16 X1[2], X2[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { X1[u][r] = 0.f; X2[u][r] = 0.f; }
-        const uint32_t sw[2] = {w2.x >> (4 * half), w2.y >> (4 * half)};
-        constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
-        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
-        const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
-        const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
-        const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
-
-        constexpr int NHG = NKS * NMAT;     // half-groups (k-step, matrix) of one sub-tile's zT: 2 fragment reads + 3 MFMAs each
-        constexpr int NGD = 2 * NJT * NMAT; // groups (k-step of 16 experts, jt, matrix) of one sub-tile's dh: 4 transposed reads + 3 MFMAs each
-        auto z_load = [&](int u, int hg, u32x4 (&fr)[3]) {
-            const int s = hg / NMAT, mat = hg % NMAT;
-            const char* ap = sb + 256 * (32 * u + il) + 16 * ((2 * s + half) ^ fil) + mat * TM;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
-        };
-        auto z_mma = [&](int u, int hg, const u32x4 (&fr)[3]) {
-            const int s = hg / NMAT, mat = hg % NMAT;
-            if (mat == 0) X1[u] = mfma_np<NP>(fr, hp[s], X1[u]);
-            else {
-                u32x4 hs[3];
-                const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
-                u32x4 hm;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hm[q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) hs[q] = hp[s][q] ^ hm;
-                hs[2] = hm;
-                X2[u] = mfma_np<NP>(fr, hs, X2[u]);
-            }
-        };
-        auto epilogue = [&](int u, int r) {     // lane = batch row i, register r <-> expert c0 + 32u + rowmap(r, half)
-            const int cr = 32 * u + (r & 3) + 8 * (r >> 2);
-            float z = fmaf(X1[u][r], pp.u_z, bias_mu[cr]);
-            if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[u][r], pp.u_z, bias_p[cr])) ^ ((sw[u] << (31 - (cr & 31))) & 0x80000000u));
-            const bool pos = z > 0.f;
-            const float l = pos ? z : z * kLeakySlope;
-            const float lc = fmaxf(l, -80.f);
-            const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
-            lacc.tile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lacc.tile);
-            X1[u][r] = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);   // dz; stored as packed planes by split_pair_a
-        };
-        u32x4 ad[2][2][3];      // [u][k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
-        auto split_pair_a = [&](int u, int r0) {   // registers r0, r0 + 1 (r0 even) of sub-tile u
-            uint32_t pq[3];
-            split_pair_np<NP>(X1[u][r0], X1[u][r0 + 1], pp.dz_scale, pq);
-            ad[u][r0 >> 3][0][(r0 & 7) >> 1] = pq[0]; ad[u][r0 >> 3][1][(r0 & 7) >> 1] = pq[1];
-            uint32_t d0, d1;
-            pack_planes(pq[0], pq[1], d0, d1);
-            __builtin_amdgcn_raw_buffer_store_b32(d0, dz_rsrc, dz_voff, (32 * u + (r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(d1, dz_rsrc, dz_voff, (32 * u + ((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
-        };
-        auto signed_a = [&](int u, int s2, u32x4 (&o)[3]) {   // planes of dz * s_out
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r0 = 8 * s2 + 2 * q, c0r = (r0 & 3) + 8 * (r0 >> 2);
-                const uint32_t m = (((sw[u] << (31 - c0r)) & 0x80000000u) >> 16) | ((sw[u] << (30 - c0r)) & 0x80000000u);
-                o[0][q] = ad[u][s2][0][q] ^ m; o[1][q] = ad[u][s2][1][q] ^ m;
-            }
-            o[2] = o[0];
-        };
-        auto tr_load = [&](int u, int g, u32x4 (&bf)[3]) {   // g = (s2, jt, mat)
-            const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const uint32_t o = 8192 * u + 4096 * s2 + q * PLANE + mat * TM;
-                const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[0][jt] + o)));
-                const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[1][jt] + o)));
-                bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
-            }
-        };
-        auto d_mma = [&](int u, int g, const u32x4 (&bf)[3]) {
-            const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
-            if (mat == 0) Y1[jt] = mfma_np<NP>(ad[u][s2], bf, Y1[jt]);
-            else { u32x4 asg[3]; signed_a(u, s2, asg); Y2[jt] = mfma_np<NP>(asg, bf, Y2[jt]); }
-        };
-        // vector work riding on MFMA group g of a 16- (Bayes) or 8-group phase: the epilogue of PER registers of sub-tile u, and once both
-        // registers of a pair are done, their split into dh fragments
-        constexpr int PERZ = 16 / NHG, PERD = 16 / NGD;
-        auto ride = [&](int u, int g, int per) {
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                if (rr < per) {
-                    const int r = g * per + rr;
-                    epilogue(u, r);
-                    if (r & 1) split_pair_a(u, r - 1);
-                }
-            }
-        };
-
-        // The 2 NHG + 2 NGD groups of 3 MFMAs run in BUNDLES of BG: the fragments of a whole bundle (BG x 8 registers) are fetched while the previous
-        // bundle's 3 BG MFMAs run — an LDS round trip under four busy waves is 2-3 groups long, and with one wave per SIMD nobody else covers it
-        constexpr int NGRP = 2 * NHG + 2 * NGD, BG = 4, NB = NGRP / BG;
-        static_assert(NHG % BG == 0 && NGD % BG == 0, "bundles must not straddle phases");
-        u32x4 fb[2][BG][3];
-        auto load_g = [&](int G, u32x4 (&dst)[3]) {
-            if (G < NHG) z_load(0, G, dst);
-            else if (G < 2 * NHG) z_load(1, G - NHG, dst);
-            else if (G < 2 * NHG + NGD) tr_load(0, G - 2 * NHG, dst);
-            else tr_load(1, G - 2 * NHG - NGD, dst);
-        };
-#pragma unroll
-        for (int k = 0; k < BG; ++k) load_g(k, fb[0][k]);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b + 1 < NB) {
-#pragma unroll
-                for (int k = 0; k < BG; ++k) load_g((b + 1) * BG + k, fb[(b + 1) & 1][k]);
-            }
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < BG; ++k) {
-                const int G = b * BG + k;
-                if (G < NHG) z_mma(0, G, fb[b & 1][k]);
-                else if (G < 2 * NHG) { z_mma(1, G - NHG, fb[b & 1][k]); ride(0, G - NHG, PERZ); }                 // epilogue + splits of sub-tile 0
-                else if (G < 2 * NHG + NGD) { d_mma(0, G - 2 * NHG, fb[b & 1][k]); ride(1, G - 2 * NHG, PERD); }    // ... of sub-tile 1
-                else d_mma(1, G - 2 * NHG - NGD, fb[b & 1][k]);
-            }
-        }
-        lacc.end_tile();
-        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // the next tile's DMA is older than this tile's 32 dzT stores
-        __builtin_amdgcn_s_barrier();
-    }
-
-    float lsum = lacc.sum;
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int irow = i0 + rowmap(r, half);
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            float v = Y1[jt][r] * pp.u_dh;
-            if (BAYES) {
-                const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
-                const float y2 = Y2[jt][r] * pp.u_dh;
-                v += ((w >> il) & 1u) ? -y2 : y2;
-            }
-            p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Round 3: the same kernel with its four 48-MFMA phases ROTATED ACROSS TILES.  In k_out_fwd_h3w the vector work of a tile (the epilogue of its two
-// sub-tiles: bias, sign, leaky_relu, BCE, dz, its fp16 split and stores - ~1.1 k instructions) rides on the two MIDDLE phases only, ~11 vector instructions
-// per MFMA there (a wave alone on its SIMD issues one per ~4.3 cycles: those phases are vector-bound at ~2x their MFMA time) while zT(u=0) and dh(u=1)
-// run bare (ISA of the tile loop + PMC: profiles/r3_fwd_isa.md).  Every phase can carry half an epilogue when the order of the matrix work is
+// Training forward (loss + dz + dh) of the fp16x3 step: 64-expert tiles = two 32-expert sub-tiles u, two LDS stages of 2 matrices x 2 planes x [64 rows][256 B]
+// (+ biases) = 2 x 64.5 KiB, everything else as in k_out_fwd_b6<.., NP = 2>.  A tile is four phases of 48 MFMAs - zT(u) = planes(u) . hT and dh += dz(u) . planes(u)
+// for u = 0, 1 - and ~1.1 k vector instructions of epilogue (bias, sign, leaky_relu, BCE, dz, its fp16 split and stores).  The phases are ROTATED ACROSS TILES so that
+// every one of them carries half an epilogue (round 2's kernel, phases in tile order, rode the vector work on the two middle phases only: ~11 vector instructions per
+// MFMA there, vector-bound at twice their MFMA time, while the outer two ran bare - retired in round 4, 0.82 against 0.70 ms):
 //   zT(0,t) | dh(1,t-1) | zT(1,t) | dh(0,t)        with the epilogue of sub-tile (1,t-1) over [dh(0,t-1), zT(0,t)] and of (0,t) over [dh(1,t-1), zT(1,t)]:
 // an epilogue needs its zT finished and must finish before its dh starts, which leaves it exactly those two phases.  Stage t-1 stays alive until dh(1,t-1)
-// is through (a barrier), then takes the DMA of tile t+1, issued one piece per MFMA group of zT(1,t) instead of a burst of 18 at the top of the tile.
-// Same sums in the same order as k_out_fwd_h3w (dh accumulates sub-tiles in the order (0,t-1), (1,t-1), (0,t), ...); the first tile's "previous" sub-tile is a
-// zero one (its dz planes are zero, its stores go to an empty buffer resource, its loss terms are masked).  Also trimmed here: the dz split needs no range
-// clamp (|dz| <= max weight / B is scaled below 2^14 by construction) and takes its scale from the row constant; accumulators start from the MFMA's zero
-// operand instead of 64 register clears per tile.
+// is through (a barrier), then takes the DMA of tile t+1, issued one piece per MFMA group of zT(1,t).  dh accumulates the sub-tiles in the order (0,t-1), (1,t-1),
+// (0,t), ...; the first tile's "previous" sub-tile is a zero one (its dz planes are zero, its stores go to an empty buffer resource, its loss terms are masked).
+// The dz split needs no range clamp (|dz| <= max weight / B is scaled below 2^14 by construction) and takes its scale from the row constant; accumulators start from
+// the MFMA's zero operand instead of 64 register clears per tile.
 // ------------------------------------------------------------------------------------------------
-// ABL (diagnostics, NTF_FWD_ABL; results are wrong for ABL != 0): 1 = no epilogue arithmetic, 2 = no epilogue at all (no splits, no dz stores), 3 = no MFMAs
+// ABL (-DNTF_DIAG builds only, NTF_FWD_ABL; results are wrong for ABL != 0, 9): 1 = no epilogue arithmetic, 2 = no epilogue at all (no splits, no dz stores), 3 = no MFMAs,
+// 9 = phase cycle stamps
 template <bool BAYES, bool INJ, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2952,251 +2658,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3y(OutFwd6Args pp) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Training forward (loss + dz + dh) of the Flipout output layer in fp16x3 with TWO WAVES PER SIMD (round 2).
-// k_out_fwd_h3w keeps one wave per SIMD at 512 registers: per 64-expert tile its 192 MFMAs (6.1 k cycles) sit beside ~1.1 k vector instructions and
-// 44 waits and the tile takes 14.9 k cycles - exposed LDS latency with nobody to cover it.  Here the two matrices are split over a wave PAIR that
-// shares 32 batch rows: wave w (role 0) multiplies by mu, wave w + 4 (role 1, the same SIMD) by Wp.  Each keeps one operand set of h planes
-// (h or h*s_in, 64 registers), one accumulator of zT (16) and one of dh (64) - under 256 registers, so both fit on the SIMD and cover each
-// other's LDS round trips.  Per 32-expert tile:
-//   S0  both: zT = W_role . hT (24 MFMAs); role 1 finishes its logit part (bias, s_out sign) and hands it over through LDS
-//   S1  role 0: z = own + partner's, leaky_relu, BCE, dz, loss; dz split into fp16 planes -> dzT (packed) and, through LDS, to the partner
-//   S2  both: dh_role += (dz | dz*s_out) . W_role (24 MFMAs)
-// The exchanges use [register][lane] images (the partners' lanes hold the same (row, expert) elements), so they are conflict-free b32 accesses.
-// MEASURED (round 2): parity-green, 228 registers, two waves per SIMD - and 9 % SLOWER than k_out_fwd_h3w (0.87 vs 0.80 ms).  Ablations: without any
-// MFMA, DMA or epilogue math the per-tile skeleton (fragment reads, the two exchanges, three barriers per 24-MFMA phase) still takes 58 % of the
-// kernel's time: on 32-expert tiles the phases are too short for their fixed LDS / barrier latencies, and 64-expert tiles do not fit beside the
-// exchange images (2 x 64.5 KB stages + 32 KB = 161 KB).  Kept as FusedOut.wide = 2 (NTF_FWD_KERNEL=2) for A/B runs; not the default.
-// ------------------------------------------------------------------------------------------------
-template <bool INJ>
-__global__ __launch_bounds__(512, 2) void k_out_fwd_rs(OutFwd6Args pp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const OutFwdArgs& p = pp.a;
-    constexpr int H = 128, NJT = 4, NKS = H / 16, NP = 2;
-    constexpr int PLANE = BN6 * H * 2;          // 8 KiB
-    constexpr int TM = NP * PLANE;              // one matrix of a tile
-    constexpr int STAGE = 2 * TM + 512;         // two matrices + two 64-float bias tiles
-    constexpr int XCH = 4 * 16 * 64 * 4;        // one exchange image: [pair][register][lane] dwords = 16 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    if (range_guard_skip(p.rflag, p.rmode, false)) return;
-    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), pair = __builtin_amdgcn_readfirstlane(wave & 3);
-
-    int bid = blockIdx.x;
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int cg = bid / p.NRB, rb = bid % p.NRB;
-    const int T = (p.M + BN6 - 1) / BN6;
-    const int t_beg = (int)((int64_t)cg * T / p.NCG), t_end = (int)((int64_t)(cg + 1) * T / p.NCG);
-    const int i0 = rb * BM + pair * 32;
-    const int i = i0 + il;
-    const bool row_ok = i < p.B;
-
-    // B operand of zT: this role's planes of h[i][16s + 8*half + e] (role 1: times s_in, applied once)
-    u32x4 hp[NKS][3];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
-        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        uint32_t w8 = 0u;
-        if (role == 1) {
-            const uint32_t sw_in = INJ ? p.sinbits[(int64_t)i * NJT + (s >> 1)] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)(s >> 1)) : 0u);
-            w8 = sw_in >> (16 * (s & 1) + 8 * half);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t pq[3];
-            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
-            const uint32_t m = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
-            hp[s][0][q] = pq[0] ^ m; hp[s][1][q] = pq[1] ^ m; hp[s][2][q] = 0u;
-        }
-    }
-    const float rmask = row_ok ? 1.f : 0.f;
-    const float rscale = row_ok ? p.tnw * p.inv_B : 0.f;
-
-    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
-    int troff[2][NJT];
-    {
-        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                const int row = 8 * rr + 4 * half + q;
-                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
-                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
-            }
-    }
-
-    f32x16 Y[NJT];
-#pragma unroll
-    for (int j = 0; j < NJT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Y[j][r] = 0.f;
-    LossAcc lacc;
-
-    const uint32_t smem_base = lds_addr(smem);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    float* xz = reinterpret_cast<float*>(smem + 2 * STAGE) + (pair * 16) * 64 + lane;                    // + 64 r : logit part of the partner
-    uint32_t* xd = reinterpret_cast<uint32_t*>(smem + 2 * STAGE + XCH) + (pair * 16) * 64 + lane;        // + 64 k : dz plane registers
-    auto stage_tile = [&](int t, int buf) {
-        const uint32_t sb = smem_base + buf * STAGE;
-        constexpr int PER_WAVE = TM / 1024 / 8;     // 1 KiB wave-instructions per wave per matrix
-#pragma unroll
-        for (int n = 0; n < PER_WAVE; ++n) {
-            const int inst = wave_u * PER_WAVE + n;
-            const int pos = inst * 1024 + lane * 16;
-            const int row = (pos >> 8) & 31, chp = (pos >> 4) & 15;
-            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
-            const size_t src = (size_t)t * TM + (pos & ~255) + 16 * ch;
-            glds16(reinterpret_cast<const char*>(pp.mu_pl) + src, sb + inst * 1024);
-            glds16(reinterpret_cast<const char*>(pp.wp_pl) + src, sb + TM + inst * 1024);
-        }
-        const int c0 = t * BN6;
-        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + 2 * TM);
-        if (wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + 2 * TM + 256);
-    };
-    if (t_beg < t_end) stage_tile(t_beg, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = t_beg; t < t_end; ++t) {
-        const int buf = (t - t_beg) & 1;
-        uint32_t sw = 0u;
-        if (row_ok) sw = (INJ ? p.sbits[(int64_t)i * p.nCB + t] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)t)) >> (4 * half);
-        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
-        char* sb = smem + buf * STAGE;
-        const int c0 = t * BN6;
-        if (c0 + BN6 > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
-            if (tid < BN6 && c0 + tid >= p.M) reinterpret_cast<float*>(sb + 2 * TM)[tid] = -1e30f;
-            __syncthreads();
-        }
-        f32x16 X;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) X[r] = 0.f;
-        const uint32_t sbase = lds_addr(sb);
-
-        // ---- S0: zT of this role's matrix: 8 k-steps of 16 hidden units, the fragments of the next k-step in flight under the MFMAs of the current one
-        {
-            auto z_load = [&](int s, u32x4 (&fr)[3]) {
-                const char* ap = sb + 256 * il + 16 * ((2 * s + half) ^ fil) + role * TM;
-#pragma unroll
-                for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const u32x4*>(ap + q * PLANE);
-            };
-            u32x4 fr[2][3];
-            z_load(0, fr[0]);
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                if (s + 1 < NKS) z_load(s + 1, fr[(s + 1) & 1]);
-                asm volatile("" ::: "memory");
-                X = mfma_np<NP>(fr[s & 1], hp[s], X);
-            }
-        }
-        const float* bias = reinterpret_cast<const float*>(sb + 2 * TM + 256 * role) + 4 * half;
-        if (role == 1) {   // the perturbation part of the logit, signed, to the partner
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cr = (r & 3) + 8 * (r >> 2);
-                xz[64 * r] = __uint_as_float(__float_as_uint(fmaf(X[r], pp.u_z, bias[cr])) ^ ((sw << (31 - cr)) & 0x80000000u));
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-
-        // ---- S1: role 0 owns the epilogue of the tile
-        u32x4 ad[2][3];
-        if (role == 0) {
-            constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
-            const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
-            const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cr = (r & 3) + 8 * (r >> 2);
-                const float z = fmaf(X[r], pp.u_z, bias[cr]) + xz[64 * r];
-                const bool pos = z > 0.f;
-                const float l = pos ? z : z * kLeakySlope;
-                const float lc = fmaxf(l, -80.f);
-                const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
-                lacc.tile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rmask, lacc.tile);
-                X[r] = rscale * __builtin_amdgcn_rcpf(tt) * (pos ? 1.f : kLeakySlope);
-            }
-#pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 2) {
-                uint32_t pq[3];
-                split_pair_np<NP>(X[r0], X[r0 + 1], pp.dz_scale, pq);
-                ad[r0 >> 3][0][(r0 & 7) >> 1] = pq[0]; ad[r0 >> 3][1][(r0 & 7) >> 1] = pq[1];
-                uint32_t d0, d1;
-                pack_planes(pq[0], pq[1], d0, d1);
-                __builtin_amdgcn_raw_buffer_store_b32(d0, dz_rsrc, dz_voff, ((r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(d1, dz_rsrc, dz_voff, (((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
-                xd[64 * (r0 >> 1)] = pq[0]; xd[64 * (8 + (r0 >> 1))] = pq[1];
-            }
-            ad[0][2] = ad[0][0]; ad[1][2] = ad[1][0];
-            lacc.end_tile();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (role == 1) {   // the partner's dz planes, times s_out
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r0 = 2 * k, c0r = (r0 & 3) + 8 * (r0 >> 2);   // registers r0, r0 + 1 are experts c0r, c0r + 1 (+ 4*half, folded into sw)
-                const uint32_t m = (((sw << (31 - c0r)) & 0x80000000u) >> 16) | ((sw << (30 - c0r)) & 0x80000000u);
-                ad[k >> 2][0][k & 3] = xd[64 * k] ^ m; ad[k >> 2][1][k & 3] = xd[64 * (8 + k)] ^ m;
-            }
-            ad[0][2] = ad[0][0]; ad[1][2] = ad[1][0];
-        }
-
-        // ---- S2: dh of this role's matrix: groups (k-step of 16 experts, jt) of 4 transposed reads + 3 MFMAs
-        {
-            auto tr_load = [&](int g, u32x4 (&bf)[3]) {
-                const int jt = g % NJT, s2 = g / NJT;
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const uint32_t o = 4096 * s2 + q * PLANE + role * TM;
-                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[0][jt] + o)));
-                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(sbase + troff[1][jt] + o)));
-                    bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
-                }
-            };
-            constexpr int NG = 2 * NJT;
-            u32x4 bf[2][3];
-            tr_load(0, bf[0]);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) tr_load(g + 1, bf[(g + 1) & 1]);
-                asm volatile("" ::: "memory");
-                Y[g % NJT] = mfma_np<NP>(ad[g / NJT], bf[g & 1], Y[g % NJT]);
-            }
-        }
-        // tile end: the next tile's DMA (older than role 0's 16 dzT stores) has landed; everybody is done with this stage and the exchange images
-        if (role == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    if (role == 0) {
-        float lsum = lacc.sum;
-        lsum += __shfl_xor(lsum, 32, 64);
-        if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
-    }
-    // dh partials: role 0 -> slab cg, role 1 (times s_in) -> slab NCG + cg; k_out_special sums 2 NCG slabs
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int irow = i0 + rowmap(r, half);
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            float v = Y[jt][r] * pp.u_dh;
-            if (role == 1) {
-                const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
-                v = ((w >> il) & 1u) ? -v : v;
-            }
-            p.slab[((int64_t)(role * p.NCG + cg) * p.Bpad + irow) * H + 32 * jt + il] = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
 static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
@@ -3243,8 +2704,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     a.rflag = f.rflag; a.rmode = 0;
     SpecialArgs s;
     s.B = f.B; s.M = f.M; s.Bpad = g.Bpad; s.NCG = g.NCG; s.nCB = g.nCB; s.ns = f.ns;
-    const bool role_split = f.bf16x6 && f.H == 128 && f.np == 2 && f.train && f.dh != nullptr && f.bayes && f.wide == 2;
-    s.nslab = role_split ? 2 * g.NCG : g.NCG;
+    s.nslab = g.NCG;
     s.h = f.h; s.hs = hs; s.mu = f.mu; s.mu_b = f.mu_b; s.wp = f.wp; s.bp = f.bp; s.slab = f.dh_slab; s.lossp = lossp; s.h_mask = f.h_mask;
     s.sbits = sbits; s.sinbits = sinbits; s.rows = f.rows; s.m_indptr = f.m_indptr; s.neg = f.neg; s.m_indices = f.m_indices;
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
@@ -3272,28 +2732,19 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_L6(BY, TR, DHF, IJ, PR) do { if (np == 2) NTF_L6N(BY, TR, DHF, IJ, PR, 2); else NTF_L6N(BY, TR, DHF, IJ, PR, 3); } while (0)
 #define NTF_L6B(BY, IJ) do { if (f.probs) NTF_L6(BY, false, false, IJ, true); else if (!f.train) NTF_L6(BY, false, false, IJ, false);  \
                              else if (dh) NTF_L6(BY, true, true, IJ, false); else NTF_L6(BY, true, false, IJ, false); } while (0)
-            if (role_split) {                            // two waves per SIMD, mu-wave / Wp-wave pairs on 32-expert tiles
-                const size_t ldsr = 2 * ((size_t)2 * 2 * BN6 * 128 * 2 + 512) + 2 * (4 * 16 * 64 * 4);
-#define NTF_LR(IJ) do { auto kf = k_out_fwd_rs<IJ>;                                                                               \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);   \
-                hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsr, st, a6); } while (0)
-                if (inj) NTF_LR(true); else NTF_LR(false);
-#undef NTF_LR
-            } else if (np == 2 && f.train && dh && f.wide) {    // 64-expert tiles (a.T counts them already)
+            if (np == 2 && f.train && dh && f.wide) {    // the fp16x3 training step: 64-expert tiles (a.T counts them already)
                 const size_t ldsw = 2 * ((size_t)(f.bayes ? 2 : 1) * 2 * 64 * 128 * 2 + 512);
-#define NTF_LW(BY, IJ) do { auto kf = k_out_fwd_h3w<BY, IJ>;                                                                    \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
-                hipLaunchKernelGGL(kf, dim3(grid), dim3(256), ldsw, st, a6); } while (0)
 #define NTF_LXA(BY, IJ, AB) do { auto kf = k_out_fwd_h3x<BY, IJ, AB>;                                                                    \
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
                 hipLaunchKernelGGL(kf, dim3(grid), dim3(256), ldsw, st, a6); } while (0)
 #define NTF_LX(BY, IJ) NTF_LXA(BY, IJ, 0)
+#ifdef NTF_DIAG
                 static const int fwd_abl = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
-                if (f.wide == 3 && fwd_abl == 9 && f.bayes && !inj) {
+                if (f.wide != 4 && fwd_abl == 9 && f.bayes && !inj) {
                     static unsigned long long* d_st = nullptr; static int n_launch = 0;
                     if (!d_st) hipMalloc(&d_st, (size_t)grid * 4 * 12 * 8);
                     a6.stamps = d_st;
-                    static const int rep = getenv("NTF_FWD_REPEAT") ? atoi(getenv("NTF_FWD_REPEAT")) : 1;    // diagnostics: the (idempotent) kernel several times back to back - its clock without the other kernels
+                    static const int rep = getenv("NTF_FWD_REPEAT") ? atoi(getenv("NTF_FWD_REPEAT")) : 1;    // the (idempotent) kernel several times back to back - its clock without the other kernels
                     for (int r = 0; r < rep; ++r) NTF_LXA(true, false, 9);
                     if (++n_launch == 30) {
                         std::vector<unsigned long long> hst((size_t)grid * 48);
@@ -3305,24 +2756,24 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                                 sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7], sum[7] / (grid * 4.0));
                     }
                 }
-                else if (f.wide == 4) {      // sixteen-row waves, two per SIMD
+                else if (f.wide != 4 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
+                else
+#endif
+                if (f.wide == 4) {      // sixteen-row waves, two per SIMD (NTF_FWD_KERNEL=4: the A/B form)
 #define NTF_LY(BY, IJ) do { auto kf = k_out_fwd_h3y<BY, IJ>;                                                                    \
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
                 hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsw, st, a6); } while (0)
                     if (f.bayes) { if (inj) NTF_LY(true, true); else NTF_LY(true, false); } else NTF_LY(false, false);
 #undef NTF_LY
                 }
-                else if (f.wide == 3 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
-                else if (f.wide == 3) { if (f.bayes) { if (inj) NTF_LX(true, true); else NTF_LX(true, false); } else NTF_LX(false, false); }
-                else if (f.bayes) { if (inj) NTF_LW(true, true); else NTF_LW(true, false); } else NTF_LW(false, false);
+                else { if (f.bayes) { if (inj) NTF_LX(true, true); else NTF_LX(true, false); } else NTF_LX(false, false); }
 #undef NTF_LX
 #undef NTF_LXA
-#undef NTF_LW
             } else if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
 #undef NTF_L6B
 #undef NTF_L6
 #undef NTF_L6N
-            const bool merged_fallback = !role_split && np == 2 && f.train && dh && f.wide == 3;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
+            const bool merged_fallback = np == 2 && f.train && dh && f.wide != 0 && f.wide != 4;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
             if (guard && np == 2 && !f.probs && !merged_fallback) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
                 OutFwdArgs af = a; af.rmode = 2;
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
@@ -3390,7 +2841,6 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.produce = (f.produce && f.adam && f.bayes && f.H == 128) ? 1 : 0;
     a.cur_eps = f.cur_eps; a.lean = (a.produce && f.lean) ? 1 : 0;
     a.nx_eps = f.nx_eps; a.nx_wp = f.nx_wp; a.nx_pl_wp = f.nx_pl_wp; a.nx_pl_mu = f.nx_pl_mu; a.nx_pscale = f.nx_pscale; a.nx_klw = f.nx_klw; a.nx_kl = f.nx_kl; a.nx_rflag = f.nx_rflag;
-    { static const int abl = getenv("NTF_DW_ABLATE") ? atoi(getenv("NTF_DW_ABLATE")) : 0; a.ablate = abl; }
     a.ntile = 0; a.stagger = 0; a.stamps = nullptr;
     const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
     a.sT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
@@ -3428,7 +2878,11 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
 #define NTF_DWQ(BY, AD) do { auto kf = k_out_dw_q<BY, AD>;                                                                     \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq);     \
             hipLaunchKernelGGL(kf, dim3(qgrid), dim3(64 * QW), ldsq, st, a); } while (0)
-            static const char* stamp_file = getenv("NTF_DW_STAMP_FILE");   // diagnostics: the 30th launch's per-wave stamps, raw (10 x u64 per wave), to this file
+#ifdef NTF_DIAG
+            static const char* stamp_file = getenv("NTF_DW_STAMP_FILE");   // -DNTF_DIAG builds: the 30th launch's per-wave stamps, raw (10 x u64 per wave), to this file (profiles/dw_stamps.py)
+#else
+            static const char* stamp_file = nullptr;
+#endif
             if (stamp_file && f.bayes && f.adam) {
                 static unsigned long long* d_st = nullptr; static int n_launch = 0;
                 if (!d_st) hipMalloc(&d_st, (size_t)qgrid * QW * 10 * 8);
@@ -3449,37 +2903,12 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
             goto exact_f32;
         }
         const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0)) + 64;
-        // persistent workgroups, one per CU; with several tiles per workgroup and an epilogue that updates in place, every second one starts late (see the kernel)
-        static const int stagger_env = getenv("NTF_DW_STAGGER") ? atoi(getenv("NTF_DW_STAGGER")) : -1;   // ticks (10 ns) per K block; default below
-        static const int pgrid_env = getenv("NTF_DW_PGRID") ? atoi(getenv("NTF_DW_PGRID")) : (1 << 30);   // default: one tile per workgroup (measured: persistent = the same time)
-        const int pgrid = std::min(grid, std::max(1, pgrid_env));
-        a.ntile = grid;
-        a.stagger = (f.adam && grid >= 2 * pgrid) ? (stagger_env >= 0 ? stagger_env : 0) * (g.Bpad / 32) : 0;
 #define NTF_DWP(BY, AD) do { auto kf = k_out_dw_p2<BY, AD>;                                                                    \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-        hipLaunchKernelGGL(kf, dim3(pgrid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
-        static const int dw_stamp = getenv("NTF_DW_STAMP") ? atoi(getenv("NTF_DW_STAMP")) : 0;
-        if (dw_stamp && f.bayes && f.adam) {
-            static unsigned long long* d_st = nullptr; static int n_launch = 0;
-            if (!d_st) hipMalloc(&d_st, (size_t)grid * DW_WAVES * 4 * 8);
-            a.stamps = d_st;
-            auto kf = k_out_dw_p2<true, true, true>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kf, dim3(pgrid), dim3(64 * DW_WAVES), lds, st, a);
-            if (++n_launch == 30) {
-                std::vector<unsigned long long> hst((size_t)grid * DW_WAVES * 4);
-                hipStreamSynchronize(st); hipMemcpy(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost);
-                double sum[4] = {0}; for (size_t w = 0; w < (size_t)grid * DW_WAVES; ++w) for (int q = 0; q < 4; ++q) sum[q] += (double)hst[w * 4 + q];
-                const double nw = (double)grid * DW_WAVES, nib = g.Bpad / 32;
-                fprintf(stderr, "[dw stamps] cycles per wave: K-block body %.0f | DMA wait %.0f | barrier %.0f  (x %g K blocks) | epilogue %.0f per tile\n",
-                        sum[0] / nw / nib, sum[1] / nw / nib, sum[2] / nw / nib, nib, sum[3] / nw);
-            }
-        }
-        else if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
+        if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
 #undef NTF_DWP
-        if (!guard || (pgrid == grid && !(dw_stamp && f.bayes && f.adam))) return;   // one tile per workgroup: the kernel runs the f32 body itself when the flag is raised
-        a.rmode = 2;
-        goto exact_f32;
+        return;   // (one tile per workgroup: the kernel runs the f32 body itself when the range flag is raised)
     }
     if (f.bf16x6) {
         const int np = f.np == 2 ? 2 : 3;

@@ -212,13 +212,19 @@ class D2v(T2v):
         os.makedirs(self.output, exist_ok=True)
         doc_ptr, words, key = self.data
         d, e, w, dm, min_alpha = int(cfg_get(c, "d")), int(cfg_get(c, "e")), int(cfg_get(c, "w")), int(cfg_get(c, "dm")), float(cfg_get(c, "lr"))
+        if d not in (64, 128, 192, 256):
+            raise ValueError(f"d2v on the device trains vector sizes 64, 128, 192 and 256 (a wave holds d / 64 values per lane); data.embedding.d = {d} is not one of them")
+        longest = int(np.diff(np.asarray(doc_ptr)).max()) if len(doc_ptr) > 1 else 0
+        if longest > 10000:
+            log.info(f"The longest document has {longest} words: as in gensim, at most 10 000 of a document's words that survive the subsampling are trained on")
         spe = cfg_get(c, "spe")
         seed = int(self.seed) if self.seed is not None else 1                # gensim's default seed
         keys, count, sample_int, cum_table, words_v = build_vocab(words)
         word_keys = [key(int(k)) for k in keys]
         wv0, dv0 = initial_vectors(n_teams, len(keys), d, seed)
+        # (gensim's train(epochs=n) leaves model.epochs = n: 1 after the reference's per-epoch loop, d2v.py:78 - which is what infer_vector then runs)
         hyper = {"vector_size": d, "window": w, "dm": dm, "dbow_words": 1, "negative": NEGATIVE, "sample": SAMPLE, "ns_exponent": NS_EXPONENT, "min_alpha": min_alpha,
-                 "alpha": ALPHA, "epochs": e, "seed": seed, "corpus_count": n_teams, "corpus_total_words": int(len(words)), "count": count}
+                 "alpha": ALPHA, "epochs": 1 if cfg_get(c, "spe") else e, "seed": seed, "corpus_count": n_teams, "corpus_total_words": int(len(words)), "count": count}
         order = None
         if spe:                                                               # d2v.py:74-75 (on every rank: the ranks' `random` streams stay in step)
             order = list(range(n_teams))
@@ -256,8 +262,9 @@ class D2v(T2v):
         epochs = int(getattr(m, "epochs", 10))
         cum = np.round(np.cumsum(np.asarray(m.count, np.float64) ** m.ns_exponent) / np.sum(np.asarray(m.count, np.float64) ** m.ns_exponent) * (2 ** 31 - 1))
         a0, a1 = float(getattr(m, "alpha", ALPHA)), float(m.min_alpha)
+        alpha_delta = (a0 - a1) / max(epochs - 1, 1)                          # gensim's infer_vector: alpha falls to min_alpha over the epochs - 1 steps between passes
         for ep in range(epochs):
-            alpha = a0 - (a0 - a1) * ep / max(epochs, 1)
+            alpha = a0 - alpha_delta * ep
             for i, word in enumerate(idx):
                 b = int(rng.integers(m.window))
                 ctx = [idx[j] for j in range(max(0, i - m.window + b), min(len(idx), i + m.window + 1 - b)) if j != i]

@@ -36,6 +36,7 @@ from __future__ import annotations
 import numpy as np
 
 MAX_EXP = 6.0
+MAX_DOCUMENT_LEN = 10000     # doc2vec_inner.pyx: the words of a document that survive the subsampling are collected up to this many (`if i == MAX_DOCUMENT_LEN: break`)
 EXP_TABLE_SIZE = 1000
 NEGATIVE = 5
 SAMPLE = 1e-3
@@ -203,7 +204,7 @@ def train_epoch(doc_ptr, words_v, vocab, wv, dv, syn1neg, dm, window, alpha_star
     for rank, doc in enumerate(order.tolist()):
         alpha = np.float32(alpha_start - (alpha_start - alpha_end) * (rank / n if progress is None else float(progress[rank])))
         w = words_v[doc_ptr[doc]:doc_ptr[doc + 1]]
-        kept = [int(x) for p, x in enumerate(w.tolist()) if int(sample_int[x]) >= draw(key, doc, p, 0, SLOT_KEEP)[0]]
+        kept = [int(x) for p, x in enumerate(w.tolist()) if int(sample_int[x]) >= draw(key, doc, p, 0, SLOT_KEEP)[0]][:MAX_DOCUMENT_LEN]
         K = len(kept)
         for i in range(K):
             b = draw(key, doc, i, 0, SLOT_WINDOW)[0] % window

@@ -38,14 +38,14 @@ with open(out_csv, "w", newline="") as f:
 main_q = out[0][1]
 step = (int(rows[fwd[-2]]["Start_Timestamp"]) - t0) / 1e3
 with open(out_md, "w") as f:
-    f.write("# One train step on the main stream (rocprofv3 --kernel-trace; round 3 defaults)\n\n")
-    f.write(f"Step period in this PROFILED run: {step:.0f} us (un-profiled: see r3_bench_n1.json).  Gaps are inflated by the profiler (11-19 us per dependent launch; 1.5-2 us un-profiled).\n\n")
+    f.write("# One train step on the main stream (rocprofv3 --kernel-trace; defaults of the round named in the file name)\n\n")
+    f.write(f"Step period in this PROFILED run: {step:.0f} us (un-profiled: see the round's bench_n1.json).  Gaps are inflated by the profiler (11-19 us per dependent launch; 1.5-2 us un-profiled).\n\n")
     f.write("| kernel | queue | start us | duration us | gap before us |\n|---|---|---|---|---|\n")
     for o in out:
         if o[2] > step + 1: break
         f.write(f"| `{o[0]}` | {o[1]} | {o[2]:.1f} | {o[4]:.1f} | {o[5]:.1f} |\n")
     ks = [o for o in out if o[2] <= step + 1 and o[1] == main_q]
-    big = sum(o[4] for o in ks if o[0].startswith(("k_out_fwd_h3", "k_out_dw_p2")))
+    big = sum(o[4] for o in ks if o[0].startswith(("k_out_fwd_h3", "k_out_dw_p2", "k_out_dw_q")))
     small = sum(o[4] for o in ks) - big
     f.write(f"\nMain stream: the two big kernels {big:.0f} us, every other kernel {small:.0f} us in {len(ks) - 2} launches; side streams run beside them.\n")
 print("wrote", out_csv, out_md)

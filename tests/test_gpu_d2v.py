@@ -21,7 +21,15 @@ def _random_docs(rng, n, V, mean):
     return ptr, np.concatenate([np.sort(rng.choice(V, k, replace=False, p=pop)) for k in lens]).astype(np.int64)
 
 
-CASES = {"toy_dblp": lambda: (Z["dblp_doc_ptr"], Z["dblp_words"], 1e-3), "toy_uspt": lambda: (Z["uspt_doc_ptr"], Z["uspt_words"], 1e-3),
+def _long_docs(rng, lens, V):
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pop = 1.0 / (np.arange(V) + 3.0); pop /= pop.sum()
+    return ptr, rng.choice(V, int(ptr[-1]), replace=True, p=pop).astype(np.int64)
+
+
+CASES = {"long_docs": lambda: (*_long_docs(np.random.default_rng(5), [3000, 5, 0, 1500, 70], 400), 0.05),        # documents far beyond the 1 024-slot ring of kept words
+         "capped_doc": lambda: (*_long_docs(np.random.default_rng(6), [12000, 9], 300), 0),                      # no subsampling: 12 000 kept words, gensim stops at 10 000
+         "toy_dblp": lambda: (Z["dblp_doc_ptr"], Z["dblp_words"], 1e-3), "toy_uspt": lambda: (Z["uspt_doc_ptr"], Z["uspt_words"], 1e-3),
          "zipf": lambda: (*_random_docs(np.random.default_rng(0), 300, 60, 8), 0.05), "empty_docs": lambda: (np.asarray([0, 0, 3, 3, 4, 4], np.int64), np.asarray([1, 2, 0, 2], np.int64), 0)}
 
 
@@ -32,6 +40,8 @@ def test_one_wave_pass_equals_the_sequential_oracle(case, d, dm):
     """serial launch: every document in order by ONE wave - gensim's single-worker semantics with this build's Philox streams: all three tables to rounding"""
     ptr, words, sample = CASES[case]()
     if case.startswith("toy") and d != 128: pytest.skip("toy corpora at their own d only")
+    if case == "long_docs" and d != 128: pytest.skip("the long documents at d = 128 only (the oracle is a Python loop)")
+    if case == "capped_doc" and (d != 64 or dm != 1): pytest.skip("the 10 000-word cap once")
     v = D.prepare_vocab(ptr, words, sample=sample)
     keys, count, si, cum, wi = P.build_vocab(words, sample=sample)
     wv, dv, s1 = D.init_vectors(len(ptr) - 1, len(keys), d, 3)

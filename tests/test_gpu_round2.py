@@ -394,23 +394,3 @@ def test_dblp_full_unfiltered_shape_fused_equals_generic():
             assert float(g[0].max()) <= 2e-2 * scale, (layer, name)
             del g; gc.collect()
     for e in eng: e.close()
-
-
-@pytest.mark.parametrize("M,B", [(1500, 70), (5000, 130), (777, 257)])
-def test_role_split_forward_kernel_equals_the_default_kernel(M, B, monkeypatch):
-    """k_out_fwd_rs (two waves per SIMD, mu-wave / Wp-wave pairs; FusedOut.wide = 2, kept for A/B runs): same loss, dz and gradients as the shipped
-    k_out_fwd_h3w with every random tensor injected - the two differ only in summation order."""
-    sd, X, y = _case(128, [128], M, B, 33, True)
-    noise = draw_noise(sd, B); neg = O.ns_uniform(y, 5)
-    out = {}
-    for kern in ("1", "2"):
-        monkeypatch.setenv("NTF_FWD_KERNEL", kern)
-        e = _engine([128, 128, M], bayesian=True, max_batch=B, ns=5, nsd="uniform")
-        e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
-        loss = e.backward(np.arange(B), inject=_inj(noise, neg))
-        out[kern] = (loss, e.dlogits(B), e.grads())
-    (l1, dz1, g1), (l2, dz2, g2) = out["1"], out["2"]
-    assert abs(l1 - l2) <= 2e-6 * abs(l1)
-    np.testing.assert_allclose(dz2, dz1, rtol=1e-4, atol=1e-12)
-    for k in g1:
-        assert np.abs(g1[k] - g2[k]).max() <= 2e-5 * np.abs(g1[k]).max(), k

@@ -121,7 +121,7 @@ def test_native_samplers_over_a_sequence_of_steps(nsd):
     rng = np.random.default_rng(0)
     tr, va = toy["train0"], toy["valid0"]
     last = {}                                   # team -> its picks at the previous visit
-    same = visits = few = 0
+    same = visits = few = 0; chance = 0.0
     hits = np.zeros(M); expect = np.zeros(M)
     for epoch in range(300):
         order = rng.permutation(tr)
@@ -146,11 +146,13 @@ def test_native_samplers_over_a_sequence_of_steps(nsd):
                 t = int(team)
                 if t in last:
                     visits += 1; same += int(sorted(last[t]) == sorted(picks.tolist()))
+                    k = int(adm.sum()); chance += 6.0 / (k * (k - 1) * (k - 2))      # 1 / C(k, 3): the repeat rate of UNIFORM independent draws; weighted ones repeat more often
                 last[t] = picks.tolist()
     ratio = hits[expect > 50] / expect[expect > 50]
     assert ratio.min() > 0.85 and ratio.max() < 1.15, (nsd, np.round(ratio, 2))
-    # a row's three picks repeating at its next visit: by chance ~1 / C(admissible, 3) (about 1 in 100 here); a generator keyed without the step would repeat always
-    assert visits > 2000 and same / visits < 0.08, (nsd, same, visits)
+    # a row's three picks repeating at its next visit: by chance >= 1 / C(admissible, 3) (1 in 120 for uniform here, 1 in ~10 inside unigram_b's batch support, more
+    # for skewed weights); a generator keyed without the step counter would repeat ALWAYS
+    assert visits > 2000 and same / visits < 4.0 * chance / visits + 0.02, (nsd, same, visits, chance)
     print(nsd, "rows with fewer than ns admissible experts:", few, "repeat rate", same / visits, "hits / expectation", np.round(ratio, 2))
     e.close()
 
