@@ -132,6 +132,11 @@ int ntf_range_fallbacks(ntf_engine* e, int64_t* steps);
  * that step then starts without the operand producer's own pass over the layer.  Reports how many steps started that way (same results either way:
  * the arithmetic is the producer's; NTF_PREFETCH=0 in the environment turns it off). */
 int ntf_prefetched_steps(ntf_engine* e, int64_t* steps);
+/* ... and, behind its hidden-layer backward, its side stream runs what the NEXT batch of the staged order (ntf_step_staged walks it front to back, as the loader of
+ * src/mdl/fnn.py:118 does) needs before its forward kernel: the negative sampler (fnn.py:48-72), the team2vec gather and the hidden layer (src/mdl/emb/gnn.py:485,
+ * fnn.py:25) - beside the dW kernel instead of between two steps' big kernels.  Reports how many steps found their head done that way (same results either way;
+ * NTF_HEAD_PREFETCH=0 turns it off; per-batch unigram_b tables, injected tensors, expert shards and data-parallel shards always run their head in their own step). */
+int ntf_head_prefetch_hits(ntf_engine* e, int64_t* steps);
 
 /* ---- the step:  body of the hot loop                              src/mdl/fnn.py:118-151
  * rows = B global team ids (host).  loss_out may be NULL: then nothing is synchronised and the loss is
@@ -209,7 +214,8 @@ int ntf_synchronize(ntf_engine* e);
 /* HIP-event timing of the kernels launched by the engine since the last reset, by kernel family:
  * names[i] (static strings), ms[i] total, calls[i].  Returns the number of families (<= cap).
  * enable: 0 off, 1 every family (two event records around each of ~15 scopes per step), 2 only the output layer's two MFMA kernels
- * (what a roofline needs; keeps the timed region of a benchmark free of the other families' event records) */
+ * (what a roofline needs; keeps the timed region of a benchmark free of the other families' event records), 3 / 4 only its forward / only its dW + Adam kernel
+ * (an event pair costs the step ~8 us: a benchmark that alternates 3 and 4 between its timed regions measures both kernels live at half that price) */
 int ntf_kernel_times(ntf_engine* e, int enable, const char** names, double* ms, int64_t* calls, int cap);
 
 /* ---- stateless kernels on caller-owned device memory (used by tests and micro-benchmarks) */

@@ -73,10 +73,24 @@ struct ntf_engine {
     std::vector<float*> Wp, bp;       // flipout perturbation operands per layer
     float *partial = nullptr, *row_fix = nullptr, *d_loss = nullptr, *ent_mc = nullptr, *ent_mean = nullptr;
     float *dh_slab = nullptr;         // fused path: partial d(hidden) slabs
-    char* fws = nullptr;              // fused path: sign-bit images, h*s_in, loss partials
+    char* fws = nullptr;              // fused path: sign-bit images, h*s_in, loss partials - of the CURRENT step: one of the two sets below, by step parity
+    char* fws_set[2] = {nullptr, nullptr};
+    // Head prefetch (round 4): what a fused train step needs before its forward kernel and that depends on the batch's rows and the hidden layer only - the sampled
+    // negatives, the transposed s_out words, gather -> hidden layer -> h images (k_head) - is issued for the NEXT batch of the staged order on the side stream, behind
+    // this step's hidden-layer backward (+ its Adam), i.e. beside the dW kernel, into the other workspace set.  hp = what was issued; a step takes it when it is that batch.
+    int head_prefetch = 1;            // NTF_HEAD_PREFETCH=0: everything at the head of its own step (A/B runs)
+    struct { bool valid = false; uint64_t step = 0; const int64_t* rows = nullptr; int B = 0; } hp;
+    const int64_t* hp_next_rows = nullptr; int hp_next_B = 0;     // the batch that follows in the staged order (ntf_step_staged), 0: unknown
+    bool hidden_adam_done = false;    // this step's Adam of the hidden layers already ran on the side stream (in front of the prefetched head)
+    int64_t hp_used = 0;
     float* gemm_slab = nullptr;       // split-K partial sums of the generic GEMM
     double* d_kl = nullptr; double* d_acc = nullptr; int64_t* d_acc_steps = nullptr;
     int fwd_kernel = -1;
+#ifdef NTF_DIAG
+    // NTF_COSCHED=ncg (a -DNTF_DIAG build; RESULTS ARE GARBAGE): the co-scheduling experiment of DESIGN.md section 4 - the forward kernel on NRB * ncg workgroups (one
+    // per CU) while, on the side stream, the dW + Adam kernel of the PREVIOUS step's operands fills the CUs it leaves free; the step's own dW launch is skipped
+    int cosched = 0; bool cosched_have = false; FusedDw cosched_dw; hipEvent_t ev_co0 = nullptr, ev_co1 = nullptr;
+#endif
     int lean = 1;                     // NTF_LEAN=0: the dW epilogue also writes the f32 copy of the next step's sigma * eps (round 3's 64 B per pair; A/B runs)
     int dw_kernel = 1;                // NTF_DW_KERNEL=0: k_out_dw_p2 (one 256-expert workgroup per CU) instead of k_out_dw_q (A/B runs)
     int dw_ksplit = 0;                // 0: automatic (few expert tiles -> split the dW kernel's K range), else forced (NTF_DW_KSPLIT)
@@ -88,7 +102,7 @@ struct ntf_engine {
     uint64_t seed = 0, step = 0;
     int maxhid = 0;
     // timing
-    int timing = 0;                   // 0 off, 1 every kernel family, 2 only the output layer's two MFMA kernels (the roofline's kernels)
+    int timing = 0;                   // 0 off, 1 every kernel family, 2 only the output layer's two MFMA kernels (the roofline's kernels), 3 / 4 only its forward / only its dW kernel
     std::vector<TimeRec> recs;
     std::vector<hipEvent_t> pool;
     double fam_ms[F_COUNT] = {0}; int64_t fam_calls[F_COUNT] = {0};
@@ -130,7 +144,10 @@ struct ntf_engine {
 
 struct Scope {
     ntf_engine* e; int fam; hipEvent_t a = nullptr, b = nullptr;
-    bool on() const { return e->timing == 1 || (e->timing == 2 && (fam == F_OUT_FUSED_FWD || fam == F_OUT_FUSED_DW || fam == F_OUT_FWD || fam == F_OUT_BWD_DW)); }
+    bool on() const {
+        const bool fwd = fam == F_OUT_FUSED_FWD || fam == F_OUT_FWD, dw = fam == F_OUT_FUSED_DW || fam == F_OUT_BWD_DW;
+        return e->timing == 1 || (e->timing == 2 && (fwd || dw)) || (e->timing == 3 && fwd) || (e->timing == 4 && dw);
+    }
     Scope(ntf_engine* e_, int f) : e(e_), fam(f) {
         if (!on()) return;
         auto get = [&]() { hipEvent_t ev; if (!e->pool.empty()) { ev = e->pool.back(); e->pool.pop_back(); } else hipEventCreate(&ev); return ev; };
@@ -204,6 +221,10 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
     if (const char* dk = getenv("NTF_DW_KERNEL")) e->dw_kernel = atoi(dk);
     if (const char* ln = getenv("NTF_LEAN")) e->lean = atoi(ln);
+    if (const char* hp = getenv("NTF_HEAD_PREFETCH")) e->head_prefetch = atoi(hp);
+#ifdef NTF_DIAG
+    if (const char* co = getenv("NTF_COSCHED")) e->cosched = atoi(co);
+#endif
     if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
@@ -247,7 +268,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B)); A(dmalloc(e, &e->gemm_slab, kGemmSlabFloats));
     if (rc == NTF_OK && fused_ok(e)) {
         A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
-        A(dmalloc(e, &e->fws, (int64_t)fused_workspace_bytes(B, e->layers[e->L - 1].in, M)));
+        for (int k = 0; k < 2; ++k) A(dmalloc(e, &e->fws_set[k], (int64_t)fused_workspace_bytes(B, e->layers[e->L - 1].in, M)));
+        e->fws = e->fws_set[0];
         if (cfg->mfma != NTF_MFMA_F32 && e->layers[e->L - 1].in == 128) {
             A(dmalloc(e, &e->pl_mu, fused_planes_elems(M, 128)));
             if (cfg->bayesian) A(dmalloc(e, &e->pl_wp, fused_planes_elems(M, 128)));
@@ -283,7 +305,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     for (auto& p : e->Wp) dfree(p);
     for (auto& p : e->bp) dfree(p);
     dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_acc); dfree(e->d_acc_steps);
-    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws); dfree(e->pl_mu); dfree(e->pl_wp); dfree(e->gemm_slab); dfree(e->tk_vals); dfree(e->tk_idx);
+    dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws_set[0]); dfree(e->fws_set[1]); dfree(e->pl_mu); dfree(e->pl_wp); dfree(e->gemm_slab); dfree(e->tk_vals); dfree(e->tk_idx);
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : e->pool) hipEventDestroy(ev);
@@ -458,9 +480,10 @@ extern "C" int ntf_reset_optimizer(ntf_engine* e) {
     return NTF_OK;
 }
 extern "C" int ntf_set_lr(ntf_engine* e, float lr) { if (!e) return NTF_EINVAL; e->lr = lr; return NTF_OK; }
-extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; e->pre_valid = false; return NTF_OK; }
+extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; e->pre_valid = false; e->hp.valid = false; return NTF_OK; }
 extern "C" int ntf_skip_step(ntf_engine* e) { if (!e) return NTF_EINVAL; e->step += 1; return NTF_OK; }
 extern "C" int ntf_prefetched_steps(ntf_engine* e, int64_t* steps) { if (!e || !steps) return NTF_EINVAL; *steps = e->pre_used; return NTF_OK; }
+extern "C" int ntf_head_prefetch_hits(ntf_engine* e, int64_t* steps) { if (!e || !steps) return NTF_EINVAL; *steps = e->hp_used; return NTF_OK; }
 extern "C" int ntf_range_fallbacks(ntf_engine* e, int64_t* steps) {
     if (!e || !steps) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
@@ -709,6 +732,36 @@ static int side_stream(ntf_engine* e) {
     return NTF_OK;
 }
 
+// gather -> hidden layer -> operand images of one batch as ONE kernel (ntf_head.hip) into workspace `ws`; `want_planes`: also the dW kernel's h planes / s_in words.
+// kl == null: no KL terms (they are in the step's sum already); with_bias: the extra workgroups that produce the output layer's bias operand; rflag: where an
+// activation beyond the fp16 window is reported (this step's flag, or the next step's slot for a prefetched head).
+static void head_launch(ntf_engine* e, hipStream_t st, const StepCtx& c, char* ws, bool want_planes, double* kl, bool with_bias, int* rflag, bool rows_part = true) {
+    const LayerInfo& l0 = e->layers[0]; const LayerInfo& lo = e->layers[e->L - 1];
+    const int M = e->cfg.dims[e->L];
+    const FusedWsPtrs wp = fused_ws_ptrs(ws, c.B, lo.in, M);
+    HeadArgs a;
+    a.B = c.B; a.Bpad = rows_part ? wp.Bpad : 0; a.D = l0.in; a.mode = e->cfg.input_mode == NTF_INPUT_DENSE ? 0 : 1; a.bayes = e->cfg.bayesian;
+    a.rows = c.rows_dev; a.s_indptr = e->s_indptr; a.s_indices = e->s_indices; a.table = e->table; a.Xall = e->Xall;
+    a.mu0 = e->P + l0.off[NTF_P_WEIGHT]; a.b0 = e->P + l0.off[NTF_P_BIAS];
+    a.X = e->act[0]; a.act1 = e->act[1]; a.hz = wp.hz; a.hs = wp.hs; a.sinbits = wp.sinbits;
+    a.hb = want_planes ? wp.hb : nullptr; a.sinT = wp.sinT;
+    a.h_scale = kH16Scale;
+    const bool guard = mfma_np(e) == 2 && rflag != nullptr;
+    a.h_limit = guard ? 65504.f / kH16Scale : 0.f; a.rflag = guard ? rflag : nullptr;
+    if (e->cfg.bayesian) {
+        const double share = e->ep ? 1.0 / (double)e->ep_world : 1.0;   // expert shards: a replicated layer's KL is counted once over the shards
+        a.rho0 = e->P + l0.off[NTF_P_RHO_WEIGHT]; a.rhob0 = e->P + l0.off[NTF_P_RHO_BIAS];
+        a.eps_w0 = normal_spec(e, c, 0, T_EPS_W); a.eps_b0 = normal_spec(e, c, 0, T_EPS_B);
+        a.si0 = sign_spec(e, c, 0, T_S_IN, l0.in); a.so0 = sign_spec(e, c, 0, T_S_OUT, l0.out); a.si1 = sign_spec(e, c, e->L - 1, T_S_IN, lo.in);
+        a.klw_w0 = share / (double)l0.nw(); a.klw_b0 = share / (double)l0.out; a.kl = kl;
+        if (with_bias) {
+            a.M = lo.out; a.rho_b1 = e->P + lo.off[NTF_P_RHO_BIAS]; a.mu_b1 = e->P + lo.off[NTF_P_BIAS]; a.eps_b1 = normal_spec(e, c, e->L - 1, T_EPS_B); a.bp1 = e->bp[e->L - 1];
+            a.klw_b1 = 1.0 / (double)e->Mg;
+        }
+    }
+    launch_head(st, a);
+}
+
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
 static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     int r;
@@ -725,6 +778,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                           (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
     // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
     const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
+    bool hp_hit = false, hp_stale = false;
+    if (fused) e->fws = e->fws_set[c.step & 1];     // (every kernel of a step works in ONE of the two workspace sets: a prefetched head of step t + 1 fills the other beside step t's dW kernel)
     if (c.part >= 2) goto backward;   // expert-sharded step, later phases
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
     {
@@ -732,14 +787,22 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                             !(c.inj && c.inj->eps_w[e->L - 1]);   // (an injected eps: the operands are made from it in this step)
         e->pre_valid = false;   // consumed, or stale
         use_pre = pre_ok;
+        // the previous step's side stream may have run this batch's head already (see `head prefetch` below)
+        const bool had = e->hp.valid; e->hp.valid = false;
+        if (had && use_pre && !use_head) use_pre = false;     // (a step that cannot take ANY k_head - injected tensors - starts from scratch: the prefetched head's KL terms are dropped with the scalars)
         if (use_pre) e->pre_used += 1;
+        if (had && use_pre && use_head) {
+            hp_hit = c.train && e->hp.step == c.step && e->hp.rows == c.rows_dev && e->hp.B == B && !c.inj;
+            hp_stale = !hp_hit;       // another batch than the one it was issued for: its KL terms (functions of the parameters alone) are in this step's sum already
+            if (hp_hit) e->hp_used += 1;
+        }
     }
     // the step's KL sum and fp16x3 range flag: zero, or the values the previous step's dW epilogue produced for this one (moved into place by that step's Adam launch
     // if pre_rotated, else here)
     if (e->cfg.bayesian) { if (!(use_pre && e->pre_rotated)) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0); }
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
     e->pre_rotated = false;
-    if (fused && e->side_bwd) {
+    if (fused && e->side_bwd && !hp_hit) {
         // Three streams through the step's head (round 3; profiles/r3_step_timeline.md).  What precedes the forward kernel is a chain of small latency-bound
         // launches and one HBM-bound pass, and most links of it do not depend on each other:
         //   side (st3): the output layer's operand producer (eps, sigma, Wp, split planes, KL: one pass over 2 x M x H floats, 0.12 ms at config 2) - parameters only;
@@ -775,7 +838,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         aux = true;
     }
     if (!use_head && (r = make_input(e, c))) return r;
-    if (!aux && (r = sample_negatives(e, c))) return r;
+    if (!aux && !hp_hit && (r = sample_negatives(e, c))) return r;
     if (fused) {
         if (!use_head && (r = forward_layers(e, c, false, true))) return r;
         FusedOut f;
@@ -805,30 +868,11 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.c_lo = e->ep_lo;
         if (use_head) {
             Scope t(e, F_GEMM_HIDDEN);
-            const LayerInfo& l0 = e->layers[0];
-            const FusedWsPtrs wp = fused_ws_ptrs(e->fws, B, lo.in, M);
-            HeadArgs a;
-            a.B = B; a.Bpad = wp.Bpad; a.D = l0.in; a.mode = e->cfg.input_mode == NTF_INPUT_DENSE ? 0 : 1; a.bayes = e->cfg.bayesian;
-            a.rows = c.rows_dev; a.s_indptr = e->s_indptr; a.s_indices = e->s_indices; a.table = e->table; a.Xall = e->Xall;
-            a.mu0 = e->P + l0.off[NTF_P_WEIGHT]; a.b0 = e->P + l0.off[NTF_P_BIAS];
-            a.X = e->act[0]; a.act1 = e->act[1]; a.hz = wp.hz; a.hs = wp.hs; a.sinbits = wp.sinbits;
-            a.hb = (c.train && e->cfg.mfma != NTF_MFMA_F32) ? wp.hb : nullptr; a.sinT = wp.sinT;
-            a.h_scale = f.h_scale;
-            const bool guard = f.np == 2 && f.rflag != nullptr;
-            a.h_limit = guard ? 65504.f / f.h_scale : 0.f; a.rflag = guard ? f.rflag : nullptr;
-            if (e->cfg.bayesian) {
-                const double share = e->ep ? 1.0 / (double)e->ep_world : 1.0;   // expert shards: a replicated layer's KL is counted once over the shards
-                a.rho0 = e->P + l0.off[NTF_P_RHO_WEIGHT]; a.rhob0 = e->P + l0.off[NTF_P_RHO_BIAS];
-                a.eps_w0 = normal_spec(e, c, 0, T_EPS_W); a.eps_b0 = normal_spec(e, c, 0, T_EPS_B);
-                a.si0 = sign_spec(e, c, 0, T_S_IN, l0.in); a.so0 = sign_spec(e, c, 0, T_S_OUT, l0.out); a.si1 = f.s_in;
-                a.klw_w0 = share / (double)l0.nw(); a.klw_b0 = share / (double)l0.out; a.kl = e->d_kl;
-                a.M = lo.out; a.rho_b1 = e->P + lo.off[NTF_P_RHO_BIAS]; a.mu_b1 = f.mu_b; a.eps_b1 = normal_spec(e, c, e->L - 1, T_EPS_B); a.bp1 = e->bp[e->L - 1];
-                a.klw_b1 = 1.0 / out_nb;
-            }
-            launch_head(e->st, a);
+            // (hp_hit: this batch's head ran beside the previous step's dW kernel; hp_stale: a head ran for another batch - redo it here, without the KL terms and the bias operand)
+            if (!hp_hit) head_launch(e, e->st, c, e->fws, c.train && e->cfg.mfma != NTF_MFMA_F32, hp_stale ? nullptr : e->d_kl, !hp_stale, f.rflag);
             f.h_ready = 1;
             if (!f.planes_ready) launch_fused_out_fwd(e->st, f, 1);   // (Fnn: the split planes of mu are made per step)
-            if (c.train && e->cfg.mfma != NTF_MFMA_F32 && !swt_aux) {   // (one stream: the s_out words were not made beside the head)
+            if (c.train && e->cfg.mfma != NTF_MFMA_F32 && !swt_aux && !hp_hit) {   // (one stream: the s_out words were not made beside the head)
                 const bool dz_packed = f.np == 2 && lo.in == 128 && e->pl_mu != nullptr;
                 launch_fused_prep_planes(e->st, B, lo.in, M, e->cfg.bayesian, e->fws, f.np, f.h_scale, dz_packed ? &f.s_out : nullptr, 0, 1);
             }
@@ -852,6 +896,22 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, nullptr,
                                    nullptr, nullptr, nullptr, 0, 3, 1.f, nullptr, range_ptr(e));
         }
+#ifdef NTF_DIAG
+        if (e->cosched > 0 && c.train) {
+            f.ncg_limit = e->cosched;
+            static const bool fwd_only = getenv("NTF_COSCHED_FWD_ONLY") != nullptr;      // the forward kernel alone on its reduced grid (no dW at all in the step)
+            if (e->cosched_have && !fwd_only) {
+                if ((r = side_stream(e))) return r;
+                if (!e->ev_co0) { HIPCHK(e, hipEventCreateWithFlags(&e->ev_co0, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_co1, hipEventDisableTiming)); }
+                HIPCHK(e, hipEventRecord(e->ev_co0, e->st));
+                { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }       // enqueued first: its workgroups take their CUs, the dW workgroups the rest
+                HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_co0, 0));
+                { StreamRestore guard{e, e->st}; e->st = e->st3; Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, e->cosched_dw); }
+                HIPCHK(e, hipEventRecord(e->ev_co1, e->st3));
+                HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_co1, 0));
+            } else { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
+        } else
+#endif
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
         nslots = fused_loss_slots(M);
@@ -970,6 +1030,9 @@ backward:
                 }
                 if (e->cfg.bayesian) { e->fin_pend = true; e->fin_eps = normal_spec(e, c, l, T_EPS_B); e->fin_klw = kl_share / ((float)out_nb * (float)c.global_B); }
             }
+#ifdef NTF_DIAG
+            if (e->cosched > 0) { e->cosched_dw = f; e->cosched_have = true; goto dw_done; }      // (this step's dW rides beside the NEXT step's forward kernel: timing only)
+#endif
             { Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f); }
         dw_done:;
         } else {
@@ -1025,6 +1088,31 @@ backward:
         }
     }
     if (side) {
+        // ---- head prefetch: behind this step's hidden-layer backward the side stream is idle while the dW kernel runs (~0.3 ms at config 2).  Everything the NEXT batch of
+        // the staged order needs before its forward kernel and that does not depend on the output layer goes there: Adam of the hidden layers (their gradients are
+        // complete), the negative sampler, the transposed s_out words and k_head - into the other workspace set, with the KL terms and the range flag in the NEXT step's
+        // slots (beside what this step's dW epilogue puts there).  What stays between the dW kernel and the next forward kernel: Adam of the output biases (+ the
+        // rotation of the scalars), the bias operand (apply_adam) and the two range-fallback launches.  Taken by run_step when the next call IS that batch (hp_hit).
+        const bool can_head = e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
+                              (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
+        if (e->head_prefetch && can_head && c.fuse_adam && e->cfg.fuse_adam == 1 && e->pre_valid && e->pre_step == c.step + 1 && e->hp_next_B > 0 && !c.inj &&
+            e->cfg.nsd != NTF_NSD_UNIGRAM_B && c.global_B == B && !e->ep) {
+            e->st = e->st3;
+            {   // Adam of the hidden layers: [0, first float of the output layer) - apply_adam then leaves that range alone
+                Scope t(e, F_ADAM);
+                const double b1 = 0.9, b2 = 0.999, tt = (double)(e->adam_t + 1);
+                const int64_t rg[2] = {0, lo.off[NTF_P_WEIGHT]};
+                launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, 1, e->lr, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)), (float)std::sqrt(1.0 - std::pow(b2, tt)));
+                e->hidden_adam_done = true;
+            }
+            StepCtx n; n.rows_dev = e->hp_next_rows; n.B = e->hp_next_B; n.global_B = e->hp_next_B; n.step = c.step + 1; n.train = true; n.row0 = 0;
+            char* ws_next = e->fws_set[n.step & 1];
+            if ((r = sample_negatives(e, n))) return r;
+            const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
+            { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1); }
+            { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr); }
+            e->hp.valid = true; e->hp.step = n.step; e->hp.rows = n.rows_dev; e->hp.B = n.B;
+        }
         HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
         e->st = restore.main;
         HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
@@ -1043,7 +1131,8 @@ static int apply_adam(ntf_engine* e) {
     const LayerInfo& lo = e->layers[e->L - 1];
     const int64_t w0 = lo.off[NTF_P_WEIGHT], w1 = lo.off[NTF_P_BIAS];  // segments are laid out weight, bias, rho_weight, rho_bias
     int64_t rg[6]; int fin[3] = {0, 0, 0}; int n = 0;
-    rg[2 * n] = 0; rg[2 * n + 1] = w0; ++n;
+    if (!e->hidden_adam_done) { rg[2 * n] = 0; rg[2 * n + 1] = w0; ++n; }      // (head prefetch: the hidden layers' Adam ran on the side stream, in front of the next batch's head)
+    e->hidden_adam_done = false;
     if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS];
         // the live lo.out floats of the two bias segments, not their 256-byte padding: a finalised range would push the KL gradient into the padding of rho_bias
         // (p = 0, g = 0 there) and read an injected eps_b past its lo.out floats
@@ -1054,6 +1143,13 @@ static int apply_adam(ntf_engine* e) {
     launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2), fin, &e->fin_eps, e->fin_klw,
                        rotate ? e->d_kl : nullptr);
     e->pre_rotated = rotate; e->fin_pend = false;
+    if (e->hp.valid && rotate && e->hp.step == e->step) {
+        // the prefetched head left out what depends on the output layer's biases, which this launch has just updated: their Flipout operand sigma_b eps_b and KL of the
+        // next step - k_head's bias workgroups alone, into the scalars the rotation above has just moved into place
+        StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B; nx.rows_dev = e->hp.rows; nx.train = true;
+        Scope t2(e, F_FLIPOUT_OPERAND);
+        head_launch(e, e->st, nx, e->fws_set[nx.step & 1], false, e->d_kl, true, nullptr, false);
+    }
     return NTF_OK;
 }
 
@@ -1152,8 +1248,13 @@ extern "C" int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t
     if (offset < 0 || B < 1 || offset + B > n || global_offset < 0 || global_offset + global_B > n || offset < global_offset ||
         offset + B > global_offset + global_B)
         FAIL(e, NTF_EINVAL, "step_staged: shard / batch outside the staged order");
-    return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, train != 0, apply != 0, true, e->h_order.data() + global_offset, global_B,
-                       false, (uint32_t)(offset - global_offset));
+    // the batch that follows in the staged order (an epoch walks it front to back, src/mdl/fnn.py:118): what the head prefetch works for
+    const int64_t no = offset + B; const int nB = (int)std::min<int64_t>(B, n - no);
+    if (train && apply && global_offset == offset && global_B == B && nB >= 1) { e->hp_next_rows = e->d_order + no; e->hp_next_B = nB; } else e->hp_next_B = 0;
+    const int rc = step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, train != 0, apply != 0, true, e->h_order.data() + global_offset, global_B,
+                               false, (uint32_t)(offset - global_offset));
+    e->hp_next_B = 0;
+    return rc;
 }
 
 extern "C" int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, float* loss_out) {
@@ -1542,7 +1643,7 @@ extern "C" int ntf_kernel_times(ntf_engine* e, int enable, const char** names, d
     int n = std::min(cap, (int)F_COUNT);
     for (int i = 0; i < n; ++i) { if (names) names[i] = kFamNames[i]; if (ms) ms[i] = e->fam_ms[i]; if (calls) calls[i] = e->fam_calls[i]; }
     for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_calls[i] = 0; }
-    e->timing = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+    e->timing = enable < 0 ? 0 : (enable > 4 ? 1 : enable);
     return F_COUNT;
 }
 

@@ -28,6 +28,7 @@ struct FusedOut {
     float w_scale = 1.f, h_scale = 1.f, dz_scale = 1.f;
     int wide = 3;                                   // np = 2 training step: 3 (default) k_out_fwd_h3x - 64-expert tiles, phases rotated across tiles; 4 k_out_fwd_h3y (sixteen-row waves,
                                                     // two per SIMD: the A/B form); 0 the 32-expert-tile kernel k_out_fwd_b6
+    int ncg_limit = 0;                              // > 0 (diagnostics, NTF_COSCHED): at most this many column groups, i.e. a forward grid of NRB * ncg_limit workgroups that leaves CUs free
     int planes_ready = 0;
     int h_ready = 0;                                // the zero-padded h, h * s_in and the s_in words are in the workspace already (ntf_head.hip): phase 1 skips k_prep_h
     // inference (train = 0, probs = 1): dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale instead of the loss; the row entropy partials go to the workspace

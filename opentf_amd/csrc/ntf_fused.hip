@@ -852,6 +852,19 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     out_dw_f32_body<H, BAYES, ADAM>(p, smem);
 }
+// the same as the range FALLBACK behind a split-product kernel that cannot run the f32 body itself (k_out_dw_q, the split-K launches): it runs only in a step whose
+// range flag is raised - in every other step it is a no-op on the critical path, so it is launched on ONE round of workgroups that walk the tiles (p.ntile of
+// them) instead of one workgroup per tile: 913 early exits of 128 KB-LDS workgroups took 5 us per step, 256 take under 2
+template <int H, bool BAYES, bool ADAM>
+__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_fallback(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (range_guard_skip(p.rflag, p.rmode, false)) return;
+    for (int t = (int)blockIdx.x; t < p.ntile; t += (int)gridDim.x) {
+        DwArgs q = p; q.rmode = 0; q.wg_begin = p.wg_begin + t - (int)blockIdx.x;      // (the body takes its tile as wg_begin + blockIdx.x)
+        out_dw_f32_body<H, BAYES, ADAM>(q, smem);
+        __syncthreads();
+    }
+}
 
 // ================================================================================================
 // bf16x6 variant: every f32 operand x is split exactly into three bf16 values x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1),
@@ -2680,7 +2693,8 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
 }
 
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
-    const Geom g = geom(f.B, f.M);
+    Geom g = geom(f.B, f.M);
+    if (f.ncg_limit > 0) g.NCG = std::max(1, std::min(g.NCG, f.ncg_limit));
     const WsLayout w = ws_layout(f.B, f.H, f.M);
     char* ws = static_cast<char*>(f.ws);
     uint32_t* sbits = reinterpret_cast<uint32_t*>(ws + w.sbits);
@@ -2928,9 +2942,12 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
         a.rmode = 2;   // fall through: the exact-f32 kernel, which runs only when the range flag is raised
     }
 exact_f32:
-#define NTF_DW1(HH, BY) do { auto kf = f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>; const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);              \
+    a.ntile = grid;
+#define NTF_DW1(HH, BY) do { const bool fb = a.rmode == 2;                                                                                    \
+        auto kf = fb ? (f.adam ? k_out_dw_fallback<HH, BY, true> : k_out_dw_fallback<HH, BY, false>) : (f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>);   \
+        const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);                                                                \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
+        hipLaunchKernelGGL(kf, dim3(fb ? std::min(grid, 256) : grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
 #define NTF_DW(HH) do { if (f.bayes) NTF_DW1(HH, true); else NTF_DW1(HH, false); } while (0)
     if (f.H == 128) NTF_DW(128); else if (f.H == 64) NTF_DW(64); else NTF_DW(32);
 #undef NTF_DW

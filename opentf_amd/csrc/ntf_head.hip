@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
         const double s = wave_reduce_sum_d((double)kl);
         if (lane == 0) red[wave] = s;
         __syncthreads();
-        if (tid == 0) atomicAdd(p.kl, (red[0] + red[1] + red[2] + red[3]) * p.klw_b1);
+        if (tid == 0 && p.kl) atomicAdd(p.kl, (red[0] + red[1] + red[2] + red[3]) * p.klw_b1);
         return;
     }
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
         if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
     }
     __syncthreads();
-    if (BAYES && blockIdx.x == 0 && tid == 0)
+    if (BAYES && blockIdx.x == 0 && tid == 0 && p.kl)      // (kl == null: a head redone for another batch than the prefetched one - its KL terms, functions of the parameters alone, are counted)
         atomicAdd(p.kl, (red[0] + red[1] + red[2] + red[3]) * p.klw_w0 + (red[4] + red[5] + red[6] + red[7]) * p.klw_b0);
 
     // ---- 4. the dW kernel's planes of this K block: [plane = h hi, h lo, (hs hi, hs lo)][slot][32 rows] fp16, slot = 32 (j % 4) + j / 4 (k_prep_planes_T)

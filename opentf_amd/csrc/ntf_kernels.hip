@@ -306,7 +306,7 @@ void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, i
                             uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale, int* rflag, const int* only_if) {
     if (n <= 0) return;
     const int64_t quads = (n + 3) / 4;
-    const int blocks = (int)std::min<int64_t>((quads + 255) / 256, only_if ? 1024 : 2048);
+    const int blocks = (int)std::min<int64_t>((quads + 255) / 256, only_if ? 256 : 2048);   // (only_if: a no-op in all but the rarest step - one short round of workgroups)
     hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale, (planes_w && np == 2) ? rflag : nullptr, only_if);
 }
 

@@ -59,6 +59,7 @@ SYMBOLS = {
     "ntf_skip_step": (C.c_int, [_P]),
     "ntf_range_fallbacks": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_prefetched_steps": (C.c_int, [_P, C.POINTER(_I64)]),
+    "ntf_head_prefetch_hits": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_get_dlogits": (C.c_int, [_P, _P, _I64]),
     "ntf_get_negatives": (C.c_int, [_P, _P, _I64]),
     "ntf_train_step": (C.c_int, [_P, _P, _I32, _P, _P]),
@@ -299,6 +300,12 @@ class Engine:
         self._ck(lib().ntf_prefetched_steps(self._h, C.byref(n)))
         return n.value
 
+    def head_prefetch_hits(self):
+        """steps whose sampler / gather / hidden layer had run beside the previous step's dW kernel (include/opentf_amd.h)"""
+        n = C.c_int64()
+        self._ck(lib().ntf_head_prefetch_hits(self._h, C.byref(n)))
+        return n.value
+
     def dlogits(self, B):
         """d loss / d z [B, M] of the output layer after the last backward (B = that step's batch)"""
         out = np.empty((int(B), self.dims[-1]), dtype=np.float32)
@@ -506,7 +513,7 @@ class Engine:
         self._ck(lib().ntf_synchronize(self._h))
 
     def kernel_times(self, enable=True):
-        """enable: False / True (every kernel family) / 2 (only the output layer's forward and dW kernels)"""
+        """enable: False / True (every kernel family) / 2 (only the output layer's forward and dW kernels) / 3 (only its forward kernel) / 4 (only its dW kernel)"""
         cap = 32
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); calls = (C.c_int64 * cap)()
         n = lib().ntf_kernel_times(self._h, int(enable), names, ms, calls, cap)

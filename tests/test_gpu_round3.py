@@ -58,6 +58,58 @@ def test_operands_written_by_the_adam_epilogue_on_expert_shards(monkeypatch):
     for k in a[3]: assert np.array_equal(a[3][k], b[3][k]), k
 
 
+# ------------------------------------------------------------------------------------------ head prefetch (round 4)
+@pytest.mark.parametrize("nsd,bayesian", [("uniform", True), ("unigram", True), ("uniform", False)])
+def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own_step(nsd, bayesian, monkeypatch):
+    """ntf_head_prefetch_hits: sampler, s_out words, gather -> hidden layer -> h images of batch t + 1 issued on the side stream of step t (behind its hidden-layer
+    backward and Adam, into the other workspace set, KL terms and range flag in the next step's slots) against the same work at the head of step t + 1: the same
+    kernels on the same inputs - parameters bit for bit, losses to the order of the KL sum's double atomics.  The sequence walks every way out of the fast path: a
+    ragged last batch, an evaluation step behind a train step (head redone without its KL terms), parameters rewritten from outside, inference in between."""
+    ds = make_dataset("dblp", d=128, seed=9, n_rows=3000, n_experts=70_000)
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(2).permutation(ds["N"])[:2500].astype(np.int64)
+    out = []
+    for hp in ("0", "1"):
+        monkeypatch.setenv("NTF_HEAD_PREFETCH", hp)
+        e = _mk(ds, dims, bayesian, 1000, nsd)
+        l1 = _full_epoch(e, order, 1000)                        # 1000, 1000, 500 rows: steps 2 and 3 find their head done
+        v = _full_epoch(e, order[:700], 1000, train=False)      # (the train step before it had no next batch: nothing was issued)
+        l2 = _full_epoch(e, order[::-1].copy(), 1000)
+        v2 = [e.eval_step(order[:300]), e.eval_step(order[300:900])]     # an eval step right behind a train step that DID issue a head? no: the epoch's last step issues none
+        sd = e.state_dict(); e.load_state_dict(sd)              # parameters touched from outside: prefetched operands and head are stale
+        l3 = _full_epoch(e, order[:2000], 1000)
+        p = e.forward(order[:64], nmc=2) if bayesian else e.forward(order[:64])
+        l4 = _full_epoch(e, order[500:], 1000)
+        out.append(((l1, v, l2, *v2, l3, l4), p, e.state_dict(), e.head_prefetch_hits())); e.close()
+    (la, pa, sa, ha), (lb, pb, sb, hb) = out
+    assert ha == 0 and hb == ((2 + 2 + 1 + 1) if bayesian else 0), (ha, hb)      # (Fnn: no side stream, no prefetch)
+    for x, y in zip(la, lb): assert abs(x - y) <= 1e-9 * abs(x), (x, y)
+    assert np.array_equal(pa, pb)
+    for k in sa: assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_head_prefetch_is_dropped_when_the_next_call_is_another_batch(monkeypatch):
+    """a train step issues the head of the batch that FOLLOWS in the staged order; the caller then steps something else (an evaluation batch, the same batch again):
+    the prefetched head is not used, its KL terms are not counted twice, the results are those of a run without prefetch"""
+    ds = make_dataset("dblp", d=128, seed=4, n_rows=2500, n_experts=20_000)
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(5).permutation(ds["N"])[:2000].astype(np.int64)
+    out = []
+    for hp in ("0", "1"):
+        monkeypatch.setenv("NTF_HEAD_PREFETCH", hp)
+        e = _mk(ds, dims, True, 500, "uniform")
+        e.stage_order(order)
+        ls = [e.step_staged(0, 500, train=True, apply=True, want_loss=True),         # issues the head of rows 500 .. 999
+              e.step_staged(1000, 500, train=True, apply=True, want_loss=True),      # ... but the caller jumps: head redone, KL counted once; issues 1500 .. 1999
+              e.step_staged(1500, 500, train=False, apply=False, want_loss=True),    # an evaluation step on the very batch that was prefetched for training: not taken (train only)
+              e.step_staged(1500, 500, train=True, apply=True, want_loss=True)]      # (no next batch: nothing issued)
+        out.append((ls, e.state_dict(), e.head_prefetch_hits())); e.close()
+    (la, sa, ha), (lb, sb, hb) = out
+    assert ha == 0 and hb == 0
+    for x, y in zip(la, lb): assert abs(x - y) <= 1e-9 * abs(x), (x, y)
+    for k in sa: assert np.array_equal(sa[k], sb[k]), k
+
+
 # ------------------------------------------------------------------------------------------ the one-kernel head (ntf_head.hip)
 @pytest.mark.parametrize("bayesian", [True, False])
 @pytest.mark.parametrize("d,dense,B", [(128, False, 1000), (64, False, 333), (256, False, 77), (128, True, 500)])
