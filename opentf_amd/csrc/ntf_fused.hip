@@ -146,6 +146,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 #endif
 }
+// the same with the source as a wave-uniform base (an SGPR pair) + a 32-bit per-lane byte offset: no 64-bit vector address arithmetic per piece (hipcc spends a
+// v_lshl_add_u64 on every `base + lane offset`: 17 of the forward kernel's ~950 vector instructions per tile)
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
 __device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -2026,7 +2032,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
             const int mat = n / PER_WAVE, nn = n % PER_WAVE;
             const int inst = wave_u * PER_WAVE + nn;
             const char* base = reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)t * (2 * 32 * NP * 256);    // wave-uniform: the tile's planes
-            glds16(base + dsrc[nn], sb + mat * TM + inst * 1024);
+            glds16s(base, dsrc[nn], sb + mat * TM + inst * 1024);
         } else {   // the two bias tiles, branch-free: even waves fetch mu_b's, odd waves bp's (twice each: the same bytes to the same place)
             const int c0 = t * BNT;
             const int which = BAYES ? (wave_u & 1) : 0;
@@ -2119,9 +2125,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
         if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[u][r], pp.u_z, bq[r & 7])) ^ ((swu << (31 - (cr & 31))) & 0x80000000u));
         const bool pos = z > 0.f;
         const float l = pos ? z : z * kLeakySlope;
-        const float lc = fmaxf(l, -80.f);
-        const float tt = 1.f + __builtin_amdgcn_exp2f(lc * -1.4426950408889634f);
-        ltile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, lc), rm, ltile);
+        // (no clamp of l at -80 here: leaky_relu keeps a real logit above -0.01 |z|, and the experts past M are masked with a bias of -8000, i.e. l = -80, in this
+        //  kernel - what the clamp made of the other kernels' -1e30: e^80 is finite, softplus = dz = 0 to rounding)
+        const float tt = 1.f + __builtin_amdgcn_exp2f(l * -1.4426950408889634f);
+        ltile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, l), rm, ltile);
         X1[u][r] = __builtin_amdgcn_rcpf(tt) * (pos ? rsp : rsn);
     };
     // registers r0, r0 + 1 (r0 even) of sub-tile u -> fp16 planes (A operand of dh) + the packed store
@@ -2197,7 +2204,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
         const int c0 = t * BNT;
         const int tn = min(t + 1, t_end - 1);
         if (c0 + BNT > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
-            if (tid < BNT && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -1e30f;
+            if (tid < BNT && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -8000.f;
             __syncthreads();
         }
         const uint32_t sw[2] = {w2.x >> (4 * half), w2.y >> (4 * half)};
