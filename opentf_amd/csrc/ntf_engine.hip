@@ -1107,15 +1107,22 @@ backward:
             }
             StepCtx n; n.rows_dev = e->hp_next_rows; n.B = e->hp_next_B; n.global_B = e->hp_next_B; n.step = c.step + 1; n.train = true; n.row0 = 0;
             char* ws_next = e->fws_set[n.step & 1];
+            // the sampler and the s_out words need the rows and the sign key only: on the auxiliary stream, from the fork on (beside the hidden backward; beside the HBM-bound
+            // dW kernel the 30 MB of k_sign_words_T take ~90 us instead of 19 - behind the hidden backward on ONE stream the chain ended 14 us before the dW kernel)
+            e->st = e->st4;
+            HIPCHK(e, hipStreamWaitEvent(e->st4, e->ev_fork, 0));
             if ((r = sample_negatives(e, n))) return r;
             const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
             { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1); }
+            HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
+            e->st = e->st3;
             { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr); }
             e->hp.valid = true; e->hp.step = n.step; e->hp.rows = n.rows_dev; e->hp.B = n.B;
         }
         HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
         e->st = restore.main;
         HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
+        if (e->hp.valid && e->hp.step == c.step + 1) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));
     }
     return NTF_OK;
 }

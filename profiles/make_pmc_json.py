@@ -19,7 +19,7 @@ for d in dirs:
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 kernels = {}
 for k, d in acc.items():
-    if not k.startswith(("void ntf::", "ntf::")):
+    if not (k.startswith(("void ntf::", "ntf::")) or "k_d2v_" in k or "k_n2v_" in k):     # (the d2v / n2v kernels live in anonymous namespaces)
         continue
     c = {n: sum(v) / len(v) for n, v in d.items()}
     e = {"dispatches": max(len(v) for v in d.values()), "sq": {n: v for n, v in c.items() if n.startswith("SQ_")}}
