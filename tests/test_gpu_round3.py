@@ -58,6 +58,29 @@ def test_operands_written_by_the_adam_epilogue_on_expert_shards(monkeypatch):
     for k in a[3]: assert np.array_equal(a[3][k], b[3][k]), k
 
 
+# ------------------------------------------------------------------------------------------ the dW + Adam kernel as two half-tile workgroups per CU (round 4)
+@pytest.mark.parametrize("bayesian,M,B", [(True, 70_000, 1000), (True, 3333, 333), (False, 70_001, 129), (True, 257, 64)])
+def test_half_tile_weight_gradient_kernel_equals_the_one_workgroup_per_cu_kernel(bayesian, M, B, monkeypatch):
+    """k_out_dw_q (NTF_DW_KERNEL=1, default: 128-expert workgroups, two per CU, h * s_in rebuilt from transposed s_in words) against k_out_dw_p2 (NTF_DW_KERNEL=0):
+    the same MFMA sequence per accumulator and the same epilogue - gradients (fuse_adam = 0) and the parameters after fused-Adam steps with the next step's operands
+    produced in the epilogue, bit for bit; ragged last expert tile, ragged last row block, a layer smaller than one old tile"""
+    ds = make_dataset("dblp", d=128, seed=17, n_rows=1500, n_experts=M)
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(8).permutation(ds["N"])[:2 * B + 5].astype(np.int64)
+    out = []
+    for k in ("0", "1"):
+        monkeypatch.setenv("NTF_DW_KERNEL", k)
+        e = _mk(ds, dims, bayesian, B, "uniform", fuse_adam=0)
+        loss = e.backward(order[:B]); g = e.grads(); e.close()
+        e = _mk(ds, dims, bayesian, B, "uniform")
+        l2 = _full_epoch(e, order, B)                    # three fused-Adam steps, the second and third on operands the first two epilogues produced
+        out.append((loss, g, l2, e.state_dict(), e.prefetched_steps())); e.close()
+    (la, ga, l2a, sa, pa), (lb, gb, l2b, sb, pb) = out
+    assert la == lb and abs(l2a - l2b) <= 1e-9 * abs(l2a) and pa == pb
+    for k in ga: assert np.array_equal(ga[k], gb[k]), k
+    for k in sa: assert np.array_equal(sa[k], sb[k]), k
+
+
 # ------------------------------------------------------------------------------------------ head prefetch (round 4)
 @pytest.mark.parametrize("nsd,bayesian", [("uniform", True), ("unigram", True), ("uniform", False)])
 def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own_step(nsd, bayesian, monkeypatch):
