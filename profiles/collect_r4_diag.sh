@@ -9,8 +9,8 @@ B="$R/bench.py --no-cpu-baseline --no-f32-line --no-extra-configs"
 if [ -f $R/scratch/var/diag.so ] && nm -D $R/scratch/var/diag.so | grep -q ntf_head_prefetch_hits; then D=$R/scratch/var/diag.so; else
   D=/tmp/diag.so; cd $R/opentf_amd/csrc
   F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -Wno-unused-value -DNTF_DIAG"
-  hipcc $F -fno-slp-vectorize -c ntf_fused.hip -o /tmp/diag_fused.o 2>/dev/null; hipcc $F -c ntf_engine.hip -o /tmp/diag_engine.o 2>/dev/null
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $D ntf_kernels.o /tmp/diag_fused.o ntf_head.o /tmp/diag_engine.o ntf_metrics.o ntf_cooc.o ntf_n2v.o ntf_d2v.o; cd /tmp
+  hipcc $F -fno-slp-vectorize -c ntf_fused.hip -o /tmp/diag_fused.o 2>/dev/null; hipcc $F -fno-slp-vectorize -c ntf_fused_dw.hip -o /tmp/diag_fused_dw.o 2>/dev/null; hipcc $F -c ntf_engine.hip -o /tmp/diag_engine.o 2>/dev/null
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $D ntf_kernels.o /tmp/diag_fused.o /tmp/diag_fused_dw.o ntf_head.o /tmp/diag_engine.o ntf_metrics.o ntf_cooc.o ntf_n2v.o ntf_d2v.o; cd /tmp
 fi
 NTF_LIB_PATH=$D NTF_DW_STAMP_FILE=$O/dw_stamps.bin python3 $B --no-gather-bench --steps 40 --warmup 10 > /dev/null 2>> $O/bench.err
 python3 $R/profiles/dw_stamps.py $O/dw_stamps.bin > $O/dw_stamps.txt 2>&1; rm -f $O/dw_stamps.bin
