@@ -727,6 +727,13 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
 
 struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } };   // launches and timing scopes follow e->st
 static int side_stream(ntf_engine* e) {
+    // NTF_SIDE_PRIO=1 (experiment): the side streams at the lowest HIP priority, so that their kernels take only what the big kernels of the main stream leave
+    static const bool low = getenv("NTF_SIDE_PRIO") && atoi(getenv("NTF_SIDE_PRIO")) > 0;
+    if (low && (!e->st3 || !e->st4)) {
+        int lo = 0, hi = 0; HIPCHK(e, hipDeviceGetStreamPriorityRange(&lo, &hi));     // lo = numerically greatest = least urgent
+        if (!e->st3) { HIPCHK(e, hipStreamCreateWithPriority(&e->st3, hipStreamNonBlocking, lo)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
+        if (!e->st4) { HIPCHK(e, hipStreamCreateWithPriority(&e->st4, hipStreamNonBlocking, lo)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_aux, hipEventDisableTiming)); }
+    }
     if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
     if (!e->st4) { HIPCHK(e, hipStreamCreateWithFlags(&e->st4, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_aux, hipEventDisableTiming)); }
     return NTF_OK;
@@ -1243,6 +1250,7 @@ extern "C" int ntf_stage_order(ntf_engine* e, const int64_t* order, int64_t n) {
     const int64_t limit = row_limit(e);
     for (int64_t i = 0; i < n; ++i) if (order[i] < 0 || order[i] >= limit) FAIL(e, NTF_EINVAL, "stage_order: row id out of range");
     if (e->order_cap < n) { dfree(e->d_order); DM(e, &e->d_order, n); e->order_cap = n; }
+    e->hp.rows = nullptr;      // a head prefetched from the previous order can never be this order's batch (its KL terms stay counted: run_step's `hp_stale`)
     e->h_order.assign(order, order + n);
     HIPCHK(e, hipMemcpyAsync(e->d_order, e->h_order.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->st));
     HIPCHK(e, hipStreamSynchronize(e->st));

@@ -126,6 +126,10 @@ def test_head_prefetch_is_dropped_when_the_next_call_is_another_batch(monkeypatc
               e.step_staged(1000, 500, train=True, apply=True, want_loss=True),      # ... but the caller jumps: head redone, KL counted once; issues 1500 .. 1999
               e.step_staged(1500, 500, train=False, apply=False, want_loss=True),    # an evaluation step on the very batch that was prefetched for training: not taken (train only)
               e.step_staged(1500, 500, train=True, apply=True, want_loss=True)]      # (no next batch: nothing issued)
+        # a new order staged into the same device buffer: the batch at the prefetched OFFSET is another batch now
+        e.stage_order(order[:1500]); e.step_staged(0, 500, train=True, apply=True)           # issues the head of rows 500 .. 999 of this order
+        e.stage_order(order[::-1].copy())
+        ls.append(e.step_staged(500, 500, train=True, apply=True, want_loss=True))          # same offset, same size, other rows: must not be taken
         out.append((ls, e.state_dict(), e.head_prefetch_hits())); e.close()
     (la, sa, ha), (lb, sb, hb) = out
     assert ha == 0 and hb == 0
