@@ -727,13 +727,6 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
 
 struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } };   // launches and timing scopes follow e->st
 static int side_stream(ntf_engine* e) {
-    // NTF_SIDE_PRIO=1 (experiment): the side streams at the lowest HIP priority, so that their kernels take only what the big kernels of the main stream leave
-    static const bool low = getenv("NTF_SIDE_PRIO") && atoi(getenv("NTF_SIDE_PRIO")) > 0;
-    if (low && (!e->st3 || !e->st4)) {
-        int lo = 0, hi = 0; HIPCHK(e, hipDeviceGetStreamPriorityRange(&lo, &hi));     // lo = numerically greatest = least urgent
-        if (!e->st3) { HIPCHK(e, hipStreamCreateWithPriority(&e->st3, hipStreamNonBlocking, lo)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
-        if (!e->st4) { HIPCHK(e, hipStreamCreateWithPriority(&e->st4, hipStreamNonBlocking, lo)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_aux, hipEventDisableTiming)); }
-    }
     if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
     if (!e->st4) { HIPCHK(e, hipStreamCreateWithFlags(&e->st4, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_aux, hipEventDisableTiming)); }
     return NTF_OK;
