@@ -1080,10 +1080,22 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
         if (slot >= 0) st_sum[slot] += tnow - st_prev;
         st_prev = tnow;
     };
+    constexpr int NS0 = (BG + NMAT - 1) / NMAT;     // k-steps the first bundle of a tile touches
+    if (t_beg < t_end) {
+        ldsp_t zb0[NKS] = {};
+#pragma unroll
+        for (int s = 0; s < NS0; ++s) zb0[s] = (ldsp_t)(size_t)(smem_base + zrow[s]);
+#pragma unroll
+        for (int k = 0; k < BG; ++k) z_load(zb0, 0, k, fb[0][k]);
+    }
     stamp(-1);
+    // the s_out words are fetched ONE TILE AHEAD: a lane reads its own row's words (64 cache lines per wave-instruction), and a load issued at the top of the
+    // tile that uses it puts an L2 round trip - and the drain of the previous phase's dzT stores, vmcnt being in order - in front of every tile
+    uint2 w2n = t_beg < t_end ? sign_words(t_beg) : make_uint2(0u, 0u);
     for (int t = t_beg; t < t_end; ++t) {
         const int buf = (t - t_beg) & 1;
-        const uint2 w2 = sign_words(t);
+        const uint2 w2 = w2n;
+        w2n = sign_words(min(t + 1, t_end - 1));
         char* sb = smem + buf * STAGE;
         char* sbp = smem + (buf ^ 1) * STAGE;                 // stage of tile t - 1 (tile t_beg again in the first iteration)
         const uint32_t sbase = lds_addr(sb), sbasep = lds_addr(sbp);
@@ -1126,6 +1138,17 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
                 } else if (ph < 3) {
 #pragma unroll
                     for (int k = 0; k < BG; ++k) load_for(ph + 1, k, fb[0][k]);
+                } else {
+                    // the last bundle of the tile fetches the first bundle of the NEXT tile's zT(0): the DMA of tile t+1 (issued over phase 2) is older than
+                    // everything but the 6 dzT stores this phase has made so far - wait for it here, one bundle before the tile ends, instead of after it, where
+                    // the next tile's first fragments would then be read with no MFMA left to cover them (round 4: ~800 cycles a tile between the tiles)
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    ldsp_t zbn[NKS] = {};
+#pragma unroll
+                    for (int s = 0; s < NS0; ++s) zbn[s] = (ldsp_t)(size_t)(sbasep + zrow[s]);
+#pragma unroll
+                    for (int k = 0; k < BG; ++k) z_load(zbn, 0, k, fb[0][k]);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // the next bundle's fragment reads stay ABOVE this bundle's MFMAs (hipcc otherwise sinks them next to their uses)
 #pragma unroll
@@ -1144,8 +1167,6 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
                 }
             }
         };
-#pragma unroll
-        for (int k = 0; k < BG; ++k) load_for(0, k, fb[0][k]);
         stamp(0);
         run_phase(std::integral_constant<int, 0>{});
         stamp(1);
@@ -1160,8 +1181,6 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
         stamp(5);
         lacc.tile = lt; lacc.end_tile();
         swp = sw[1]; rm_prev = rmask; rsp_prev = rscale_pos; rsn_prev = rscale_neg; rsrc_prev = dz_rsrc;
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the DMA of tile t+1 is older than all but (at most) the 8 dzT stores of the last phase
-        __builtin_amdgcn_s_barrier();
         stamp(6);
     }
 
