@@ -528,6 +528,14 @@ __device__ __forceinline__ void pack_planes(uint32_t p_hi, uint32_t p_lo, uint32
     d0 = __builtin_amdgcn_perm(p_lo, p_hi, 0x05040100u);
     d1 = __builtin_amdgcn_perm(p_lo, p_hi, 0x07060302u);
 }
+// the same two steps in one: f32 -> the element's packed dword (hi | lo << 16), hi = fp16(x), lo = fp16(x - hi), both rounded to nearest even like split_pair_h's
+// conversions.  v_fma_mixhi_f16 reads hi as the fp16 source of an f32 fma and writes the rounded result into the upper half: 2 vector instructions an element
+// against 5 (convert, convert back, subtract, convert, permute) - bit-identical dwords (tests/test_gpu_round3.py, the packed dz of the two forward kernels)
+__device__ __forceinline__ uint32_t split_packed(float x) {
+    uint32_t d;
+    asm("v_cvt_f16_f32 %0, %1\n\tv_fma_mixhi_f16 %0, %0, -1.0, %1 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(x));
+    return d;
+}
 __device__ __forceinline__ float unpack_planes(uint32_t d, float inv_scale) {
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const h2_t v = __builtin_bit_cast(h2_t, d);
@@ -826,6 +834,9 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
 // ------------------------------------------------------------------------------------------------
 // ABL (-DNTF_DIAG builds only, NTF_FWD_ABL; results are wrong for ABL != 0, 9): 1 = no epilogue arithmetic, 2 = no epilogue at all (no splits, no dz stores), 3 = no MFMAs,
 // 9 = phase cycle stamps
+#ifndef H3X_PIPE
+#define H3X_PIPE 5
+#endif
 template <bool BAYES, bool INJ, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1019,11 +1030,9 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
     };
     // registers r0, r0 + 1 (r0 even) of sub-tile u -> fp16 planes (A operand of dh) + the packed store
     auto split_pair_a = [&](int u, int r0, __amdgpu_buffer_rsrc_t rsrc) {
-        uint32_t p0, p1;
-        split_pair_h(X1[u][r0], X1[u][r0 + 1], p0, p1);    // (no clamp: |dz| * dz_scale < 2^14)
-        ad[u][r0 >> 3][0][(r0 & 7) >> 1] = p0; ad[u][r0 >> 3][1][(r0 & 7) >> 1] = p1;
-        uint32_t d0, d1;
-        pack_planes(p0, p1, d0, d1);
+        const uint32_t d0 = split_packed(X1[u][r0]), d1 = split_packed(X1[u][r0 + 1]);    // (no clamp: |dz| * dz_scale < 2^14)
+        ad[u][r0 >> 3][0][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);         // hi plane of the pair
+        ad[u][r0 >> 3][1][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);         // lo plane
         __builtin_amdgcn_raw_buffer_store_b32(d0, rsrc, dz_voff, (32 * u + (r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
         __builtin_amdgcn_raw_buffer_store_b32(d1, rsrc, dz_voff, (32 * u + ((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
     };
@@ -1053,14 +1062,57 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
         if (mat == 0) Y1[jt] = mfma_np<NP>(ad[u][s2], bf, Y1[jt]);
         else { u32x4 asg[3]; signed_a(u, s2, swu, asg); Y2[jt] = mfma_np<NP>(asg, bf, Y2[jt]); }
     };
-    // half an epilogue (registers 8 hf .. 8 hf + 7 of sub-tile u) spread over the NG groups of a phase
-    constexpr int GPR = NG / 8;         // groups per register (2 with Flipout, 1 without)
+    // half an epilogue (registers 8 hf .. 8 hf + 7 of sub-tile u) spread over the NG groups of a phase, TWO REGISTERS AT A TIME: a lone wave issues in order, and
+    // a vector instruction that needs the result of the one before it costs 8.4 cycles against 5.3 for an independent one (6.5 with two chains interleaved;
+    // scratch/probe_valu.hip) - a register's epilogue is one such chain of ~17.  The pair (r0, r0 + 1) that is split together goes through four stages
+    // (logit | exp | log, loss, dz | split + store), stage by stage over both registers, a stage per group (two per group without Flipout).
+    constexpr int GPP = NG / 4;         // groups per register pair (4 with Flipout, 2 without)
+    constexpr int SPG = 4 / GPP;        // stages per group
+    float e_l[2] = {0.f, 0.f}, e_sel[2] = {0.f, 0.f}, e_tt[2] = {1.f, 1.f};     // the pair's state between its stages
     auto ride = [&](const float (&bm)[8], const float (&bq)[8], int u, int hf, int g, uint32_t swu, float rm, float rsp, float rsn, __amdgpu_buffer_rsrc_t rsrc, float& ltile) {
         if (ABL == 2) return;
-        if (g % GPR == 0) {
-            const int r = 8 * hf + g / GPR;
-            epilogue(bm, bq, u, r, swu, rm, rsp, rsn, ltile);
-            if (r & 1) split_pair_a(u, r - 1, rsrc);
+        const int r0 = 8 * hf + 2 * (g / GPP);
+#pragma unroll
+        for (int st = (g % GPP) * SPG; st < (g % GPP + 1) * SPG; ++st) {
+            if (ABL == 1) { if (st == 2) { X1[u][r0] = fmaf(X1[u][r0], rsp, X2[u][r0]); X1[u][r0 + 1] = fmaf(X1[u][r0 + 1], rsp, X2[u][r0 + 1]); } if (st == 3) split_pair_a(u, r0, rsrc); continue; }
+            if (st == 0) {          // logit: bias, s_out sign, leaky_relu; the factor of dz that depends on its branch
+                float z[2], y[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) z[j] = fmaf(X1[u][r0 + j], pp.u_z, bm[(r0 + j) & 7]);
+                if (BAYES) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) y[j] = fmaf(X2[u][r0 + j], pp.u_z, bq[(r0 + j) & 7]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int cr = 32 * u + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2);
+                        y[j] = __uint_as_float(__float_as_uint(y[j]) ^ ((swu << (31 - (cr & 31))) & 0x80000000u));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) z[j] += y[j];
+                }
+                // (no clamp of l at -80 here: leaky_relu keeps a real logit above -0.01 |z|, and the experts past M are masked with a bias of -8000, i.e. l = -80, in
+                //  this kernel - what the clamp made of the other kernels' -1e30: e^80 is finite, softplus = dz = 0 to rounding)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { const bool pos = z[j] > 0.f; e_l[j] = pos ? z[j] : z[j] * kLeakySlope; e_sel[j] = pos ? rsp : rsn; }
+            } else if (st == 1) {   // 1 + e^-l
+#pragma unroll
+                for (int j = 0; j < 2; ++j) e_tt[j] = e_l[j] * -1.4426950408889634f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) e_tt[j] = __builtin_amdgcn_exp2f(e_tt[j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) e_tt[j] += 1.f;
+            } else if (st == 2) {   // softplus(l) = log(1 + e^-l) + l into the row's loss; dz * dz_scale = sigmoid(l) * (row constant of the branch)
+                float lg[2], rc[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) lg[j] = __builtin_amdgcn_logf(e_tt[j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rc[j] = __builtin_amdgcn_rcpf(e_tt[j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) lg[j] = fmaf(lg[j], 0.6931471805599453f, e_l[j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) X1[u][r0 + j] = rc[j] * e_sel[j];
+                ltile = fmaf(lg[0] + lg[1], rm, ltile);
+            } else split_pair_a(u, r0, rsrc);
         }
     };
 
@@ -1165,6 +1217,16 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
                     }
                     else { d_mma(0, g, sw[0], fb[lb & 1][k]); ride(bm, bq, 1, 0, g, sw[1], rmask, rscale_pos, rscale_neg, dz_rsrc, lt); }
                 }
+#if H3X_PIPE
+                // the bundle's order: one MFMA, then what rides in its shadow (32 cycles of matrix pipe, 8 of them holding the vector issue) - hipcc's own order
+                // clumps up to 45 vector instructions behind one MFMA and then issues six MFMAs bare
+#pragma unroll
+                for (int q = 0; q < 3 * BG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, H3X_PIPE, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                }
+#endif
             }
         };
         stamp(0);
