@@ -1645,6 +1645,440 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3y(OutFwd6Args pp) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_out_fwd_h3p (round 4): the fp16x3 training forward as PRODUCER / CONSUMER WAVE PAIRS, two waves per SIMD.
+// k_out_fwd_h3x's lone wave per SIMD issues everything it does in order - 192 MFMAs (8 issue cycles each), ~860 vector instructions, ~210 LDS reads, 17 DMA
+// pieces, 32 stores a tile: ~10.5 k cycles of issue against 6.1 k of matrix pipe, and the issue is what its 10.9 k cycles a tile are (without its MFMAs the
+// kernel takes 0.59 of its 0.71 ms, without its epilogue 0.57; re-ordering or trimming the vector work moves nothing).  Sixteen-row waves (k_out_fwd_h3y) double
+// the LDS traffic and the MFMA issue instead.  Here the 32 rows of a wave pair stay together and the WORK is split:
+//   wave A ("logit", waves 0-3):    zT(s) = planes(s) . hT on its h / h*s_in planes (128 registers), bias, s_out sign, leaky_relu, softplus into the loss;
+//                                   1 + e^-l of its 32 rows x 32 experts handed to wave B through LDS (4 KiB a sub-tile); the LDS-DMA of sub-tile s+1
+//   wave B ("gradient", waves 4-7): dz = sigmoid(l) * row constant, its fp16 split, the dzT stores, and dh += dz(s-1) . planes(s-1) on its 128 accumulators
+// of the same 32 batch rows (lane = row in both: the hand-over is lane to lane), one step = one 32-expert sub-tile, one barrier a step.  A issues its MFMAs
+// first and its vector work after them, B its vector work first and its MFMAs after it: the matrix pipe of their SIMD is fed by one of the two all the time.
+// LDS: a ring of three 32-expert stages (2 matrices x 2 planes x [32 rows][256 B] + biases = 32.5 KiB each: zT reads stage s, dh stage s-1, the DMA fills s+1)
+// + two hand-over slots of 16 KiB = 129.5 KiB.  Sub-tile order, MFMA order per accumulator, epilogue arithmetic and the packed dz are k_out_fwd_h3x's: dzT and
+// the dh slabs are bit-identical, the loss differs in the order of its sums.  An operand outside the fp16 window: the kernel returns (exact-f32 launch behind it).
+// ------------------------------------------------------------------------------------------------
+#ifndef H3P_DMA_SPLIT
+#define H3P_DMA_SPLIT 1
+#endif
+template <bool BAYES, bool INJ, bool STAMP = false>      // STAMP (-DNTF_DIAG builds, NTF_FWD_ABL=9): cycle sums per wave and step segment into pp.stamps
+__global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OutFwdArgs& p = pp.a;
+    constexpr int H = 128, NJT = 4, NKS = H / 16, SUB = 32;
+    constexpr int PLANE = SUB * H * 2;          // 8 KiB
+    constexpr int TM = 2 * PLANE;               // one matrix of a sub-tile: hi and lo plane
+    constexpr int NMAT = BAYES ? 2 : 1;
+    constexpr int SLOT = NMAT * TM + 512;       // + two 32-float bias tiles (each fetched by all 64 lanes: 256 B apart)
+    constexpr int HB0 = 3 * SLOT, HBSLOT = 4 * 4096;
+    const int tid = threadIdx.x, lane = tid & 63, il = lane & 31, half = lane >> 5;
+#ifdef H3P_SWAP
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave_u & 3, role = 1 - (wave_u >> 2);
+#else
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave_u & 3, role = wave_u >> 2;
+#endif
+    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) return;
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int slot) {
+        if (!STAMP) return;
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long tnow;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot >= 0) st_sum[slot] += tnow - st_prev;
+        st_prev = tnow;
+    };
+    auto stamp_out = [&](int nstep) {
+        if (STAMP && pp.stamps && lane == 0) {
+            unsigned long long* o = pp.stamps + ((int64_t)blockIdx.x * 8 + wave_u) * 8;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o[q] = st_sum[q];
+            o[6] = (unsigned long long)nstep;
+        }
+    };
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int cg = bid / p.NRB, rb = bid % p.NRB;
+    const int s_beg = 2 * (int)((int64_t)cg * p.T / p.NCG), s_end = 2 * (int)((int64_t)(cg + 1) * p.T / p.NCG);   // p.T = 64-expert tiles; s = 32-expert sub-tiles
+    const int i0 = rb * BM + pair * 32;
+    const int i = i0 + il;
+    const bool row_ok = i < p.B;
+    const uint32_t smem_base = lds_addr(smem);
+    typedef const __attribute__((address_space(3))) char* ldsp_t;
+    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
+    auto sign_w = [&](int s) -> uint32_t {          // s_out signs of (row i, experts 32 s .. 32 s + 31), shifted to this half's registers
+        if (!BAYES || !row_ok) return 0u;
+        const uint32_t w = INJ ? p.sbits[(int64_t)i * p.nCB + s] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)s);
+        return w >> (4 * half);
+    };
+    // a ragged or empty last sub-tile (workgroup-uniform): the experts past M are masked through their bias (l = -80: softplus = dz = 0 to rounding)
+    auto mask_past_m = [&](int s) {
+        if (32 * s + SUB > p.M) {
+            if (tid < SUB && 32 * s + tid >= p.M) reinterpret_cast<float*>(smem + (s % 3) * SLOT + NMAT * TM)[tid] = -8000.f;
+            __syncthreads();
+        }
+    };
+
+#ifdef H3P_PRIO_A
+    if (role == 0) __builtin_amdgcn_s_setprio(H3P_PRIO_A);
+#endif
+#ifdef H3P_PRIO_B
+    if (role == 1) __builtin_amdgcn_s_setprio(H3P_PRIO_B);
+#endif
+    if (role == 0) {
+        // ================================================================ wave A: zT, logits, DMA
+        u32x4 hp[NKS][2], hs[NKS][2];               // B operand of zT: fp16 planes of h[i][16 s + 8 half ..] and of h * s_in
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
+            const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const uint32_t sw_in = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + (s >> 1)] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)(s >> 1)) : 0u)) : 0u;
+            const uint32_t w8 = sw_in >> (16 * (s & 1) + 8 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t pq[3];
+                split_pair_np<2>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
+                const uint32_t hm = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+                hp[s][0][q] = pq[0]; hp[s][1][q] = pq[1];
+                hs[s][0][q] = pq[0] ^ hm; hs[s][1][q] = pq[1] ^ hm;
+            }
+        }
+        // DMA: the 16 one-KiB pieces of a matrix image over the four A waves (4 each and matrix) + the bias piece
+        constexpr int PER_WAVE = TM / 1024 / 4;
+#if H3P_DMA_SPLIT == 2
+        constexpr int NPIECE = 1;                   // wave B issues all matrix pieces, wave A the biases
+#elif H3P_DMA_SPLIT == 1
+        constexpr int NPIECE = PER_WAVE + 1;        // wave B issues the pieces of the second matrix
+#else
+        constexpr int NPIECE = NMAT * PER_WAVE + 1;
+#endif
+        uint32_t dsrc[PER_WAVE];
+#pragma unroll
+        for (int n = 0; n < PER_WAVE; ++n) {
+            const int pos = (pair * PER_WAVE + n) * 1024 + lane * 16;       // destination inside the matrix image: plane, row (0..31), physical chunk
+            const int plane = pos / PLANE, row = (pos >> 8) & 31, chp = (pos >> 4) & 15;
+            const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            dsrc[n] = (uint32_t)(((plane * 32 + row) * 256) + 16 * ch);   // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
+        }
+        auto stage_piece = [&](int s, int slot, int n) {    // piece n of sub-tile s into ring slot `slot`
+            const uint32_t sb = smem_base + slot * SLOT;
+            if (n < NPIECE - 1) {
+                const int mat = n / PER_WAVE, nn = n % PER_WAVE;
+                const char* base = reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)s * TM;    // wave-uniform
+                glds16s(base, dsrc[nn], sb + mat * TM + (pair * PER_WAVE + nn) * 1024);
+            } else {   // the two bias tiles: even waves fetch mu_b's, odd waves bp's (lanes 32-63 repeat lanes 0-31 into the 128 B behind them)
+                const int which = BAYES ? (pair & 1) : 0;
+                glds4((which ? p.bp : p.mu_b) + min(32 * s + il, p.M - 1), sb + NMAT * TM + which * 256);
+            }
+        };
+        if (s_beg < s_end) {
+#pragma unroll
+            for (int n = 0; n < NPIECE; ++n) stage_piece(s_beg, s_beg % 3, n);
+#if H3P_DMA_SPLIT
+#pragma unroll
+            for (int mat = (H3P_DMA_SPLIT == 2 ? 0 : 1); mat < NMAT; ++mat)
+#pragma unroll
+                for (int nn = 0; nn < PER_WAVE; ++nn) glds16s(reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)s_beg * TM, dsrc[nn], smem_base + (s_beg % 3) * SLOT + mat * TM + (pair * PER_WAVE + nn) * 1024);
+#endif
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        int zrow[NKS];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) zrow[s] = 256 * il + 16 * ((2 * s + half) ^ fil);
+        LossAcc lacc;
+        const float rmask = row_ok ? 1.f : 0.f;
+        constexpr int NHG = NKS * NMAT, BG = 2, NB = NHG / BG;
+        uint32_t swn = s_beg < s_end ? sign_w(s_beg) : 0u;
+        stamp(-1);
+        const int dz_voff = ((i0 >> 5) * 8192 + (lane >> 3) * 32 + 4 * (lane & 7)) * 4;      // rows i0 + 4 (lane & 7) .. + 3 of expert lane >> 3 (+ 8 per store)
+        // the packed dz of sub-tile sd, left as [32 experts][32 rows] by wave B in the slot of that sub-tile: read at the top of the step, stored (1 KiB a store)
+        // behind its MFMAs - a store waiting for its LDS read cost 120 cycles
+        u32x4 dzv[4];
+        auto load_dz = [&](int sd) {
+            const char* hbr = smem + HB0 + (sd & 1) * HBSLOT + pair * 4096 + lane * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dzv[q] = *reinterpret_cast<const u32x4*>(hbr + q * 1024);
+        };
+        auto store_dz = [&](int sd) {
+            const int u = sd & 1, c0 = (sd >> 1) * 64;
+            const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(dzv[q], dz_rsrc, dz_voff, (32 * u + 8 * q) * 128, 0);
+        };
+        for (int s = s_beg; s <= s_end + 1; ++s) {
+            if (s - 2 >= s_beg) load_dz(s - 2);
+            if (s - 2 >= s_beg && s >= s_end) store_dz(s - 2);      // (behind the last sub-tiles; otherwise after this step's MFMAs, below)
+            if (s < s_end) {
+                mask_past_m(s);
+                const uint32_t swu = swn;
+                swn = sign_w(min(s + 1, s_end - 1));
+                const uint32_t sbase = smem_base + (s % 3) * SLOT;
+                const char* sb = smem + (s % 3) * SLOT;
+                ldsp_t zb[NKS];
+#pragma unroll
+                for (int k = 0; k < NKS; ++k) zb[k] = (ldsp_t)(size_t)(sbase + zrow[k]);
+                f32x16 X1, X2;
+                u32x4 fb[2][BG][2];
+                auto z_load = [&](int hg, u32x4 (&fr)[2]) {
+                    const int k = hg / NMAT, mat = hg % NMAT;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) fr[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(zb[k] + (mat * TM + q * PLANE));
+                };
+                auto z_mma = [&](int hg, const u32x4 (&fr)[2]) {
+                    const int k = hg / NMAT, mat = hg % NMAT;
+                    f32x16 zero;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                    f32x16 acc = mat == 0 ? (k == 0 ? zero : X1) : (k == 0 ? zero : X2);
+                    const u32x4 (&b)[2] = mat == 0 ? hp[k] : hs[k];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(fr[1]), as_frag_h(b[0]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(fr[0]), as_frag_h(b[1]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(fr[0]), as_frag_h(b[0]), acc, 0, 0, 0);
+                    if (mat == 0) X1 = acc; else X2 = acc;
+                };
+#pragma unroll
+                for (int k = 0; k < BG; ++k) z_load(k, fb[0][k]);
+                stamp(4);
+#ifdef H3P_MPRIO
+                __builtin_amdgcn_s_setprio(H3P_MPRIO);
+#endif
+                const int sn = min(s + 1, s_end - 1);       // behind the last sub-tile the free stage takes that sub-tile once more
+#pragma unroll
+                for (int lb = 0; lb < NB; ++lb) {
+                    if (lb + 1 < NB) {
+#pragma unroll
+                        for (int k = 0; k < BG; ++k) z_load((lb + 1) * BG + k, fb[(lb + 1) & 1][k]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < BG; ++k) {
+                        const int hg = lb * BG + k;
+                        z_mma(hg, fb[lb & 1][k]);
+                        if (hg < NPIECE) stage_piece(sn, (s + 1) % 3, hg);
+                    }
+                }
+#ifdef H3P_MPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                stamp(0);
+                if (s - 2 >= s_beg) store_dz(s - 2);    // before this step's 1 + e^-l go into the same slot
+                stamp(5);
+                // logits of the 16 registers: lane = batch row i, register r <-> expert 32 s + rowmap(r, half)
+                float bm[16], bq[16];
+                {
+                    const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
+                    const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 m = *reinterpret_cast<const float4*>(bias_mu + 8 * j);
+                        bm[4 * j] = m.x; bm[4 * j + 1] = m.y; bm[4 * j + 2] = m.z; bm[4 * j + 3] = m.w;
+                        if (BAYES) { const float4 q = *reinterpret_cast<const float4*>(bias_p + 8 * j); bq[4 * j] = q.x; bq[4 * j + 1] = q.y; bq[4 * j + 2] = q.z; bq[4 * j + 3] = q.w; }
+                    }
+                }
+                // what wave B gets is tt = 1 + e^-l with the branch of leaky_relu in its sign (-tt: z > 0); softplus(l) = log(tt) + l goes into the row's loss here
+                char* hb = smem + HB0 + (s & 1) * HBSLOT + pair * 4096 + lane * 16;
+                float lt = 0.f;
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    float l[4], tt[4], v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * j4 + j, cr = (r & 3) + 8 * (r >> 2);
+                        float z = fmaf(X1[r], pp.u_z, bm[r]);
+                        if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[r], pp.u_z, bq[r])) ^ ((swu << (31 - cr)) & 0x80000000u));
+                        const bool pos = z > 0.f;
+                        l[j] = pos ? z : z * kLeakySlope;
+                        tt[j] = 1.f + __builtin_amdgcn_exp2f(l[j] * -1.4426950408889634f);
+                        v[j] = pos ? -tt[j] : tt[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) l[j] = fmaf(__builtin_amdgcn_logf(tt[j]), 0.6931471805599453f, l[j]);
+                    lt += (l[0] + l[1]) + (l[2] + l[3]);
+                    *reinterpret_cast<float4*>(hb + j4 * 1024) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                lacc.tile = lt * rmask; lacc.end_tile();
+            }
+            stamp(1);
+            // the DMA of sub-tile s+1 has landed (it is older than the four dz stores of this step, where there are any), the logits of s are in the slot
+            if (s - 2 >= s_beg && s < s_end) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stamp(2);
+            __builtin_amdgcn_s_barrier();
+            stamp(3);
+        }
+        stamp_out(s_end - s_beg);
+        float lsum = lacc.sum;
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+        return;
+    }
+
+    // ==================================================================== wave B: loss, dz, dh
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // (the barrier behind wave A's first DMA)
+    const float rscale_pos = row_ok ? p.tnw * p.inv_B * pp.dz_scale : 0.f;    // dz * dz_scale = this * sigmoid(l)   (z > 0), ...
+    const float rscale_neg = rscale_pos * kLeakySlope;                         // ... * leaky slope                       (z <= 0)
+    int troff[2][NJT];                              // transposed read (rr, jt): rows 8*rr + 4*half + q (+ 16 per k-step as an immediate)
+    {
+        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int row = 8 * rr + 4 * half + q;
+                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
+            }
+    }
+    f32x16 Y1[NJT], Y2[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
+    constexpr int NGD = 2 * NJT * NMAT, BGD = 2, NBD = NGD / BGD;
+    uint32_t swn = s_beg < s_end ? sign_w(s_beg) : 0u;
+#if H3P_DMA_SPLIT
+    uint32_t dsrcb[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int pos = (pair * 4 + n) * 1024 + lane * 16;
+        const int plane = pos / PLANE, row = (pos >> 8) & 31, chp = (pos >> 4) & 15;
+        dsrcb[n] = (uint32_t)(((plane * 32 + row) * 256) + 16 * (chp ^ (((row & 3) << 2) | ((row >> 2) & 3))));
+    }
+#endif
+    stamp(-1);
+    for (int s = s_beg; s <= s_end + 1; ++s) {
+        if (s < s_end) mask_past_m(s);
+#if H3P_DMA_SPLIT
+        if (s < s_end) {       // this wave's share of sub-tile s+1 (behind the last one: that one once more) into the free stage
+            const int sn = min(s + 1, s_end - 1);
+#pragma unroll
+            for (int mat = (H3P_DMA_SPLIT == 2 ? 0 : 1); mat < NMAT; ++mat)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) glds16s(reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)sn * TM, dsrcb[nn], smem_base + ((s + 1) % 3) * SLOT + mat * TM + (pair * 4 + nn) * 1024);
+        }
+#endif
+        if (s > s_beg && s <= s_end) {
+            const int sd = s - 1;
+            const uint32_t swu = swn;
+            swn = sign_w(min(sd + 1, s_end - 1));
+            const uint32_t sbase = smem_base + (sd % 3) * SLOT;
+            ldsp_t tb[2][NJT];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) tb[rr][jt] = (ldsp_t)(size_t)(sbase + troff[rr][jt]);
+            u32x4 fb[2][BGD][2];
+            auto tr_load = [&](int g, u32x4 (&bf)[2]) {   // g = (s2, jt, mat)
+                const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int o = 4096 * s2 + q * PLANE + mat * TM;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[0][jt] + o)));
+                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[1][jt] + o)));
+                    bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
+                }
+            };
+            // 1 + e^-l of sub-tile sd (negative: z > 0), as wave A's same lane left them
+            float l[16];
+            {
+                const char* hb = smem + HB0 + (sd & 1) * HBSLOT + pair * 4096 + lane * 16;
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    const float4 v = *reinterpret_cast<const float4*>(hb + j4 * 1024);
+                    l[4 * j4] = v.x; l[4 * j4 + 1] = v.y; l[4 * j4 + 2] = v.z; l[4 * j4 + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BGD; ++k) tr_load(k, fb[0][k]);
+            stamp(4);
+            char* hbw = smem + HB0 + (sd & 1) * HBSLOT + pair * 4096 + (4 * half * 32 + il) * 4;      // element (expert 4 half + .., row il) of [32 experts][32 rows]
+            u32x4 ad[2][2];         // [k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
+            auto dz_pair = [&](int r0) {
+                float rc[2], dz[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rc[j] = __builtin_amdgcn_rcpf(__builtin_fabsf(l[r0 + j]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dz[j] = rc[j] * (l[r0 + j] < 0.f ? rscale_pos : rscale_neg);
+                const uint32_t d0 = split_packed(dz[0]), d1 = split_packed(dz[1]);    // (no clamp: |dz| * dz_scale < 2^14)
+                ad[r0 >> 3][0][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
+                ad[r0 >> 3][1][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
+                // the packed dz goes back into the slot its 1 + e^-l came from, as [expert][row]: wave A stores it from there, 16 bytes a lane (a dword store
+                // per register from here cost this wave ~35 cycles each, 1 100 of its 4 800 a step)
+                *reinterpret_cast<uint32_t*>(hbw + ((r0 & 3) + 8 * (r0 >> 2)) * 128) = d0;
+                *reinterpret_cast<uint32_t*>(hbw + (((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * 128) = d1;
+            };
+            // (all of it before the MFMAs: riding half of it on the first k-step's MFMAs puts this wave's vector work beside wave A's and costs 1 350 cycles of the MFMA segment)
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 2) dz_pair(r0);
+            stamp(0);
+#ifdef H3P_MPRIO
+            __builtin_amdgcn_s_setprio(H3P_MPRIO);
+#endif
+            auto d_mma = [&](int g, const u32x4 (&bf)[2]) {
+                const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
+                u32x4 a0 = ad[s2][0], a1 = ad[s2][1];
+                if (mat) {          // planes of dz * s_out
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r0 = 8 * s2 + 2 * q, c0r = (r0 & 3) + 8 * (r0 >> 2);
+                        const uint32_t m = (((swu << (31 - c0r)) & 0x80000000u) >> 16) | ((swu << (30 - c0r)) & 0x80000000u);
+                        a0[q] ^= m; a1[q] ^= m;
+                    }
+                }
+                f32x16 acc = mat == 0 ? Y1[jt] : Y2[jt];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(a1), as_frag_h(bf[0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(a0), as_frag_h(bf[1]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(a0), as_frag_h(bf[0]), acc, 0, 0, 0);
+                if (mat == 0) Y1[jt] = acc; else Y2[jt] = acc;
+            };
+#pragma unroll
+            for (int lb = 0; lb < NBD; ++lb) {
+                if (lb + 1 < NBD) {
+#pragma unroll
+                    for (int k = 0; k < BGD; ++k) tr_load((lb + 1) * BGD + k, fb[(lb + 1) & 1][k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < BGD; ++k) d_mma(lb * BGD + k, fb[lb & 1][k]);
+            }
+        }
+#ifdef H3P_MPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        stamp(1);
+#if H3P_DMA_SPLIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage and of the hand-over slot have returned
+        stamp(2);
+        __builtin_amdgcn_s_barrier();
+        stamp(3);
+    }
+    stamp_out(s_end - s_beg);
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int irow = i0 + rowmap(r, half);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            float v = Y1[jt][r] * pp.u_dh;
+            if (BAYES) {
+                const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
+                const float y2 = Y2[jt][r] * pp.u_dh;
+                v += ((w >> il) & 1u) ? -y2 : y2;
+            }
+            p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
 static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
@@ -1728,7 +2162,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_LX(BY, IJ) NTF_LXA(BY, IJ, 0)
 #ifdef NTF_DIAG
                 static const int fwd_abl = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
-                if (f.wide != 4 && fwd_abl == 9 && f.bayes && !inj) {
+                if (f.wide != 4 && f.wide != 5 && fwd_abl == 9 && f.bayes && !inj) {
                     static unsigned long long* d_st = nullptr; static int n_launch = 0;
                     if (!d_st) hipMalloc(&d_st, (size_t)grid * 4 * 12 * 8);
                     a6.stamps = d_st;
@@ -1744,10 +2178,41 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                                 sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7], sum[7] / (grid * 4.0));
                     }
                 }
-                else if (f.wide != 4 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
+                else if (f.wide != 4 && f.wide != 5 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
                 else
 #endif
-                if (f.wide == 4) {      // sixteen-row waves, two per SIMD (NTF_FWD_KERNEL=4: the A/B form)
+                if (f.wide == 5) {      // producer / consumer wave pairs, two waves per SIMD (NTF_FWD_KERNEL=5)
+                    const size_t ldsp = 3 * ((size_t)(f.bayes ? 2 : 1) * 2 * 32 * 128 * 2 + 512) + 2 * 16384;
+#define NTF_LP(BY, IJ) do { auto kf = k_out_fwd_h3p<BY, IJ>;                                                                    \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);  \
+                hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsp, st, a6); } while (0)
+#ifdef NTF_DIAG
+                    static const int fwd_abl5 = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
+                    if (fwd_abl5 == 9 && f.bayes && !inj) {
+                        static unsigned long long* d_st = nullptr; static int n_launch = 0;
+                        if (!d_st) hipMalloc(&d_st, (size_t)grid * 8 * 8 * 8);
+                        a6.stamps = d_st;
+                        auto kf = k_out_fwd_h3p<true, false, true>;
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                        hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsp, st, a6);
+                        if (++n_launch == 30) {
+                            std::vector<unsigned long long> hst((size_t)grid * 64);
+                            hipStreamSynchronize(st); hipMemcpy(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost);
+                            for (int role = 0; role < 2; ++role) {
+                                double sum[7] = {0};
+                                for (int wg = 0; wg < grid; ++wg) for (int w = 4 * role; w < 4 * role + 4; ++w) for (int q = 0; q < 7; ++q) sum[q] += (double)hst[((size_t)wg * 8 + w) * 8 + q];
+                                if (role == 0) fprintf(stderr, "[pair stamps] waves 0-3, cycles per step: top+first reads %.0f | MFMAs+DMA %.0f | dz stores %.0f | logits %.0f | wait %.0f | barrier %.0f  (steps/wave %.1f)\n",
+                                        sum[4] / sum[6], sum[0] / sum[6], sum[5] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[6] / (grid * 4.0));
+                                else fprintf(stderr, "[pair stamps] waves 4-7, cycles per step: top+reads %.0f | dz %.0f | dh MFMAs %.0f | wait %.0f | barrier %.0f\n",
+                                        sum[4] / sum[6], sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6]);
+                            }
+                        }
+                    } else
+#endif
+                    if (f.bayes) { if (inj) NTF_LP(true, true); else NTF_LP(true, false); } else NTF_LP(false, false);
+#undef NTF_LP
+                }
+                else if (f.wide == 4) {      // sixteen-row waves, two per SIMD (NTF_FWD_KERNEL=4: the A/B form)
 #define NTF_LY(BY, IJ) do { auto kf = k_out_fwd_h3y<BY, IJ>;                                                                    \
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
                 hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsw, st, a6); } while (0)
@@ -1761,7 +2226,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #undef NTF_L6B
 #undef NTF_L6
 #undef NTF_L6N
-            const bool merged_fallback = np == 2 && f.train && dh && f.wide != 0 && f.wide != 4;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
+            const bool merged_fallback = np == 2 && f.train && dh && f.wide != 0 && f.wide != 4 && f.wide != 5;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
             if (guard && np == 2 && !f.probs && !merged_fallback) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
                 OutFwdArgs af = a; af.rmode = 2;
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
