@@ -26,8 +26,9 @@ struct FusedOut {
     int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
     int np = 3;                                     // 3: bf16x6, 2: fp16x3 (operands scaled by exact powers of two before their two-way fp16 split)
     float w_scale = 1.f, h_scale = 1.f, dz_scale = 1.f;
-    int wide = 3;                                   // np = 2 training step: 3 (default) k_out_fwd_h3x - 64-expert tiles, phases rotated across tiles; 4 k_out_fwd_h3y (sixteen-row waves,
-                                                    // two per SIMD: the A/B form); 0 the 32-expert-tile kernel k_out_fwd_b6
+    int wide = 5;                                   // np = 2 training step: 5 (default, round 4) k_out_fwd_h3p - a logit wave and a gradient wave per 32 rows, two waves per SIMD, 32-expert steps;
+                                                    // 3 k_out_fwd_h3x - one wave per SIMD, 64-expert tiles, phases rotated across tiles (round 3's default); 4 k_out_fwd_h3y (sixteen-row
+                                                    // waves, two per SIMD); 0 the 32-expert-tile kernel k_out_fwd_b6.  NTF_FWD_KERNEL selects the A/B forms
     int ncg_limit = 0;                              // > 0 (diagnostics, NTF_COSCHED): at most this many column groups, i.e. a forward grid of NRB * ncg_limit workgroups that leaves CUs free
     int planes_ready = 0;
     int h_ready = 0;                                // the zero-padded h, h * s_in and the s_in words are in the workspace already (ntf_head.hip): phase 1 skips k_prep_h

@@ -1662,6 +1662,9 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3y(OutFwd6Args pp) {
 #ifndef H3P_DMA_SPLIT
 #define H3P_DMA_SPLIT 1
 #endif
+#ifndef H3P_LOSS_IN_B
+#define H3P_LOSS_IN_B 0
+#endif
 template <bool BAYES, bool INJ, bool STAMP = false>      // STAMP (-DNTF_DIAG builds, NTF_FWD_ABL=9): cycle sums per wave and step segment into pp.stamps
 __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1894,15 +1897,23 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                         if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[r], pp.u_z, bq[r])) ^ ((swu << (31 - cr)) & 0x80000000u));
                         const bool pos = z > 0.f;
                         l[j] = pos ? z : z * kLeakySlope;
+#if !H3P_LOSS_IN_B
                         tt[j] = 1.f + __builtin_amdgcn_exp2f(l[j] * -1.4426950408889634f);
                         v[j] = pos ? -tt[j] : tt[j];
+#else
+                        v[j] = l[j]; tt[j] = 1.f;
+#endif
                     }
+#if !H3P_LOSS_IN_B
 #pragma unroll
                     for (int j = 0; j < 4; ++j) l[j] = fmaf(__builtin_amdgcn_logf(tt[j]), 0.6931471805599453f, l[j]);
                     lt += (l[0] + l[1]) + (l[2] + l[3]);
+#endif
                     *reinterpret_cast<float4*>(hb + j4 * 1024) = make_float4(v[0], v[1], v[2], v[3]);
                 }
+#if !H3P_LOSS_IN_B
                 lacc.tile = lt * rmask; lacc.end_tile();
+#endif
             }
             stamp(1);
             // the DMA of sub-tile s+1 has landed (it is older than the four dz stores of this step, where there are any), the logits of s are in the slot
@@ -1912,9 +1923,11 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             stamp(3);
         }
         stamp_out(s_end - s_beg);
+#if !H3P_LOSS_IN_B
         float lsum = lacc.sum;
         lsum += __shfl_xor(lsum, 32, 64);
         if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+#endif
         return;
     }
 
@@ -1941,6 +1954,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
     constexpr int NGD = 2 * NJT * NMAT, BGD = 2, NBD = NGD / BGD;
+    LossAcc laccb;
     uint32_t swn = s_beg < s_end ? sign_w(s_beg) : 0u;
 #if H3P_DMA_SPLIT
     uint32_t dsrcb[4];
@@ -1999,12 +2013,24 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             stamp(4);
             char* hbw = smem + HB0 + (sd & 1) * HBSLOT + pair * 4096 + (4 * half * 32 + il) * 4;      // element (expert 4 half + .., row il) of [32 experts][32 rows]
             u32x4 ad[2][2];         // [k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
+            float ltb = 0.f;
             auto dz_pair = [&](int r0) {
                 float rc[2], dz[2];
+#if H3P_LOSS_IN_B
+                float tt[2], lg[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tt[j] = 1.f + __builtin_amdgcn_exp2f(l[r0 + j] * -1.4426950408889634f);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { lg[j] = fmaf(__builtin_amdgcn_logf(tt[j]), 0.6931471805599453f, l[r0 + j]); rc[j] = __builtin_amdgcn_rcpf(tt[j]); }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dz[j] = rc[j] * (l[r0 + j] > 0.f ? rscale_pos : rscale_neg);
+                ltb += lg[0] + lg[1];
+#else
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rc[j] = __builtin_amdgcn_rcpf(__builtin_fabsf(l[r0 + j]));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) dz[j] = rc[j] * (l[r0 + j] < 0.f ? rscale_pos : rscale_neg);
+#endif
                 const uint32_t d0 = split_packed(dz[0]), d1 = split_packed(dz[1]);    // (no clamp: |dz| * dz_scale < 2^14)
                 ad[r0 >> 3][0][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
                 ad[r0 >> 3][1][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
@@ -2016,6 +2042,9 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             // (all of it before the MFMAs: riding half of it on the first k-step's MFMAs puts this wave's vector work beside wave A's and costs 1 350 cycles of the MFMA segment)
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 2) dz_pair(r0);
+#if H3P_LOSS_IN_B
+            laccb.tile = ltb * (row_ok ? 1.f : 0.f); laccb.end_tile();
+#endif
             stamp(0);
 #ifdef H3P_MPRIO
             __builtin_amdgcn_s_setprio(H3P_MPRIO);
@@ -2061,7 +2090,13 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         stamp(3);
     }
     stamp_out(s_end - s_beg);
-
+#if H3P_LOSS_IN_B
+    {
+        float lsum = laccb.sum;
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int irow = i0 + rowmap(r, half);
