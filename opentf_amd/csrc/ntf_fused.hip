@@ -1650,21 +1650,22 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3y(OutFwd6Args pp) {
 // pieces, 32 stores a tile: ~10.5 k cycles of issue against 6.1 k of matrix pipe, and the issue is what its 10.9 k cycles a tile are (without its MFMAs the
 // kernel takes 0.59 of its 0.71 ms, without its epilogue 0.57; re-ordering or trimming the vector work moves nothing).  Sixteen-row waves (k_out_fwd_h3y) double
 // the LDS traffic and the MFMA issue instead.  Here the 32 rows of a wave pair stay together and the WORK is split:
-//   wave A ("logit", waves 0-3):    zT(s) = planes(s) . hT on its h / h*s_in planes (128 registers), bias, s_out sign, leaky_relu, softplus into the loss;
-//                                   1 + e^-l of its 32 rows x 32 experts handed to wave B through LDS (4 KiB a sub-tile); the LDS-DMA of sub-tile s+1
-//   wave B ("gradient", waves 4-7): dz = sigmoid(l) * row constant, its fp16 split, the dzT stores, and dh += dz(s-1) . planes(s-1) on its 128 accumulators
+//   wave A ("logit", waves 0-3):    zT(s) = planes(s) . hT on its h / h*s_in planes (128 registers), bias, s_out sign, leaky_relu, softplus into the loss (one
+//                                   v_log_f32 per four logits: the log of a product); tt = 1 + e^-l of its 32 rows x 32 experts, the leaky_relu branch in its sign,
+//                                   handed to wave B through LDS (4 KiB a sub-tile); the dzT stores of sub-tile s-2 (16 bytes a lane, from the same LDS slot);
+//                                   the LDS-DMA of the first matrix and the biases of sub-tile s+1
+//   wave B ("gradient", waves 4-7): dz = row constant / tt, its fp16 split (packed back into the slot as [expert][row] for wave A's stores), and
+//                                   dh += dz(s-1) . planes(s-1) on its 128 accumulators; the LDS-DMA of the second matrix of sub-tile s+1
 // of the same 32 batch rows (lane = row in both: the hand-over is lane to lane), one step = one 32-expert sub-tile, one barrier a step.  A issues its MFMAs
-// first and its vector work after them, B its vector work first and its MFMAs after it: the matrix pipe of their SIMD is fed by one of the two all the time.
+// first and its vector work after them, B its vector work first and its MFMAs after it: matrix work of one beside vector work of the other (the other pairings -
+// half of B's vector work riding on its first MFMAs, the roles on the other wave age, priorities per segment - cost 3 to 15 %: vector issue is arbitrated by
+// age, and two vector streams side by side starve the younger one's MFMAs).  Measured per step and wave (`-DNTF_DIAG`, NTF_FWD_ABL=9): A 530 (top, first
+// fragments) + 1 810 (48 MFMAs + DMA) + 380 (4 stores) + 1 730 (logits); B 810 (top, hand-over and first fragment reads) + 1 250 (dz) + 2 220 (48 MFMAs beside A's
+// vector work) = 4.7 k cycles a sub-tile against k_out_fwd_h3x's 5.45 k: 0.72 -> 0.66 ms on the same box.
 // LDS: a ring of three 32-expert stages (2 matrices x 2 planes x [32 rows][256 B] + biases = 32.5 KiB each: zT reads stage s, dh stage s-1, the DMA fills s+1)
 // + two hand-over slots of 16 KiB = 129.5 KiB.  Sub-tile order, MFMA order per accumulator, epilogue arithmetic and the packed dz are k_out_fwd_h3x's: dzT and
 // the dh slabs are bit-identical, the loss differs in the order of its sums.  An operand outside the fp16 window: the kernel returns (exact-f32 launch behind it).
 // ------------------------------------------------------------------------------------------------
-#ifndef H3P_DMA_SPLIT
-#define H3P_DMA_SPLIT 1
-#endif
-#ifndef H3P_LOSS_IN_B
-#define H3P_LOSS_IN_B 0
-#endif
 template <bool BAYES, bool INJ, bool STAMP = false>      // STAMP (-DNTF_DIAG builds, NTF_FWD_ABL=9): cycle sums per wave and step segment into pp.stamps
 __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1676,11 +1677,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     constexpr int SLOT = NMAT * TM + 512;       // + two 32-float bias tiles (each fetched by all 64 lanes: 256 B apart)
     constexpr int HB0 = 3 * SLOT, HBSLOT = 4 * 4096;
     const int tid = threadIdx.x, lane = tid & 63, il = lane & 31, half = lane >> 5;
-#ifdef H3P_SWAP
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave_u & 3, role = 1 - (wave_u >> 2);
-#else
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave_u & 3, role = wave_u >> 2;
-#endif
     if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) return;
     unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
     auto stamp = [&](int slot) {
@@ -1717,20 +1714,14 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         const uint32_t w = INJ ? p.sbits[(int64_t)i * p.nCB + s] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)s);
         return w >> (4 * half);
     };
-    // a ragged or empty last sub-tile (workgroup-uniform): the experts past M are masked through their bias (l = -80: softplus = dz = 0 to rounding)
+    // a ragged or empty last sub-tile (workgroup-uniform): the experts past M are masked through their bias (l = -20: softplus = 2e-9, dz = 0 to rounding)
     auto mask_past_m = [&](int s) {
         if (32 * s + SUB > p.M) {
-            if (tid < SUB && 32 * s + tid >= p.M) reinterpret_cast<float*>(smem + (s % 3) * SLOT + NMAT * TM)[tid] = -8000.f;
+            if (tid < SUB && 32 * s + tid >= p.M) reinterpret_cast<float*>(smem + (s % 3) * SLOT + NMAT * TM)[tid] = -2000.f;
             __syncthreads();
         }
     };
 
-#ifdef H3P_PRIO_A
-    if (role == 0) __builtin_amdgcn_s_setprio(H3P_PRIO_A);
-#endif
-#ifdef H3P_PRIO_B
-    if (role == 1) __builtin_amdgcn_s_setprio(H3P_PRIO_B);
-#endif
     if (role == 0) {
         // ================================================================ wave A: zT, logits, DMA
         u32x4 hp[NKS][2], hs[NKS][2];               // B operand of zT: fp16 planes of h[i][16 s + 8 half ..] and of h * s_in
@@ -1752,13 +1743,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         }
         // DMA: the 16 one-KiB pieces of a matrix image over the four A waves (4 each and matrix) + the bias piece
         constexpr int PER_WAVE = TM / 1024 / 4;
-#if H3P_DMA_SPLIT == 2
-        constexpr int NPIECE = 1;                   // wave B issues all matrix pieces, wave A the biases
-#elif H3P_DMA_SPLIT == 1
         constexpr int NPIECE = PER_WAVE + 1;        // wave B issues the pieces of the second matrix
-#else
-        constexpr int NPIECE = NMAT * PER_WAVE + 1;
-#endif
         uint32_t dsrc[PER_WAVE];
 #pragma unroll
         for (int n = 0; n < PER_WAVE; ++n) {
@@ -1781,12 +1766,10 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         if (s_beg < s_end) {
 #pragma unroll
             for (int n = 0; n < NPIECE; ++n) stage_piece(s_beg, s_beg % 3, n);
-#if H3P_DMA_SPLIT
 #pragma unroll
-            for (int mat = (H3P_DMA_SPLIT == 2 ? 0 : 1); mat < NMAT; ++mat)
+            for (int mat = 1; mat < NMAT; ++mat)
 #pragma unroll
                 for (int nn = 0; nn < PER_WAVE; ++nn) glds16s(reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)s_beg * TM, dsrc[nn], smem_base + (s_beg % 3) * SLOT + mat * TM + (pair * PER_WAVE + nn) * 1024);
-#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1848,9 +1831,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
 #pragma unroll
                 for (int k = 0; k < BG; ++k) z_load(k, fb[0][k]);
                 stamp(4);
-#ifdef H3P_MPRIO
-                __builtin_amdgcn_s_setprio(H3P_MPRIO);
-#endif
                 const int sn = min(s + 1, s_end - 1);       // behind the last sub-tile the free stage takes that sub-tile once more
 #pragma unroll
                 for (int lb = 0; lb < NB; ++lb) {
@@ -1866,9 +1846,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                         if (hg < NPIECE) stage_piece(sn, (s + 1) % 3, hg);
                     }
                 }
-#ifdef H3P_MPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 stamp(0);
                 if (s - 2 >= s_beg) store_dz(s - 2);    // before this step's 1 + e^-l go into the same slot
                 stamp(5);
@@ -1897,23 +1874,15 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                         if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[r], pp.u_z, bq[r])) ^ ((swu << (31 - cr)) & 0x80000000u));
                         const bool pos = z > 0.f;
                         l[j] = pos ? z : z * kLeakySlope;
-#if !H3P_LOSS_IN_B
                         tt[j] = 1.f + __builtin_amdgcn_exp2f(l[j] * -1.4426950408889634f);
                         v[j] = pos ? -tt[j] : tt[j];
-#else
-                        v[j] = l[j]; tt[j] = 1.f;
-#endif
                     }
-#if !H3P_LOSS_IN_B
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) l[j] = fmaf(__builtin_amdgcn_logf(tt[j]), 0.6931471805599453f, l[j]);
-                    lt += (l[0] + l[1]) + (l[2] + l[3]);
-#endif
+                    // sum of four softplus(l) = log(tt0 tt1 tt2 tt3) + (l0 + l1 + l2 + l3): one v_log_f32 for four.  The product overflows past sum(-l) = 88, i.e. a mean
+                    // logit below -22 (a pre-activation below -2 200 under leaky_relu); the experts past M are masked at l = -20 for that (tt = 4.9e8)
+                    lt += fmaf(__builtin_amdgcn_logf((tt[0] * tt[1]) * (tt[2] * tt[3])), 0.6931471805599453f, (l[0] + l[1]) + (l[2] + l[3]));
                     *reinterpret_cast<float4*>(hb + j4 * 1024) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-#if !H3P_LOSS_IN_B
                 lacc.tile = lt * rmask; lacc.end_tile();
-#endif
             }
             stamp(1);
             // the DMA of sub-tile s+1 has landed (it is older than the four dz stores of this step, where there are any), the logits of s are in the slot
@@ -1923,11 +1892,9 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             stamp(3);
         }
         stamp_out(s_end - s_beg);
-#if !H3P_LOSS_IN_B
         float lsum = lacc.sum;
         lsum += __shfl_xor(lsum, 32, 64);
         if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
-#endif
         return;
     }
 
@@ -1954,9 +1921,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
     constexpr int NGD = 2 * NJT * NMAT, BGD = 2, NBD = NGD / BGD;
-    LossAcc laccb;
     uint32_t swn = s_beg < s_end ? sign_w(s_beg) : 0u;
-#if H3P_DMA_SPLIT
     uint32_t dsrcb[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -1964,19 +1929,16 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         const int plane = pos / PLANE, row = (pos >> 8) & 31, chp = (pos >> 4) & 15;
         dsrcb[n] = (uint32_t)(((plane * 32 + row) * 256) + 16 * (chp ^ (((row & 3) << 2) | ((row >> 2) & 3))));
     }
-#endif
     stamp(-1);
     for (int s = s_beg; s <= s_end + 1; ++s) {
         if (s < s_end) mask_past_m(s);
-#if H3P_DMA_SPLIT
         if (s < s_end) {       // this wave's share of sub-tile s+1 (behind the last one: that one once more) into the free stage
             const int sn = min(s + 1, s_end - 1);
 #pragma unroll
-            for (int mat = (H3P_DMA_SPLIT == 2 ? 0 : 1); mat < NMAT; ++mat)
+            for (int mat = 1; mat < NMAT; ++mat)
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) glds16s(reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)sn * TM, dsrcb[nn], smem_base + ((s + 1) % 3) * SLOT + mat * TM + (pair * 4 + nn) * 1024);
         }
-#endif
         if (s > s_beg && s <= s_end) {
             const int sd = s - 1;
             const uint32_t swu = swn;
@@ -2013,24 +1975,12 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             stamp(4);
             char* hbw = smem + HB0 + (sd & 1) * HBSLOT + pair * 4096 + (4 * half * 32 + il) * 4;      // element (expert 4 half + .., row il) of [32 experts][32 rows]
             u32x4 ad[2][2];         // [k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
-            float ltb = 0.f;
             auto dz_pair = [&](int r0) {
                 float rc[2], dz[2];
-#if H3P_LOSS_IN_B
-                float tt[2], lg[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) tt[j] = 1.f + __builtin_amdgcn_exp2f(l[r0 + j] * -1.4426950408889634f);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { lg[j] = fmaf(__builtin_amdgcn_logf(tt[j]), 0.6931471805599453f, l[r0 + j]); rc[j] = __builtin_amdgcn_rcpf(tt[j]); }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) dz[j] = rc[j] * (l[r0 + j] > 0.f ? rscale_pos : rscale_neg);
-                ltb += lg[0] + lg[1];
-#else
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rc[j] = __builtin_amdgcn_rcpf(__builtin_fabsf(l[r0 + j]));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) dz[j] = rc[j] * (l[r0 + j] < 0.f ? rscale_pos : rscale_neg);
-#endif
                 const uint32_t d0 = split_packed(dz[0]), d1 = split_packed(dz[1]);    // (no clamp: |dz| * dz_scale < 2^14)
                 ad[r0 >> 3][0][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
                 ad[r0 >> 3][1][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
@@ -2042,13 +1992,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             // (all of it before the MFMAs: riding half of it on the first k-step's MFMAs puts this wave's vector work beside wave A's and costs 1 350 cycles of the MFMA segment)
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 2) dz_pair(r0);
-#if H3P_LOSS_IN_B
-            laccb.tile = ltb * (row_ok ? 1.f : 0.f); laccb.end_tile();
-#endif
             stamp(0);
-#ifdef H3P_MPRIO
-            __builtin_amdgcn_s_setprio(H3P_MPRIO);
-#endif
             auto d_mma = [&](int g, const u32x4 (&bf)[2]) {
                 const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
                 u32x4 a0 = ad[s2][0], a1 = ad[s2][1];
@@ -2077,26 +2021,14 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                 for (int k = 0; k < BGD; ++k) d_mma(lb * BGD + k, fb[lb & 1][k]);
             }
         }
-#ifdef H3P_MPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         stamp(1);
-#if H3P_DMA_SPLIT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage and of the hand-over slot have returned
         stamp(2);
         __builtin_amdgcn_s_barrier();
         stamp(3);
     }
     stamp_out(s_end - s_beg);
-#if H3P_LOSS_IN_B
-    {
-        float lsum = laccb.sum;
-        lsum += __shfl_xor(lsum, 32, 64);
-        if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
-    }
-#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int irow = i0 + rowmap(r, half);
