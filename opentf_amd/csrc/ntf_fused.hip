@@ -2194,7 +2194,12 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #undef NTF_L6
 #undef NTF_L6N
             const bool merged_fallback = np == 2 && f.train && dh && f.wide != 0 && f.wide != 4 && f.wide != 5;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
-            if (guard && np == 2 && !f.probs && !merged_fallback) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
+#ifdef NTF_DIAG
+            static const bool skip_fb = getenv("NTF_SKIP_FALLBACK") != nullptr;     // timing only: what the conditional exact-f32 launch behind k_out_fwd_h3p costs
+#else
+            constexpr bool skip_fb = false;
+#endif
+            if (guard && np == 2 && !f.probs && !merged_fallback && !skip_fb) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
                 OutFwdArgs af = a; af.rmode = 2;
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
             }

@@ -19,10 +19,10 @@ python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset uspt --d 256 > $O/b
 python3 $B --no-gather-bench --steps 30 --warmup 5 --dataset gith > $O/bench_n1_config5_gith.json 2>> $O/bench.err
 # A/B of this round's changes, same box (each switch restores the round-3 behaviour of one piece); the default line before and after them
 python3 $B --no-gather-bench --steps 40 --warmup 10 > $O/ab_default_a.json 2>> $O/bench.err
-for v in "NTF_DW_KERNEL=0" "NTF_LEAN=0" "NTF_HEAD_PREFETCH=0" "NTF_PREFETCH=0" "NTF_HEAD=0" "NTF_SIDE_BWD=0" "NTF_FWD_KERNEL=4" "NTF_DW_STAGGER=0"; do
+for v in "NTF_FWD_KERNEL=3" "NTF_DW_KERNEL=0" "NTF_LEAN=0" "NTF_HEAD_PREFETCH=0" "NTF_PREFETCH=0" "NTF_HEAD=0" "NTF_SIDE_BWD=0" "NTF_FWD_KERNEL=4" "NTF_DW_STAGGER=0"; do
   env $v python3 $B --no-gather-bench --steps 40 --warmup 10 > $O/ab_$v.json 2>> $O/bench.err
 done
-env NTF_DW_KERNEL=0 NTF_LEAN=0 NTF_HEAD_PREFETCH=0 python3 $B --no-gather-bench --steps 40 --warmup 10 > $O/ab_round3_step_with_round4_adam.json 2>> $O/bench.err
+env NTF_FWD_KERNEL=3 NTF_DW_KERNEL=0 NTF_LEAN=0 NTF_HEAD_PREFETCH=0 python3 $B --no-gather-bench --steps 40 --warmup 10 > $O/ab_round3_step_with_round4_adam.json 2>> $O/bench.err
 python3 $B --no-gather-bench --steps 40 --warmup 10 > $O/ab_default_b.json 2>> $O/bench.err
 # expert-sharded multi-GPU path: what ONE rank of G runs, emulated on this GPU
 for G in 2 4 8; do python3 $R/bench.py --steps 20 --warmup 4 --ep-emulate $G --no-extra-configs > $O/bench_ep_rank_of_$G.json 2>> $O/bench.err; done
@@ -46,6 +46,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $B --n
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_lds -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_lds.log 2>&1
+if [ -z "$R4_SKIP_UNCHANGED" ]; then
 # the whole-dataset gather launch (roofline_gather's traffic)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_gather_fetch -- python3 $B --gather-only --steps 1 --warmup 0 > $O/pmc_gather_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_gather_write -- python3 $B --gather-only --steps 1 --warmup 0 > $O/pmc_gather_write.log 2>&1
@@ -54,5 +55,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/d2v_stats -- python3 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/d2v_pmc_fetch -- python3 $R/profiles/d2v_pass.py > $O/d2v_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/d2v_pmc_write -- python3 $R/profiles/d2v_pass.py > $O/d2v_pmc_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum --output-format csv -d $O/d2v_pmc_tcc -- python3 $R/profiles/d2v_pass.py > $O/d2v_pmc_tcc.log 2>&1
+fi
 find $O -name "*.db" -delete 2>/dev/null; find $O -name "*_agent_info.csv" -delete 2>/dev/null
 du -sh $O | tail -1
