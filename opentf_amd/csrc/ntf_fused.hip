@@ -1679,6 +1679,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     const int tid = threadIdx.x, lane = tid & 63, il = lane & 31, half = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave_u & 3, role = wave_u >> 2;
     if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) return;
+    const long long k_c0 = STAMP ? clock64() : 0, k_w0 = STAMP ? wall_clock64() : 0;
     unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
     auto stamp = [&](int slot) {
         if (!STAMP) return;
@@ -1691,10 +1692,10 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     };
     auto stamp_out = [&](int nstep) {
         if (STAMP && pp.stamps && lane == 0) {
-            unsigned long long* o = pp.stamps + ((int64_t)blockIdx.x * 8 + wave_u) * 8;
+            unsigned long long* o = pp.stamps + ((int64_t)blockIdx.x * 8 + wave_u) * 10;
 #pragma unroll
             for (int q = 0; q < 6; ++q) o[q] = st_sum[q];
-            o[6] = (unsigned long long)nstep;
+            o[6] = (unsigned long long)nstep; o[7] = (unsigned long long)(clock64() - k_c0); o[8] = (unsigned long long)(wall_clock64() - k_w0); o[9] = 0;
         }
     };
 
@@ -2157,17 +2158,21 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                     static const int fwd_abl5 = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
                     if (fwd_abl5 == 9 && f.bayes && !inj) {
                         static unsigned long long* d_st = nullptr; static int n_launch = 0;
-                        if (!d_st) hipMalloc(&d_st, (size_t)grid * 8 * 8 * 8);
+                        if (!d_st) hipMalloc(&d_st, (size_t)grid * 8 * 10 * 8);
                         a6.stamps = d_st;
                         auto kf = k_out_fwd_h3p<true, false, true>;
                         hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
                         hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsp, st, a6);
                         if (++n_launch == 30) {
-                            std::vector<unsigned long long> hst((size_t)grid * 64);
+                            std::vector<unsigned long long> hst((size_t)grid * 80);
                             hipStreamSynchronize(st); hipMemcpy(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost);
+                            double cyc = 0, wall = 0;
+                            for (size_t w = 0; w < (size_t)grid * 8; ++w) { cyc += (double)hst[w * 10 + 7]; wall += (double)hst[w * 10 + 8]; }
+                            fprintf(stderr, "[pair stamps] per wave, kernel entry to the end of its loop: %.0f shader-clock cycles in %.0f ticks of 100 MHz = %.3f GHz, %.3f ms\n",
+                                    cyc / (grid * 8.0), wall / (grid * 8.0), cyc / (wall * 10.0), wall / (grid * 8.0) / 1e5);
                             for (int role = 0; role < 2; ++role) {
                                 double sum[7] = {0};
-                                for (int wg = 0; wg < grid; ++wg) for (int w = 4 * role; w < 4 * role + 4; ++w) for (int q = 0; q < 7; ++q) sum[q] += (double)hst[((size_t)wg * 8 + w) * 8 + q];
+                                for (int wg = 0; wg < grid; ++wg) for (int w = 4 * role; w < 4 * role + 4; ++w) for (int q = 0; q < 7; ++q) sum[q] += (double)hst[((size_t)wg * 8 + w) * 10 + q];
                                 if (role == 0) fprintf(stderr, "[pair stamps] waves 0-3, cycles per step: top+first reads %.0f | MFMAs+DMA %.0f | dz stores %.0f | logits %.0f | wait %.0f | barrier %.0f  (steps/wave %.1f)\n",
                                         sum[4] / sum[6], sum[0] / sum[6], sum[5] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[6] / (grid * 4.0));
                                 else fprintf(stderr, "[pair stamps] waves 4-7, cycles per step: top+reads %.0f | dz %.0f | dh MFMAs %.0f | wait %.0f | barrier %.0f\n",

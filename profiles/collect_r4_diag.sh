@@ -15,7 +15,7 @@ fi
 NTF_LIB_PATH=$D NTF_DW_STAMP_FILE=$O/dw_stamps.bin python3 $B --no-gather-bench --steps 40 --warmup 10 > /dev/null 2>> $O/bench.err
 python3 $R/profiles/dw_stamps.py $O/dw_stamps.bin > $O/dw_stamps.txt 2>&1; rm -f $O/dw_stamps.bin
 # forward kernels: the wave-pair kernel's segment stamps (default), the one-wave kernel's phase stamps (NTF_FWD_KERNEL=3), and the one-wave kernel's ablations
-NTF_LIB_PATH=$D NTF_FWD_ABL=9 python3 $B --no-gather-bench --steps 40 --warmup 10 > /dev/null 2> $O/fwd_pair_stamps.err; grep "pair stamps" $O/fwd_pair_stamps.err | head -2 > $O/fwd_pair_stamps.txt
+NTF_LIB_PATH=$D NTF_FWD_ABL=9 python3 $B --no-gather-bench --steps 40 --warmup 10 > /dev/null 2> $O/fwd_pair_stamps.err; grep "pair stamps" $O/fwd_pair_stamps.err | head -3 > $O/fwd_pair_stamps.txt
 NTF_LIB_PATH=$D NTF_FWD_KERNEL=3 NTF_FWD_ABL=9 python3 $B --no-gather-bench --steps 40 --warmup 10 > /dev/null 2> $O/fwd_stamps.err; grep "fwd stamps" $O/fwd_stamps.err > $O/fwd_stamps.txt
 for a in 0 2 3; do NTF_LIB_PATH=$D NTF_FWD_KERNEL=3 NTF_FWD_ABL=$a python3 $B --no-gather-bench --steps 40 --warmup 10 > $O/fwd_h3x_abl_$a.json 2>> $O/bench.err; done
 if [ -n "$R4_COSCHED" ]; then
