@@ -308,7 +308,7 @@ def test_uspt_unfiltered_expert_count_step_against_the_oracle():
 @pytest.mark.parametrize("bayesian", [True, False])
 @pytest.mark.parametrize("M,B", [(70_000, 1000), (3000, 333), (70_001, 129)])     # ragged last expert tile / ragged last row block
 def test_sixteen_row_wave_forward_equals_the_default_kernel(bayesian, M, B, monkeypatch):
-    """NTF_FWD_KERNEL=4 (eight 16-row waves on v_mfma_f32_16x16x32_f16, two per SIMD, biases folded into the zT accumulators) against the default k_out_fwd_h3x:
+    """NTF_FWD_KERNEL=4 (eight 16-row waves on v_mfma_f32_16x16x32_f16, two per SIMD, biases folded into the zT accumulators) against round 3's default k_out_fwd_h3x (NTF_FWD_KERNEL=3):
     the same fp16x3 products in another summation order - loss, logits' gradients (through every parameter after one Adam step) agree to rounding"""
     ds = make_dataset("dblp", d=128, seed=13, n_rows=1500, n_experts=M)
     dims = [128, 128, ds["M"]]
