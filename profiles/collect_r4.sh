@@ -40,7 +40,8 @@ done
 wait $BP
 export NTF_BENCH_MIN_TIMED_S=0.01
 # kernel trace (every dispatch: the step timeline) + stats of the default run
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --no-gather-bench --steps 20 --warmup 3 > $O/stats.log 2>&1
+# (200 steps: the first ~15 dispatches of a fresh process run 5-40 % long - clocks and caches settling - and would carry a 23-dispatch average 5 % over the bench's)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --no-gather-bench --steps 200 --warmup 10 > $O/stats.log 2>&1
 # PMC passes (each on its own, no tracing)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_write.log 2>&1
