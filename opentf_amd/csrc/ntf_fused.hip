@@ -1659,9 +1659,10 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3y(OutFwd6Args pp) {
 // of the same 32 batch rows (lane = row in both: the hand-over is lane to lane), one step = one 32-expert sub-tile, one barrier a step.  A issues its MFMAs
 // first and its vector work after them, B its vector work first and its MFMAs after it: matrix work of one beside vector work of the other (the other pairings -
 // half of B's vector work riding on its first MFMAs, the roles on the other wave age, priorities per segment - cost 3 to 15 %: vector issue is arbitrated by
-// age, and two vector streams side by side starve the younger one's MFMAs).  Measured per step and wave (`-DNTF_DIAG`, NTF_FWD_ABL=9): A 530 (top, first
-// fragments) + 1 810 (48 MFMAs + DMA) + 380 (4 stores) + 1 730 (logits); B 810 (top, hand-over and first fragment reads) + 1 250 (dz) + 2 220 (48 MFMAs beside A's
-// vector work) = 4.7 k cycles a sub-tile against k_out_fwd_h3x's 5.45 k: 0.72 -> 0.66 ms on the same box.
+// age, and two vector streams side by side starve the younger one's MFMAs).  Measured per step and wave (`-DNTF_DIAG`, NTF_FWD_ABL=9, profiles/r4_fwd_pair_stamps.txt):
+// A 535 (top, first fragments) + 1 820 (48 MFMAs + DMA) + 345 (4 stores) + 1 625 (logits); B 830 (top, hand-over and first fragment reads) + 1 280 (dz) + 2 200
+// (48 MFMAs beside A's vector work) = 4.7 k cycles a sub-tile against k_out_fwd_h3x's 5.5 k - 1.07 M cycles a wave at 1.65 GHz against 1.27 M at 1.76 (the package
+// power limit gives a third of the saving back): 0.72 -> 0.65-0.67 ms on the same box.
 // LDS: a ring of three 32-expert stages (2 matrices x 2 planes x [32 rows][256 B] + biases = 32.5 KiB each: zT reads stage s, dh stage s-1, the DMA fills s+1)
 // + two hand-over slots of 16 KiB = 129.5 KiB.  Sub-tile order, MFMA order per accumulator, epilogue arithmetic and the packed dz are k_out_fwd_h3x's: dzT and
 // the dh slabs are bit-identical, the loss differs in the order of its sums.  An operand outside the fp16 window: the kernel returns (exact-f32 launch behind it).
