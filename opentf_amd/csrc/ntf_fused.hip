@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
     };
     // half an epilogue (registers 8 hf .. 8 hf + 7 of sub-tile u) spread over the NG groups of a phase, TWO REGISTERS AT A TIME: a lone wave issues in order, and
     // a vector instruction that needs the result of the one before it costs 8.4 cycles against 5.3 for an independent one (6.5 with two chains interleaved;
-    // scratch/probe_valu.hip) - a register's epilogue is one such chain of ~17.  The pair (r0, r0 + 1) that is split together goes through four stages
+    // profiles/probes/probe_valu.hip) - a register's epilogue is one such chain of ~17.  The pair (r0, r0 + 1) that is split together goes through four stages
     // (logit | exp | log, loss, dz | split + store), stage by stage over both registers, a stage per group (two per group without Flipout).
     constexpr int GPP = NG / 4;         // groups per register pair (4 with Flipout, 2 without)
     constexpr int SPG = 4 / GPP;        // stages per group
