@@ -337,7 +337,8 @@ def test_sixteen_row_wave_forward_equals_the_default_kernel(bayesian, M, B, monk
 @pytest.mark.parametrize("M,B", [(70_000, 1000), (3000, 333), (70_001, 129), (40, 70)])     # ragged / empty last sub-tile, ragged last row block, one tile only
 def test_wave_pair_forward_equals_the_one_wave_kernel(bayesian, M, B, monkeypatch):
     """k_out_fwd_h3p (a logit wave and a gradient wave per 32 rows, two waves per SIMD) against k_out_fwd_h3x (NTF_FWD_KERNEL=3): the same fp16x3 products and the
-    same epilogue arithmetic in the same order per accumulator - every gradient is bit-identical; the loss differs in the order its terms are summed"""
+    same epilogue arithmetic in the same order per accumulator - every gradient is bit-identical, and so is every parameter after three steps of the default path
+    (Adam in the dW epilogue, prefetched head); the loss differs in the order its terms are summed"""
     ds = make_dataset("dblp", d=128, seed=13, n_rows=1500, n_experts=M)
     dims = [128, 128, ds["M"]]
     order = np.random.default_rng(6).permutation(ds["N"])[:2 * B].astype(np.int64)
@@ -348,10 +349,16 @@ def test_wave_pair_forward_equals_the_one_wave_kernel(bayesian, M, B, monkeypatc
         loss = e.backward(order[:B])
         g = e.grads()
         l2 = [e.train_step(order[:B]), e.train_step(order[B:])]
-        out.append((loss, l2[0], l2[1], g)); e.close()
+        sd = {n: np.array(v, copy=True) for n, v in e.state_dict().items()}; e.close()
+        # the default step (Adam and the next step's operands in the dW epilogue, the head of the next batch prefetched): three steps, parameters bit for bit
+        e = _mk(ds, dims, bayesian, B, "uniform")
+        l3 = [e.train_step(order[:B]), e.train_step(order[B:]), e.train_step(order[:B])]
+        sd3 = {n: np.array(v, copy=True) for n, v in e.state_dict().items()}; e.close()
+        out.append((loss, l2[0], l2[1], l3[0], l3[1], l3[2], g, sd, sd3))
     a, b = out
-    for x, y in zip(a[:3], b[:3]): assert abs(x - y) <= 2e-6 * abs(x), (x, y)
-    for k in a[3]: np.testing.assert_array_equal(a[3][k], b[3][k], err_msg=k)
+    for x, y in zip(a[:6], b[:6]): assert abs(x - y) <= 2e-6 * abs(x), (x, y)
+    for t in (6, 7, 8):
+        for k in a[t]: np.testing.assert_array_equal(np.asarray(a[t][k]), np.asarray(b[t][k]), err_msg=k)
 
 
 # ------------------------------------------------------------------------------------------ inference (Fnn.test, src/mdl/fnn.py:172-219) at BASELINE config 2's expert count
