@@ -375,10 +375,17 @@ def main():
     # ---- the JSON line (rank 0), assembled from the headline BEFORE anything else runs: whatever happens in a later leg, this much is printed
     extra_modes = {}
     state = {"exact_f32": None, "extra_configs": None, "cpu_baseline": None, "printed": False}
+    import threading
+    emit_lock = threading.Lock()      # the watchdog thread and the main thread may both reach emit(): exactly one line is printed
 
     def emit(final):
-        if rank != 0 or state["printed"]: return
-        state["printed"] = True
+        if rank != 0: return
+        with emit_lock:
+            if state["printed"]: return
+            state["printed"] = True
+        _emit(final)
+
+    def _emit(final):
         B, H, M = a.batch, a.hidden, ds["M"]
         ep = head["ep"]; dt = head["dt"]
         roof, roof_other = rooflines(head["times"], a, bayesian, head["eB"], H, head["Mloc"], ds, ep)
@@ -445,14 +452,13 @@ def main():
 
         watchdog = None
         if rank == 0:
-            import threading
             budget = float(os.environ.get("NTF_BENCH_LEG_BUDGET_S", "150")) * 2
 
             def cut_off():
                 for k in ("ep_weak", "strong_b1000"):
                     extra_modes.setdefault(k, {"error": f"no result within {budget:.0f} s of the extra legs (a hang?): cut off by rank 0's watchdog"})
                 emit(final=False)
-                os._exit(0)
+                os._exit(3)      # the headline is printed, but a leg hung: the launcher must see a failure (dp.CollectiveTimeout's contract)
             watchdog = threading.Timer(budget, cut_off); watchdog.daemon = True; watchdog.start()
         if shardable:
             guarded("ep_weak", "ep", a.batch * world, "weak",
@@ -506,10 +512,11 @@ def main():
                                       "ms_per_pass": float(np.median(ms)), "value": len(d_idx) / (float(np.median(ms)) * 1e-3), "unit": "words/s",
                                       "reference_log": {"file": "output/dblp/dblp.v12.json.mt10.ts2/prep.d2v.skill.log", "s_per_pass": 276.4, "raw_words_per_s": 19073021 / 276.4, "workers": 224, "words": 19073021}}
 
+    leg_failed = any("error" in v and not str(v["error"]).startswith("skipped before any collective") for v in extra_modes.values() if isinstance(v, dict))
     if rank != 0:
         if world > 1 and not any("error" in v for v in extra_modes.values() if isinstance(v, dict)): dist.destroy_process_group()
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0) if world > 1 else None      # (N > 1: no interpreter teardown over process groups whose state an abandoned leg may have left undefined)
+        os._exit(4 if leg_failed else 0) if world > 1 else None      # (N > 1: no interpreter teardown over process groups whose state an abandoned leg may have left undefined; a leg that failed while running: non-zero)
         return
     if a.force_dist and world == 1: dist.destroy_process_group()
     state["exact_f32"], state["extra_configs"] = exact_f32, extra_configs
@@ -520,7 +527,7 @@ def main():
     emit(final=True)
     if world > 1:
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        os._exit(4 if leg_failed else 0)      # the line (with the leg's {"error": ...}) is printed; the exit code says a leg failed while running
 
 
 if __name__ == "__main__":

@@ -116,6 +116,12 @@ int ntf_get_dlogits(ntf_engine* e, float* host, int64_t count);
 /* The sampled negatives [B, ns] (GLOBAL expert ids) of the last step: `topk_indices` of src/mdl/fnn.py:48-76 as the device samplers drew them (or as they were injected).
  * Exposed so that the samplers can be checked draw by draw over a sequence of steps (batch support, distinctness, frequencies), not only through the loss. */
 int ntf_get_negatives(ntf_engine* e, int64_t* host, int64_t count);
+/* The device generators' own draws of ONE random tensor of bayesian-torch's LinearFlipout.forward (called from src/mdl/fnn.py:126,135 through mdl/bnn.py:17-27) for step
+ * index `step` of this engine's seed - what a native, non-injected step with that index consumes: kind 0 eps_weight [out, in], 1 eps_bias [out], 2 sign_input
+ * [rows, in], 3 sign_output [rows, out] (+1 / -1; row r = position r of the step's minibatch), in the reference's layouts.  Exposed so that a sequence of native
+ * steps can be replayed through the oracle with exactly the tensors the kernels regenerate in place (forward sign words, the dW epilogue's re-drawn eps, the
+ * operands the previous step's epilogue produced): tests/test_gpu_replay.py. */
+int ntf_get_noise(ntf_engine* e, uint64_t step, int32_t layer, int32_t kind, int32_t rows, float* host, int64_t count);
 int ntf_reset_optimizer(ntf_engine* e);                  /* fresh Adam per fold, src/mdl/fnn.py:104 */
 int ntf_set_lr(ntf_engine* e, float lr);                 /* ReduceLROnPlateau result, fnn.py:105,163 */
 int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step);

@@ -65,7 +65,9 @@ struct ntf_engine {
     float* al_prob = nullptr; int32_t* al_alias = nullptr; double* al_weight = nullptr; double al_total = 0; int64_t al_n = 0;
     // per-step buffers
     int64_t* d_rows = nullptr; int64_t* d_order = nullptr; int64_t order_cap = 0; std::vector<int64_t> h_order;
-    int64_t* d_neg = nullptr;
+    // sampled negatives [B, ns] of a step live in one of TWO buffers, by step parity (as the fused workspace does): a train step's head prefetch runs the NEXT batch's
+    // sampler beside this step's dW kernel, and ntf_get_negatives / the sparse fix-up of the step in flight must keep reading their own draws
+    int64_t* d_neg_set[2] = {nullptr, nullptr}; uint64_t neg_step = 0;
     std::vector<float*> act;          // act[0] = X [B, D], act[l] = leaky_relu output of layer l-1 (hidden)
     float *Zout = nullptr, *dZout = nullptr, *Pbuf = nullptr;
     float *Zh = nullptr;              // [B, max hidden] pre-activation scratch for hidden flipout layers
@@ -93,6 +95,8 @@ struct ntf_engine {
 #endif
     int lean = 1;                     // NTF_LEAN=0: the dW epilogue also writes the f32 copy of the next step's sigma * eps (round 3's 64 B per pair; A/B runs)
     int dw_kernel = 1;                // NTF_DW_KERNEL=0: k_out_dw_p2 (one 256-expert workgroup per CU) instead of k_out_dw_q (A/B runs)
+    int dw_tail = 0;                  // NTF_DW_TAIL=1|2|3 (experiment, measured slower - DESIGN.md section 4.0): the last partial round of half-tiles as split-K launches (see dw_launch_whole); 0: the whole layer in ONE k_out_dw_q launch
+    int n_cu = 256;
     int dw_ksplit = 0;                // 0: automatic (few expert tiles -> split the dW kernel's K range), else forced (NTF_DW_KSPLIT)
     int32_t* d_range = nullptr;       // fp16x3 range guard (lives behind d_kl[0]): [0] raised for the current step, [1] steps that fell back to the f32 kernels
     int64_t range_fallbacks_host = 0; // inference calls redone on the generic path for the same reason
@@ -221,6 +225,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
     if (const char* dk = getenv("NTF_DW_KERNEL")) e->dw_kernel = atoi(dk);
     if (const char* ln = getenv("NTF_LEAN")) e->lean = atoi(ln);
+    if (const char* dt = getenv("NTF_DW_TAIL")) e->dw_tail = atoi(dt);
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) e->n_cu = ncu; }
     if (const char* hp = getenv("NTF_HEAD_PREFETCH")) e->head_prefetch = atoi(hp);
 #ifdef NTF_DIAG
     if (const char* co = getenv("NTF_COSCHED")) e->cosched = atoi(co);
@@ -256,7 +262,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     int rc = NTF_OK;
     auto A = [&](int r) { if (rc == NTF_OK) rc = r; };
     A(dmalloc(e, &e->P, off)); A(dmalloc(e, &e->G, off)); A(dmalloc(e, &e->M1, off)); A(dmalloc(e, &e->V2, off));
-    A(dmalloc(e, &e->d_rows, B)); A(dmalloc(e, &e->d_neg, (int64_t)B * std::max(1, cfg->ns)));
+    A(dmalloc(e, &e->d_rows, B)); for (int k = 0; k < 2; ++k) A(dmalloc(e, &e->d_neg_set[k], (int64_t)B * std::max(1, cfg->ns)));
     e->act.assign(e->L, nullptr);
     for (int l = (cfg->input_mode == NTF_INPUT_MULTIHOT ? 1 : 0); l < e->L; ++l) A(dmalloc(e, &e->act[l], (int64_t)B * cfg->dims[l]));  // multi-hot X is never dense
     A(dmalloc(e, &e->Zout, (int64_t)B * M)); A(dmalloc(e, &e->dZout, (int64_t)((M + 255) / 256 * 256) * fused_ldb(B)));
@@ -299,7 +305,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     dfree(e->P); dfree(e->G); dfree(e->M1); dfree(e->V2);
     dfree(e->m_indptr); dfree(e->m_indices); dfree(e->s_indptr); dfree(e->s_indices); dfree(e->table); dfree(e->Xall);
     dfree(e->al_prob); dfree(e->al_alias); dfree(e->al_weight);
-    dfree(e->d_rows); dfree(e->d_order); dfree(e->d_neg);
+    dfree(e->d_rows); dfree(e->d_order); dfree(e->d_neg_set[0]); dfree(e->d_neg_set[1]);
     for (auto& p : e->act) dfree(p);
     dfree(e->Zout); dfree(e->dZout); dfree(e->Pbuf); dfree(e->Zh); dfree(e->dAct[0]); dfree(e->dAct[1]);
     for (auto& p : e->Wp) dfree(p);
@@ -588,7 +594,7 @@ static int stage_all_inj(ntf_engine* e, const StepCtx& c) {
             HIPCHK(e, hipMemcpyAsync(e->inj_s_out[l], c.inj->s_out[l], (size_t)c.B * li.out * 4, hipMemcpyHostToDevice, e->st)); }
     }
     if (c.inj->neg_idx && e->cfg.ns > 0)
-        HIPCHK(e, hipMemcpyAsync(e->d_neg, c.inj->neg_idx, (size_t)c.B * e->cfg.ns * 8, hipMemcpyHostToDevice, e->st));
+        HIPCHK(e, hipMemcpyAsync(e->d_neg_set[c.step & 1], c.inj->neg_idx, (size_t)c.B * e->cfg.ns * 8, hipMemcpyHostToDevice, e->st));
     HIPCHK(e, hipStreamSynchronize(e->st));
     return NTF_OK;
 }
@@ -665,17 +671,17 @@ static int sample_negatives(ntf_engine* e, const StepCtx& c) {
     uint32_t k0, k1; make_key(e, c.step, 0, T_NEG, k0, k1);
     const int M = e->Mg;   // negatives are drawn over the WHOLE output layer (an expert shard keeps the ones it owns, k_out_special)
     if (e->cfg.nsd == NTF_NSD_UNIFORM) {
-        launch_ns_uniform(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
+        launch_ns_uniform(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, k0, k1, (uint32_t)c.step, c.row0, e->d_neg_set[c.step & 1]);
     } else if (e->cfg.nsd == NTF_NSD_UNIGRAM) {
         if (!e->al_prob) FAIL(e, NTF_ESTATE, "unigram table not set (ntf_set_unigram)");
         launch_ns_alias(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, e->al_prob, e->al_alias, e->al_weight, e->al_total,
-                        k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
+                        k0, k1, (uint32_t)c.step, c.row0, e->d_neg_set[c.step & 1]);
     } else if (e->cfg.nsd == NTF_NSD_UNIGRAM_B) {
         const char* d = static_cast<const char*>(e->ub_dev[e->ub_slot]);
         const size_t n = (size_t)e->ub_nsup;
         launch_ns_alias_sparse(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, reinterpret_cast<const int32_t*>(d),
                                reinterpret_cast<const float*>(d + n * 8), reinterpret_cast<const int32_t*>(d + n * 4),
-                               reinterpret_cast<const float*>(d + n * 12), e->ub_nsup, e->ub_total, k0, k1, (uint32_t)c.step, c.row0, e->d_neg);
+                               reinterpret_cast<const float*>(d + n * 12), e->ub_nsup, e->ub_total, k0, k1, (uint32_t)c.step, c.row0, e->d_neg_set[c.step & 1]);
     } else FAIL(e, NTF_EINVAL, "bad nsd");
     return NTF_OK;
 }
@@ -762,6 +768,39 @@ static void head_launch(ntf_engine* e, hipStream_t st, const StepCtx& c, char* w
     launch_head(st, a);
 }
 
+// The output layer's dW (+ Adam + next-step operands) of a whole step.  k_out_dw_q runs two 128-expert workgroups per CU, the epilogue of one beside the main loop of the
+// other; its grid of ceil(M / 128) half-tiles is dealt over 2 x CUs slots, and what bounds the launch is the LAST, partial round: at config 2, 1 826 half-tiles over 512
+// slots are 3.57 per slot - 290 slots run a fourth tile of ~130 us while 222 idle, and a CU left with one workgroup keeps neither HBM nor the matrix pipe busy (DESIGN.md
+// section 4.0: 0.46 ms of work in a 0.58-0.61 ms span).  Here the launch is cut at the last whole round: [0, rounds x slots) half-tiles go to k_out_dw_q - every slot the same
+// number of tiles, all ending together - and the rest (the tail) to the split-K form of k_out_dw_p2 (every tile's K range over `ks` workgroups, raw partial slabs in the
+// idle dense-logits buffer) followed by k_out_dw_finish, whose epilogue - the HBM-bound half of a tile - is one thread per four weights over the whole chip.
+// mode (NTF_DW_TAIL): 1 = tail behind the main launch on the same stream, 2 = in front of it, 3 = beside it on the chunk stream.
+static int dw_launch_whole(ntf_engine* e, const FusedDw& f) {
+    const int slots = 2 * e->n_cu, total_q = (f.M + 127) / 128, full_q = total_q / slots * slots, tail_q = total_q - full_q;
+    const bool can = e->dw_tail > 0 && f.kernel == 1 && f.dz_packed && f.adam && f.ksplit <= 1 && f.wg_count <= 0 && f.H == 128 && full_q > 0 && tail_q > 0 &&
+                     tail_q * 10 <= slots * 8 && e->Zout != nullptr;
+    if (!can) { launch_fused_out_dw(e->st, f); return NTF_OK; }
+    const int tail_p2 = (tail_q + 1) / 2, nib = fused_ldb(f.B) / 32;
+    // K ranges per tail tile: as many as fill whole rounds of one 256-expert workgroup per CU (two rounds unless the tail is tiny), at least 4 K blocks each
+    int ks = std::max(1, std::min({2 * e->n_cu / tail_p2, 8, std::max(1, nib / 4)}));
+    if (const char* v = getenv("NTF_DW_TAIL_KS")) ks = std::max(1, atoi(v));
+    if (ks < 2 || fused_dw_part_floats(tail_p2 * 256, f.H, ks) > (int64_t)e->cfg.max_batch * e->cfg.dims[e->L]) { launch_fused_out_dw(e->st, f); return NTF_OK; }
+    FusedDw fm = f; fm.wg_begin = 0; fm.wg_count = full_q / 2; fm.no_fallback = 1;
+    FusedDw ft = f; ft.wg_begin = full_q / 2; ft.wg_count = tail_p2; ft.ksplit = ks; ft.part = e->Zout; ft.no_fallback = 1;
+    if (e->dw_tail == 3) {
+        if (!e->st2) { HIPCHK(e, hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_chunk, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming)); }
+        HIPCHK(e, hipEventRecord(e->ev_chunk, e->st));
+        HIPCHK(e, hipStreamWaitEvent(e->st2, e->ev_chunk, 0));
+        launch_fused_out_dw(e->st, fm);
+        launch_fused_out_dw(e->st2, ft);
+        HIPCHK(e, hipEventRecord(e->ev_side, e->st2));
+        HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_side, 0));
+    } else if (e->dw_tail == 2) { launch_fused_out_dw(e->st, ft); launch_fused_out_dw(e->st, fm); }
+    else { launch_fused_out_dw(e->st, fm); launch_fused_out_dw(e->st, ft); }
+    if (f.rflag) { FusedDw fb = f; fb.fallback_only = 1; launch_fused_out_dw(e->st, fb); }
+    return NTF_OK;
+}
+
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
 static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     int r;
@@ -771,7 +810,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const bool fused = fused_ok(e);
     const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
     int nslots;
-    const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg : nullptr;
+    const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg_set[c.step & 1] : nullptr;
     bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false;
     // one kernel for gather -> hidden layer -> operand images (ntf_head.hip): one hidden layer of 128 units over a dense / mean-pooled input, native generators, fp16x3 planes
     const bool use_head = fused && e->head && e->L == 2 && c.part <= 1 && !c.inj && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
@@ -1033,7 +1072,7 @@ backward:
 #ifdef NTF_DIAG
             if (e->cosched > 0) { e->cosched_dw = f; e->cosched_have = true; goto dw_done; }      // (this step's dW rides beside the NEXT step's forward kernel: timing only)
 #endif
-            { Scope t(e, F_OUT_FUSED_DW); launch_fused_out_dw(e->st, f); }
+            { Scope t(e, F_OUT_FUSED_DW); if ((r = dw_launch_whole(e, f))) return r; }
         dw_done:;
         } else {
             const float* dZ = last ? e->dZout : e->dAct[(l + 1) & 1];
@@ -1208,7 +1247,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
         if ((r = set_batch_unigram(e, global_rows_host, n_global))) return r;
     }
     if ((r = run_step(e, c, true))) return r;
-    e->last_B = B; e->last_global_B = global_B;
+    e->last_B = B; e->last_global_B = global_B; e->neg_step = c.step;
     if (train && apply && (r = apply_adam(e))) return r;
     if ((r = read_loss(e, loss_out))) return r;
     hipError_t s = hipGetLastError();
@@ -1336,7 +1375,7 @@ extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int3
         if ((r = stage_rows(e, e->d_order + offset, B, true, &c.rows_dev))) return r;
         if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && (r = set_batch_unigram(e, e->h_order.data() + offset, B))) return r;
         if ((r = run_step(e, c, true))) return r;
-        e->last_B = B; e->last_global_B = B;
+        e->last_B = B; e->last_global_B = B; e->neg_step = c.step;
         e->ep_ctx = c; e->ep_open = 1;
         // phase 2 (this shard's dW kernel) on the side stream, beside the exchange and phase 3: one rank of 2 runs 1.684 -> 1.626 ms, of 4 1.605 -> 1.584, of 8
         // unchanged (its split-K dW launch is a single round: no idle tail to fill)
@@ -1456,7 +1495,7 @@ extern "C" int ntf_get_negatives(ntf_engine* e, int64_t* host, int64_t count) {
     if (count != (int64_t)B * ns) FAIL(e, NTF_EINVAL, "negatives: count != B * ns of the last step");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (e->st4) HIPCHK(e, hipStreamSynchronize(e->st4));
-    HIPCHK(e, hipMemcpyAsync(host, e->d_neg, (size_t)count * 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(e, hipMemcpyAsync(host, e->d_neg_set[e->neg_step & 1], (size_t)count * 8, hipMemcpyDeviceToHost, e->st));
     HIPCHK(e, hipStreamSynchronize(e->st));
     return NTF_OK;
 }
@@ -1676,4 +1715,37 @@ extern "C" int ntf_k_fill_sign(void* stream, uint64_t seed, uint64_t step, int l
     SignSpec s; s.enabled = 1; s.ld = cols; make_key(&tmp, step, layer, T_S_OUT, s.k0, s.k1);
     launch_fill_sign((hipStream_t)stream, s, rows, cols, dev_out);
     return hipGetLastError() == hipSuccess ? NTF_OK : NTF_EHIP;
+}
+
+// The device generators' own draws of one tensor of one step of THIS engine (its seed, its expert shard): what a native - non-injected - step with that step index
+// consumes, in the reference's layouts (bayesian-torch LinearFlipout.forward: eps_weight [out, in], eps_bias [out], sign_input [rows, in], sign_output [rows, out];
+// signs as +1 / -1, row r = position r of the step's minibatch).  Test hook: feeding these to the oracle ties the kernels that regenerate them in place (the forward
+// kernels' sign words, the dW epilogue's Philox re-draw, the operand producers of the previous step's epilogue) to ONE exported tensor per (step, layer, kind).
+extern "C" int ntf_get_noise(ntf_engine* e, uint64_t step, int32_t layer, int32_t kind, int32_t rows, float* host, int64_t count) {
+    if (!e || !host) return NTF_EINVAL;
+    if (!e->cfg.bayesian) FAIL(e, NTF_ESTATE, "noise: not a Bayesian model");
+    if (layer < 0 || layer >= e->L || kind < 0 || kind > 3) FAIL(e, NTF_EINVAL, "noise: bad layer / kind (0 eps_weight, 1 eps_bias, 2 sign_input, 3 sign_output)");
+    const LayerInfo& li = e->layers[layer];
+    const bool sign = kind >= 2;
+    if (sign && (rows < 1 || rows > e->cfg.max_batch)) FAIL(e, NTF_EINVAL, "noise: rows must be in [1, max_batch] for a sign tensor");
+    const int64_t n = kind == 0 ? li.nw() : kind == 1 ? (int64_t)li.out : (int64_t)rows * (kind == 2 ? li.in : li.out);
+    if (count != n) FAIL(e, NTF_EINVAL, "noise: element count mismatch");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    float* tmp = nullptr;
+    DM(e, &tmp, n);
+    StepCtx c; c.step = step; c.B = sign ? rows : 0; c.global_B = c.B;
+    if (sign) { SignSpec s = sign_spec(e, c, layer, kind == 2 ? T_S_IN : T_S_OUT, kind == 2 ? li.in : li.out); s.inj = nullptr; launch_fill_sign(e->st, s, rows, kind == 2 ? li.in : li.out, tmp); }
+    else { NormalSpec s = normal_spec(e, c, layer, kind == 0 ? T_EPS_W : T_EPS_B); s.inj = nullptr; launch_fill_normal(e->st, s, n, tmp); }
+    hipError_t st = hipStreamSynchronize(e->st);
+    int rc = NTF_OK;
+    if (st == hipSuccess) {
+        if (kind == 0 && stored_transposed(e, layer, NTF_P_WEIGHT)) {   // the producer walks the stored [S, H] order of a multi-hot first layer
+            std::vector<float> t((size_t)n);
+            st = hipMemcpy(t.data(), tmp, n * 4, hipMemcpyDeviceToHost);
+            if (st == hipSuccess) transpose_host(t.data(), host, li.in, li.out);
+        } else st = hipMemcpy(host, tmp, n * 4, hipMemcpyDeviceToHost);
+    }
+    hipFree(tmp);
+    if (st != hipSuccess) { e->err = std::string("noise: ") + hipGetErrorString(st); rc = NTF_EHIP; }
+    return rc;
 }

@@ -27,8 +27,8 @@ struct FusedOut {
     int np = 3;                                     // 3: bf16x6, 2: fp16x3 (operands scaled by exact powers of two before their two-way fp16 split)
     float w_scale = 1.f, h_scale = 1.f, dz_scale = 1.f;
     int wide = 5;                                   // np = 2 training step: 5 (default, round 4) k_out_fwd_h3p - a logit wave and a gradient wave per 32 rows, two waves per SIMD, 32-expert steps;
-                                                    // 3 k_out_fwd_h3x - one wave per SIMD, 64-expert tiles, phases rotated across tiles (round 3's default); 4 k_out_fwd_h3y (sixteen-row
-                                                    // waves, two per SIMD); 0 the 32-expert-tile kernel k_out_fwd_b6.  NTF_FWD_KERNEL selects the A/B forms
+                                                    // 3 k_out_fwd_h3x - one wave per SIMD, 64-expert tiles, phases rotated across tiles (round 3's default); 0 the 32-expert-tile kernel
+                                                    // k_out_fwd_b6.  NTF_FWD_KERNEL selects the A/B forms (round 3's sixteen-row-wave form, 4, was retired in round 5)
     int ncg_limit = 0;                              // > 0 (diagnostics, NTF_COSCHED): at most this many column groups, i.e. a forward grid of NRB * ncg_limit workgroups that leaves CUs free
     int planes_ready = 0;
     int h_ready = 0;                                // the zero-padded h, h * s_in and the s_in words are in the workspace already (ntf_head.hip): phase 1 skips k_prep_h
@@ -59,8 +59,10 @@ struct FusedDw {
     int* rflag = nullptr;                           // fp16x3 range guard, see FusedOut
     int dz_packed = 0;                              // np = 2, H = 128: dzT holds the forward kernel's packed fp16 plane pairs (see pack_planes)
     int kernel = 1;                                 // dz_packed, unsplit K: 1 = k_out_dw_q (two 128-expert workgroups per CU, epilogue beside main loop), 0 = k_out_dw_p2
-    int ksplit = 1; float* part = nullptr;          // dz_packed path, whole-layer launch: split every expert tile's K (batch) range over ksplit workgroups; part = scratch
+    int ksplit = 1; float* part = nullptr;          // dz_packed path: split every launched expert tile's K (batch) range over ksplit workgroups; part = scratch
                                                     // of fused_dw_part_floats(M, H, ksplit) floats.  For few expert tiles (a narrow expert shard under a wide minibatch).
+    int no_fallback = 0, fallback_only = 0;         // a step whose dW is issued as several launches (the tail split): the split-product launches carry no exact-f32 launch behind
+                                                    // them (no_fallback), ONE launch over the whole layer follows (fallback_only: nothing but that kernel)
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
     float lr_over_bc1 = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, bc2_sqrt = 1.f;
     // produce != 0 (adam, bayes, H = 128, fp16x3 planes): the Adam epilogue also writes the NEXT step's operands from the updated parameters - eps' (nx_eps: the

@@ -1293,362 +1293,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
 
 
 // ------------------------------------------------------------------------------------------------
-// k_out_fwd_h3y: k_out_fwd_h3x's tile, LDS stages and rotated phases with TWO WAVES PER SIMD (round 3).
-// One wave per SIMD is bound by its own instruction stream: every vector / LDS / wait instruction of a lone wave takes ~4.3 issue cycles, a 64-expert tile
-// carries ~1.4 k of them beside 192 MFMAs (6.1 k cycles of matrix pipe) and runs 10.9 k cycles.  Eight waves of SIXTEEN batch rows keep the workgroup's
-// 128 rows and halve a wave's state (dh accumulators 64 registers, zT 32, h and h*s_in planes 64: under 256), on v_mfma_f32_16x16x32_f16:
-//   zT   X[T] (16 experts x 16 rows) += W[16 experts x 32 hidden] . hT        A = one ds_read_b128 per plane, B = the wave's h planes
-//        a lane (c = lane & 15, g = lane >> 4) ends with row c, experts 16 T + 4 g + (0..3)
-//   dh   Y[jt] (16 rows x 16 hidden) += dz[16 rows x 32 experts] . W          A = the lane's own dz planes of the sub-tile pair T0 = 2u, T1 = 2u + 1:
-//        k = 8 g + j  <->  expert 16 T0 + 4 g + j (j < 4), 16 T1 + 4 g + j - 4 (j >= 4) - no data movement; B = two ds_read_b64_tr_b16 per plane
-//        (4 x 16 blocks at expert rows 16 T + 4 g ..), the same k order
-// Each wave reads every weight fragment of the tile itself: twice the LDS traffic of h3x (1 MB per tile and CU = 4.1 k LDS cycles); the stage image is
-// swizzled for THIS pair of accesses (f16 below): both are conflict-free.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_frag_h(a), as_frag_h(b), acc, 0, 0, 0); }
-// physical 16-byte chunk of logical chunk ch in LDS row r: ch ^ f16(r & 15).  ds_read_b128 (lane groups {0-3,12-15,20-27} ..: rows {0-3,12-15} at chunk 4s,
-// rows 4-11 at 4s + 1) needs f16(rows 4..11) closed under ^1; the transposed read (32 lanes: rows 0..7 or 8..15, chunks 2jt, 2jt + 1) needs f16 >> 1
-// distinct over 8 consecutive rows.
-__host__ __device__ __forceinline__ constexpr int f16swz(int r) { return (r & 15) < 8 ? 2 * (r & 15) : 2 * (((r & 15) + 4) & 7) + 1; }
-
-#ifndef H3Y_BG
-#define H3Y_BG 2
-#endif
-template <bool BAYES, bool INJ>
-__global__ __launch_bounds__(512) void k_out_fwd_h3y(OutFwd6Args pp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const OutFwdArgs& p = pp.a;
-    constexpr int H = 128, NJT = 8, NKS = 4, NP = 2, BNT = 64;
-    constexpr int PLANE = BNT * H * 2;          // 16 KiB
-    constexpr int TM = NP * PLANE;              // one matrix of a tile
-    constexpr int NMAT = BAYES ? 2 : 1;
-    constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g4 = lane >> 4;
-    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) return;   // an operand left the fp16 window: the exact-f32 launch behind this one runs the step
-
-    int bid = blockIdx.x;
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int cg = bid / p.NRB, rb = bid % p.NRB;
-    const int t_beg = (int)((int64_t)cg * p.T / p.NCG), t_end = (int)((int64_t)(cg + 1) * p.T / p.NCG);   // p.T = 64-expert tiles
-    const int i0 = rb * BM + wave * 16;
-    const int i = i0 + c;
-    const bool row_ok = i < p.B;
-
-    // B operand of zT: h[i][32 s + 8 g + j], j = 0..7, as fp16 planes (hq) and with the s_in signs (hsq)
-    u32x4 hq[NKS][NP], hsq[NKS][NP];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 32 * s + 8 * g4);   // p.h = zero-padded copy
-        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 32 * s + 8 * g4 + 4);
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        const uint32_t sw_in = BAYES ? (INJ ? p.sinbits[(int64_t)i * 4 + s] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)s) : 0u)) : 0u;
-        const uint32_t w8 = sw_in >> (8 * g4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t pq[3];
-            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
-            const uint32_t hm = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
-            hq[s][0][q] = pq[0]; hq[s][1][q] = pq[1];
-            hsq[s][0][q] = pq[0] ^ hm; hsq[s][1][q] = pq[1] ^ hm;
-        }
-    }
-    const float rmask = row_ok ? 1.f : 0.f;
-    const float rscale_pos = row_ok ? p.tnw * p.inv_B * pp.dz_scale : 0.f;    // dz * dz_scale = this * sigmoid(l)   (z > 0), ...
-    const float rscale_neg = rscale_pos * kLeakySlope;                         // ... * leaky slope                       (z <= 0)
-
-    f32x4 Y1[NJT], Y2[NJT];
-#pragma unroll
-    for (int j = 0; j < NJT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
-    LossAcc lacc;
-
-    const uint32_t smem_base = lds_addr(smem);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    constexpr int PER_WAVE = TM / 1024 / 8;     // 1 KiB wave-instructions per wave per matrix
-    constexpr int NPIECE = NMAT * PER_WAVE + 1; // DMA pieces per wave and tile (+ the bias piece)
-    uint32_t dsrc[PER_WAVE];
-#pragma unroll
-    for (int n = 0; n < PER_WAVE; ++n) {
-        const int inst = wave_u * PER_WAVE + n;
-        const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row (0..63), physical chunk
-        const int plane = pos / PLANE, row = (pos >> 8) & 63, chp = (pos >> 4) & 15;
-        const int ch = chp ^ f16swz(row);
-        // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
-        dsrc[n] = (uint32_t)((((row >> 5) * (32 * NP) + plane * 32 + (row & 31)) * 256) + 16 * ch);
-    }
-    auto stage_piece = [&](int t, int buf, int n) {
-        const uint32_t sb = smem_base + buf * STAGE;
-        if (n < NMAT * PER_WAVE) {
-            const int mat = n / PER_WAVE, nn = n % PER_WAVE;
-            const int inst = wave_u * PER_WAVE + nn;
-            const char* base = reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)t * (2 * 32 * NP * 256);    // wave-uniform: the tile's planes
-            glds16(base + dsrc[nn], sb + mat * TM + inst * 1024);
-        } else {   // the two bias tiles, branch-free: even waves fetch mu_b's, odd waves bp's (several times each: the same bytes to the same place)
-            const int c0 = t * BNT;
-            const int which = BAYES ? (wave_u & 1) : 0;
-            glds4((which ? p.bp : p.mu_b) + min(c0 + lane, p.M - 1), sb + NMAT * TM + which * 256);
-        }
-    };
-    auto sign_words = [&](int t) -> uint2 {         // s_out signs of (row i, experts 64t .. 64t+63)
-        if (!BAYES || !row_ok) return make_uint2(0u, 0u);
-        if (INJ) return *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);
-        return make_uint2(sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t)), sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t + 1)));
-    };
-    if (t_beg < t_end) {
-        // the first tile into BOTH stages: the zero "previous" sub-tile multiplies whatever stage 1 holds - it must be finite
-#pragma unroll
-        for (int n = 0; n < NPIECE; ++n) { stage_piece(t_beg, 0, n); stage_piece(t_beg, 1, n); }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // X[T]: zT of the 16-expert sub-tile T of the tile; the pair u = (2u, 2u + 1) is one dh operand.  Pair 1 is carried across iterations.
-    f32x4 X1[4], X2[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { X1[T][r] = 0.f; X2[T][r] = 0.f; }
-    u32x4 ad[2][NP];        // [u][plane]: fp16 planes of dz, element 2 Tl + (r >> 1) holds registers (r, r + 1) of sub-tile 2u + Tl
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) ad[u][q] = u32x4{0u, 0u, 0u, 0u};
-    uint32_t swp = 0u;                  // s_out word of pair (1, t-1), shifted by 4 g
-    float rm_prev = 0.f, rsp_prev = 0.f, rsn_prev = 0.f;    // row constants of pair (1, t-1): zero for the virtual one before the first tile
-    constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
-    const int dz_voff = ((i >> 5) * 8192 + 4 * g4 * 32 + (i & 31)) * 4;
-    __amdgpu_buffer_rsrc_t rsrc_prev = __builtin_amdgcn_make_buffer_rsrc(p.dzT, 0, 0, 0x00020000);   // zero records: the virtual sub-tile's stores are dropped
-
-    constexpr int NHG = NKS * 2 * NMAT;  // groups (k-step, sub-tile of the pair, matrix) of one pair's zT: 2 fragment reads + 3 MFMAs each
-    constexpr int NGD = NJT * NMAT;      // groups (jt, matrix) of one pair's dh: 4 transposed reads + 3 MFMAs each
-    static_assert(NHG == NGD, "the four phases have the same number of MFMA groups");
-    constexpr int NG = NHG, BG = H3Y_BG;
-
-    typedef const __attribute__((address_space(3))) char* ldsp_t;
-    const int fc = f16swz(c);
-    // LDS addresses: per-lane base registers (moved from stage to stage by +-STAGE as the tiles go by) + immediates
-    ldsp_t zb[NKS];                                  // row read of k-step s: row c (+ 16 T as an immediate), logical chunk 4 s + g.  Stage of the current tile.
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) zb[s] = (ldsp_t)(size_t)(smem_base + 256 * c + 16 * ((4 * s + g4) ^ fc));
-    ldsp_t tb[NJT];                                  // transposed read of hidden tile jt: block rows 4 g + q (+ 16 T), logical chunks 2 jt, 2 jt + 1.
-    {                                                // Stage of the previous tile up to dh(1, t-1), of the current one from there on: starts in stage 1
-        const int q = c >> 2, pq = c & 3, row = 4 * g4 + q;
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) tb[jt] = (ldsp_t)(size_t)(smem_base + STAGE + 256 * row + 16 * ((2 * jt + (pq >> 1)) ^ f16swz(row)) + 8 * (pq & 1));
-    }
-    auto z_load = [&](const ldsp_t (&zb)[NKS], int u, int hg, u32x4 (&fr)[NP]) {
-        const int mat = hg % NMAT, Tl = (hg / NMAT) & 1, s = hg / (2 * NMAT);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(zb[s] + (4096 * (2 * u + Tl) + mat * TM + q * PLANE));
-    };
-    // the three products of group hg, one at a time (k = 0, 1, 2) so that two groups can be issued interleaved: lo*hi, hi*lo, hi*hi
-    auto z_mma1 = [&](int u, int hg, int k, const u32x4 (&fr)[NP]) {
-        const int mat = hg % NMAT, Tl = (hg / NMAT) & 1, s = hg / (2 * NMAT), T = 2 * u + Tl;
-        const int ia = k == 0 ? 1 : 0, ib = k == 1 ? 1 : 0;
-        if (mat == 0) X1[T] = mfma16h(fr[ia], hq[s][ib], X1[T]);      // (X starts from the scaled biases, see bias_init)
-        else X2[T] = mfma16h(fr[ia], hsq[s][ib], X2[T]);
-    };
-    // zT accumulators of the pair u start from bias / u_z (u_z = the exact power of two that undoes the operand scales): z / u_z = X1 +- X2 needs no bias afterwards
-    const float inv_uz = 1.f / pp.u_z;
-    auto bias_init = [&](const char* sb, int u) {
-#pragma unroll
-        for (int Tl = 0; Tl < 2; ++Tl) {
-            const int T = 2 * u + Tl;
-            const float4 m0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sb + NMAT * TM) + 16 * T + 4 * g4);
-            X1[T][0] = m0.x * inv_uz; X1[T][1] = m0.y * inv_uz; X1[T][2] = m0.z * inv_uz; X1[T][3] = m0.w * inv_uz;
-            if (BAYES) {
-                const float4 q0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 16 * T + 4 * g4);
-                X2[T][0] = q0.x * inv_uz; X2[T][1] = q0.y * inv_uz; X2[T][2] = q0.z * inv_uz; X2[T][3] = q0.w * inv_uz;
-            }
-        }
-    };
-    // epilogue of register r of sub-tile T: lane = batch row i, expert c0 + 16 T + 4 g + r; leaves dz * dz_scale in X1[T][r].  swu = the pair's s_out word >> 4 g.
-    // With a = -log2(e) * max(leaky_relu(z), -80): softplus = ln2 * (log2(1 + 2^a) - a), sigmoid = 1 / (1 + 2^a); lsum collects log2(1 + 2^a) - a.
-    const float k_pos = -1.4426950408889634f * pp.u_z, k_neg = k_pos * kLeakySlope;
-    auto epilogue = [&](int T, int r, uint32_t swu, float rsp, float rsn, float& lsum) {
-        const int bit = 16 * (T & 1) + r;
-        float zs = X1[T][r];
-        if (BAYES) zs += __uint_as_float(__float_as_uint(X2[T][r]) ^ ((swu << (31 - bit)) & 0x80000000u));
-        const bool pos = zs > 0.f;
-        const float a = fminf(zs * (pos ? k_pos : k_neg), 115.41560327111707f);
-        const float tt = 1.f + __builtin_amdgcn_exp2f(a);
-        lsum += __builtin_amdgcn_logf(tt) - a;
-        X1[T][r] = __builtin_amdgcn_rcpf(tt) * (pos ? rsp : rsn);
-    };
-    // registers r0, r0 + 1 (r0 even) of sub-tile T -> fp16 planes (A operand of dh) + the packed store
-    auto split_pair_a = [&](int T, int r0, __amdgpu_buffer_rsrc_t rsrc) {
-        uint32_t p0, p1;
-        split_pair_h(X1[T][r0], X1[T][r0 + 1], p0, p1);    // (no clamp: |dz| * dz_scale < 2^14)
-        const int u = T >> 1, e = 2 * (T & 1) + (r0 >> 1);
-        ad[u][0][e] = p0; ad[u][1][e] = p1;
-        uint32_t d0, d1;
-        pack_planes(p0, p1, d0, d1);
-        __builtin_amdgcn_raw_buffer_store_b32(d0, rsrc, dz_voff, (16 * T + r0) * dz_row_bytes, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(d1, rsrc, dz_voff, (16 * T + r0 + 1) * dz_row_bytes, 0);
-    };
-    auto tr_load = [&](const ldsp_t (&tb)[NJT], int u, int g, u32x4 (&bf)[NP]) {   // g = (jt, mat)
-        const int mat = g % NMAT, jt = g / NMAT;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int o = 8192 * u + q * PLANE + mat * TM;
-            const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[jt] + o)));
-            const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[jt] + o + 4096)));
-            bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
-        }
-    };
-    auto signed_a = [&](int u, uint32_t swu, u32x4 (&o)[NP]) {   // planes of dz * s_out
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int bit = 16 * (e >> 1) + 2 * (e & 1);
-            const uint32_t m = (((swu << (31 - bit)) & 0x80000000u) >> 16) | ((swu << (30 - bit)) & 0x80000000u);
-            o[0][e] = ad[u][0][e] ^ m; o[1][e] = ad[u][1][e] ^ m;
-        }
-    };
-    auto d_mma1 = [&](int u, int g, int k, const u32x4 (&asg)[NP], const u32x4 (&bf)[NP]) {
-        const int mat = g % NMAT, jt = g / NMAT;
-        const int ia = k == 0 ? 1 : 0, ib = k == 1 ? 1 : 0;
-        if (mat == 0) Y1[jt] = mfma16h(ad[u][ia], bf[ib], Y1[jt]);
-        else Y2[jt] = mfma16h(asg[ia], bf[ib], Y2[jt]);
-    };
-    // one sub-tile's epilogue (4 registers) spread over the NG groups of a phase
-    constexpr int GPR = NG / 4;         // groups per register
-    auto ride = [&](int T, int g, uint32_t swu, float rsp, float rsn, __amdgpu_buffer_rsrc_t rsrc, float& lsum) {
-        if (g % GPR == 0) {
-            const int r = g / GPR;
-            epilogue(T, r, swu, rsp, rsn, lsum);
-            if (r & 1) split_pair_a(T, r - 1, rsrc);
-        }
-    };
-
-    u32x4 fb[BG][NP];       // ring: group g's fragments sit in fb[g % BG]; they are reloaded for group g + BG right behind its MFMAs
-    static_assert(NG % BG == 0 && BG % 2 == 0, "the fragment ring keeps its phase across phases; groups are issued in pairs");
-
-    for (int t = t_beg; t < t_end; ++t) {
-        const int buf = (t - t_beg) & 1;
-        const int to_cur = buf ? STAGE : -STAGE;              // from the previous tile's stage to this tile's
-        const uint2 w2 = sign_words(t);
-        char* sb = smem + buf * STAGE;
-        const int c0 = t * BNT;
-        const int tn = min(t + 1, t_end - 1);
-        if (c0 + BNT > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
-            if (tid < BNT && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -1e30f;
-            __syncthreads();
-        }
-        const uint32_t sw[2] = {w2.x >> (4 * g4), w2.y >> (4 * g4)};
-        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
-        float lt = 0.f, ltp = 0.f;      // log2 sums of this tile's sub-tiles / of sub-tile 3 of the previous tile (other row mask)
-
-        auto load_for = [&](int ph, int g, u32x4 (&dst)[NP]) {
-            if (ph == 0) z_load(zb, 0, g, dst);             // zT(0, t)
-            else if (ph == 1) tr_load(tb, 1, g, dst);       // dh(1, t-1) from the previous tile's stage
-            else if (ph == 2) z_load(zb, 1, g, dst);        // zT(1, t)
-            else tr_load(tb, 0, g, dst);                    // dh(0, t)
-        };
-        auto run_phase = [&](auto phc) {
-            constexpr int ph = decltype(phc)::value;
-            // the sub-tile whose epilogue rides on this phase: (T = 3, tile t-1) | T = 0 | T = 1 | T = 2
-            if (ph == 0) bias_init(sb, 0); else if (ph == 2) bias_init(sb, 1);
-            // all transposed reads of dh(1, t-1) are issued when zT(1, t) starts, all row reads of zT(1, t) when dh(0, t) starts: move the bases on
-            if (ph == 2) {
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) tb[jt] += to_cur;
-            } else if (ph == 3) {
-#pragma unroll
-                for (int s = 0; s < NKS; ++s) zb[s] -= to_cur;      // to the next tile's stage = the previous tile's
-            }
-            u32x4 asg[NP] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-            if (BAYES && ph == 1) signed_a(1, swp, asg); else if (BAYES && ph == 3) signed_a(0, sw[0], asg);
-#pragma unroll
-            for (int g = 0; g < NG; g += 2) {
-                // two groups (different accumulators) issued product by product
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (ph == 0) z_mma1(0, g + j, k, fb[(g + j) % BG]);
-                        else if (ph == 1) d_mma1(1, g + j, k, asg, fb[(g + j) % BG]);
-                        else if (ph == 2) z_mma1(1, g + j, k, fb[(g + j) % BG]);
-                        else d_mma1(0, g + j, k, asg, fb[(g + j) % BG]);
-                    }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int gg = g + j;
-                    if (ph == 0) ride(3, gg, swp, rsp_prev, rsn_prev, rsrc_prev, ltp);
-                    else if (ph == 1) ride(0, gg, sw[0], rscale_pos, rscale_neg, dz_rsrc, lt);
-                    else if (ph == 2) {
-                        ride(1, gg, sw[0], rscale_pos, rscale_neg, dz_rsrc, lt);
-                        if (gg < NPIECE - 1) stage_piece(tn, buf ^ 1, gg);
-                        if (gg == 0) stage_piece(tn, buf ^ 1, NPIECE - 1);
-                    }
-                    else ride(2, gg, sw[1], rscale_pos, rscale_neg, dz_rsrc, lt);
-                    if (gg + BG < NG) load_for(ph, gg + BG, fb[gg % BG]);
-                    else if (ph < 3) load_for(ph + 1, gg + BG - NG, fb[gg % BG]);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // the reloads stay right behind the MFMAs that freed their registers (hipcc otherwise sinks them next to their uses)
-            }
-        };
-#pragma unroll
-        for (int k = 0; k < BG; ++k) load_for(0, k, fb[k]);
-        run_phase(std::integral_constant<int, 0>{});
-        run_phase(std::integral_constant<int, 1>{});
-        // dh(1, t-1) is through: every wave's reads of stage t-1 have returned (its MFMAs consumed them) - the stage may take tile t+1
-        __builtin_amdgcn_s_barrier();
-        run_phase(std::integral_constant<int, 2>{});
-        run_phase(std::integral_constant<int, 3>{});
-        lacc.tile = 0.6931471805599453f * fmaf(lt, rmask, ltp * rm_prev); lacc.end_tile();
-        swp = sw[1]; rm_prev = rmask; rsp_prev = rscale_pos; rsn_prev = rscale_neg; rsrc_prev = dz_rsrc;
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the DMA of tile t+1 is older than all but (at most) the 4 dzT stores of the last phase
-        __builtin_amdgcn_s_barrier();
-    }
-
-    if (t_beg < t_end) {
-        // ---- drain: epilogue of sub-tile 3 of the last tile, then dh(1, last)
-        float ltp = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { epilogue(3, r, swp, rsp_prev, rsn_prev, ltp); if (r & 1) split_pair_a(3, r - 1, rsrc_prev); }
-        u32x4 asg[NP] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-        if (BAYES) signed_a(1, swp, asg);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            u32x4 bf[NP];
-            tr_load(tb, 1, g, bf);      // (tb is in the last tile's stage)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) d_mma1(1, g, k, asg, bf);
-        }
-        lacc.tile = 0.6931471805599453f * ltp * rm_prev; lacc.end_tile();
-    }
-
-    float lsum = lacc.sum;
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (g4 == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int irow = i0 + 4 * g4 + r;
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        if (BAYES) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = INJ ? p.sinbits[(int64_t)irow * 4 + k] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)k);
-        }
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            float v = Y1[jt][r] * pp.u_dh;
-            if (BAYES) {
-                const float y2 = Y2[jt][r] * pp.u_dh;
-                v += ((w[jt >> 1] >> (16 * (jt & 1) + c)) & 1u) ? -y2 : y2;
-            }
-            p.slab[((int64_t)cg * p.Bpad + irow) * H + 16 * jt + c] = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_out_fwd_h3p (round 4): the fp16x3 training forward as PRODUCER / CONSUMER WAVE PAIRS, two waves per SIMD.
 // k_out_fwd_h3x's lone wave per SIMD issues everything it does in order - 192 MFMAs (8 issue cycles each), ~860 vector instructions, ~210 LDS reads, 17 DMA
 // pieces, 32 stores a tile: ~10.5 k cycles of issue against 6.1 k of matrix pipe, and the issue is what its 10.9 k cycles a tile are (without its MFMAs the
-// kernel takes 0.59 of its 0.71 ms, without its epilogue 0.57; re-ordering or trimming the vector work moves nothing).  Sixteen-row waves (k_out_fwd_h3y) double
+// kernel takes 0.59 of its 0.71 ms, without its epilogue 0.57; re-ordering or trimming the vector work moves nothing).  Sixteen-row waves (round 3's k_out_fwd_h3y, retired in round 5) double
 // the LDS traffic and the MFMA issue instead.  Here the 32 rows of a wave pair stay together and the WORK is split:
 //   wave A ("logit", waves 0-3):    zT(s) = planes(s) . hT on its h / h*s_in planes (128 registers), bias, s_out sign, leaky_relu, softplus into the loss (one
 //                                   v_log_f32 per four logits: the log of a product); tt = 1 + e^-l of its 32 rows x 32 experts, the leaky_relu branch in its sign,
@@ -2058,7 +1706,7 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
     do {                                                                                                                  \
         auto kf = inj ? k_out_fwd<H, BAYES, TR, DHF, BAYES> : k_out_fwd<H, BAYES, TR, DHF, false>;                        \
         if (phases & 2) {                                                                                                 \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            set_max_lds(reinterpret_cast<const void*>(kf), (int)lds); \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);                                                    \
         }                                                                                                                 \
         if (phases & 4) hipLaunchKernelGGL((k_out_special<H, BAYES, TR, DHF>), dim3(f.B), dim3(64), 0, st, s);            \
@@ -2118,7 +1766,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
             const bool dh = f.dh != nullptr;
             const size_t lds = (size_t)((!f.train && !inj) ? 3 : 2) * ((size_t)(f.bayes ? 2 : 1) * np * BN6 * 128 * 2 + 512);
 #define NTF_L6N(BY, TR, DHF, IJ, PR, NPV) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ, PR, NPV>;                               \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);       \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
 #define NTF_L6(BY, TR, DHF, IJ, PR) do { if (np == 2) NTF_L6N(BY, TR, DHF, IJ, PR, 2); else NTF_L6N(BY, TR, DHF, IJ, PR, 3); } while (0)
 #define NTF_L6B(BY, IJ) do { if (f.probs) NTF_L6(BY, false, false, IJ, true); else if (!f.train) NTF_L6(BY, false, false, IJ, false);  \
@@ -2126,12 +1774,12 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
             if (np == 2 && f.train && dh && f.wide) {    // the fp16x3 training step: 64-expert tiles (a.T counts them already)
                 const size_t ldsw = 2 * ((size_t)(f.bayes ? 2 : 1) * 2 * 64 * 128 * 2 + 512);
 #define NTF_LXA(BY, IJ, AB) do { auto kf = k_out_fwd_h3x<BY, IJ, AB>;                                                                    \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
+                set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsw);  \
                 hipLaunchKernelGGL(kf, dim3(grid), dim3(256), ldsw, st, a6); } while (0)
 #define NTF_LX(BY, IJ) NTF_LXA(BY, IJ, 0)
 #ifdef NTF_DIAG
                 static const int fwd_abl = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
-                if (f.wide != 4 && f.wide != 5 && fwd_abl == 9 && f.bayes && !inj) {
+                if (f.wide != 5 && fwd_abl == 9 && f.bayes && !inj) {
                     static unsigned long long* d_st = nullptr; static int n_launch = 0;
                     if (!d_st) hipMalloc(&d_st, (size_t)grid * 4 * 12 * 8);
                     a6.stamps = d_st;
@@ -2147,13 +1795,13 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                                 sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7], sum[7] / (grid * 4.0));
                     }
                 }
-                else if (f.wide != 4 && f.wide != 5 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
+                else if (f.wide != 5 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
                 else
 #endif
                 if (f.wide == 5) {      // producer / consumer wave pairs, two waves per SIMD (NTF_FWD_KERNEL=5)
                     const size_t ldsp = 3 * ((size_t)(f.bayes ? 2 : 1) * 2 * 32 * 128 * 2 + 512) + 2 * 16384;
 #define NTF_LP(BY, IJ) do { auto kf = k_out_fwd_h3p<BY, IJ>;                                                                    \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);  \
+                set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsp);  \
                 hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsp, st, a6); } while (0)
 #ifdef NTF_DIAG
                     static const int fwd_abl5 = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
@@ -2162,7 +1810,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                         if (!d_st) hipMalloc(&d_st, (size_t)grid * 8 * 10 * 8);
                         a6.stamps = d_st;
                         auto kf = k_out_fwd_h3p<true, false, true>;
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                        set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsp);
                         hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsp, st, a6);
                         if (++n_launch == 30) {
                             std::vector<unsigned long long> hst((size_t)grid * 80);
@@ -2185,13 +1833,6 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                     if (f.bayes) { if (inj) NTF_LP(true, true); else NTF_LP(true, false); } else NTF_LP(false, false);
 #undef NTF_LP
                 }
-                else if (f.wide == 4) {      // sixteen-row waves, two per SIMD (NTF_FWD_KERNEL=4: the A/B form)
-#define NTF_LY(BY, IJ) do { auto kf = k_out_fwd_h3y<BY, IJ>;                                                                    \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);  \
-                hipLaunchKernelGGL(kf, dim3(grid), dim3(512), ldsw, st, a6); } while (0)
-                    if (f.bayes) { if (inj) NTF_LY(true, true); else NTF_LY(true, false); } else NTF_LY(false, false);
-#undef NTF_LY
-                }
                 else { if (f.bayes) { if (inj) NTF_LX(true, true); else NTF_LX(true, false); } else NTF_LX(false, false); }
 #undef NTF_LX
 #undef NTF_LXA
@@ -2199,7 +1840,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #undef NTF_L6B
 #undef NTF_L6
 #undef NTF_L6N
-            const bool merged_fallback = np == 2 && f.train && dh && f.wide != 0 && f.wide != 4 && f.wide != 5;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
+            const bool merged_fallback = np == 2 && f.train && dh && f.wide != 0 && f.wide != 5;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
 #ifdef NTF_DIAG
             static const bool skip_fb = getenv("NTF_SKIP_FALLBACK") != nullptr;     // timing only: what the conditional exact-f32 launch behind k_out_fwd_h3p costs
 #else

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <type_traits>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace ntf {
 
@@ -21,6 +23,18 @@ constexpr int DW_WAVES = 8;               // waves per workgroup of the dW kerne
 constexpr int DW_TC = 32 * DW_WAVES;      // experts per workgroup of the dW kernel
 
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel that asks for more than 64 KiB of dynamic LDS: a property of (device, kernel) that never changes - set the first
+// time that kernel is launched with that size, not once per launch (round 4 paid the runtime call on every launch of every big kernel)
+inline void set_max_lds(const void* fn, int bytes) {
+    static std::mutex mu; static std::unordered_map<uint64_t, int> done;
+    int dev = 0; (void)hipGetDevice(&dev);
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)(dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[key] = bytes;
+}
 // Layout of dzT (d loss / d z of the output layer, the only dense [experts x batch] tensor of a step): tiles of DW_TC = 256 experts x 32 batch
 // rows, [expert tile][32-row K block][expert in tile][row in block].  The dW kernel consumes one K block of its expert tile per stage: one
 // contiguous 32 KiB piece, and a whole tile is a contiguous (Bpad / 32) * 32 KiB stream; the forward kernels' stores (32 rows = 128 B per expert)

@@ -29,7 +29,7 @@ struct DwArgs {
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
     // split-K (k_out_dw_p2 only): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
     // contiguous part of the K blocks into part[(split * 2 + matrix) * slab ..] (bias sums behind the slabs); k_out_dw_finish adds the parts and runs the epilogue
-    int ksplit; float* part; int64_t slab;
+    int ksplit; float* part; int64_t slab; int part_row0;   // part_row0: first expert of the launched tile range - the slabs hold that range only
     unsigned long long* stamps;   // diagnostics (k_out_dw_q<.., STAMP>, NTF_DW_STAMP_FILE)
     int ntile, stagger;   // k_out_dw_p2, unsplit: expert tiles of this launch (walked by persistent workgroups), start delay of every second workgroup (100 MHz ticks)
     // produce != 0 (fused Adam, Flipout, fp16x3 planes): the epilogue holds the UPDATED mu' / rho' of its elements - it also is the next step's operand producer:
@@ -526,26 +526,27 @@ __device__ __forceinline__ void dw_finish_vec(const DwArgs& p, int64_t idx0, con
 template <bool BAYES, bool ADAM>
 __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
     if (p.rflag && *p.rflag) return;           // an operand left the fp16 window: the exact-f32 dW kernel (unsplit, own epilogue) ran instead
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, idx0 = q * 4;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, il0 = q * 4, idx0 = il0 + (int64_t)p.part_row0 * 128;   // il0: offset inside the slabs (the launched tile range)
     const int64_t Mp = p.slab / 128;
-    if (q < p.M) {
+    if (q < Mp && q + p.part_row0 < p.M) {
         const float* pb = p.part + (int64_t)p.ksplit * 2 * p.slab;
         float b1 = 0.f, b2 = 0.f;
         for (int s = 0; s < p.ksplit; ++s) { b1 += pb[(int64_t)(s * 2) * Mp + q]; if (BAYES) b2 += pb[(int64_t)(s * 2 + 1) * Mp + q]; }
-        p.g_b[q] = b1; if (BAYES) p.g_bp[q] = b2;
+        p.g_b[q + p.part_row0] = b1; if (BAYES) p.g_bp[q + p.part_row0] = b2;
     }
     float nx_kl = 0.f, nx_amax = 0.f;
     const bool produce = BAYES && ADAM && p.produce;
-    if (idx0 >= (int64_t)p.M * 128 && !produce) return;
+    const bool live = il0 < p.slab && idx0 < (int64_t)p.M * 128;
+    if (!live && !produce) return;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (idx0 < (int64_t)p.M * 128) {
+    if (live) {
     for (int s = 0; s < p.ksplit; ++s) {
         float t[4];
-        ld_vec<4>(p.part + (int64_t)(s * 2) * p.slab + idx0, t);
+        ld_vec<4>(p.part + (int64_t)(s * 2) * p.slab + il0, t);
 #pragma unroll
         for (int k = 0; k < 4; ++k) s1[k] += t[k];
         if (BAYES) {
-            ld_vec<4>(p.part + (int64_t)(s * 2 + 1) * p.slab + idx0, t);
+            ld_vec<4>(p.part + (int64_t)(s * 2 + 1) * p.slab + il0, t);
 #pragma unroll
             for (int k = 0; k < 4; ++k) s2[k] += t[k];
         }
@@ -698,8 +699,8 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
     const float inv_a = 1.f / p.a_scale;
     if (half == 0 && c < p.M) {
         if (split) {
-            float* pb = p.part + (int64_t)p.ksplit * 2 * p.slab; const int64_t Mp = p.slab / 128;
-            pb[(int64_t)(ksi * 2) * Mp + c] = sum1 * inv_a; if (BAYES) pb[(int64_t)(ksi * 2 + 1) * Mp + c] = sum2 * inv_a;
+            float* pb = p.part + (int64_t)p.ksplit * 2 * p.slab; const int64_t Mp = p.slab / 128; const int cl = c - p.part_row0;
+            pb[(int64_t)(ksi * 2) * Mp + cl] = sum1 * inv_a; if (BAYES) pb[(int64_t)(ksi * 2 + 1) * Mp + cl] = sum2 * inv_a;
         } else { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
     }
 
@@ -712,8 +713,9 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) { s1[jt] = acc1[jt][r] * p.unscale; s2[jt] = acc2[jt][r] * p.unscale; }
         if (split) {   // raw partial sums of this K range; k_out_dw_finish adds the ranges and finalises
-            st_vec<NJT>(p.part + (int64_t)(ksi * 2) * p.slab + idx0, s1);
-            if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + idx0, s2);
+            const int64_t il0 = idx0 - (int64_t)p.part_row0 * H;
+            st_vec<NJT>(p.part + (int64_t)(ksi * 2) * p.slab + il0, s1);
+            if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + il0, s2);
         } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
     if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
@@ -975,21 +977,26 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     a.ntile = 0; a.stagger = 0; a.stamps = nullptr;
     const bool guard = f.bf16x6 && f.np == 2 && f.rflag != nullptr;
     a.sT = reinterpret_cast<const uint32_t*>(ws + w.sbitsT);
-    a.ksplit = 1; a.part = nullptr; a.slab = 0;
+    a.ksplit = 1; a.part = nullptr; a.slab = 0; a.part_row0 = 0;
+    if (f.fallback_only) {   // the exact-f32 kernel of a step whose split-product launches (several, e.g. the tail split of a whole step) were issued with no_fallback
+        if (!guard) return;
+        a.rmode = 2; a.a_scale = f.a_scale; a.unscale = 1.f / (f.a_scale * f.h_scale);
+        goto exact_f32;
+    }
     if (f.bf16x6 && f.np == 2 && f.dz_packed) {   // fp16x3 step, H = 128: the forward kernel left packed plane pairs in dzT
         a.a_scale = f.a_scale; a.unscale = 1.f / (f.a_scale * f.h_scale); a.rmode = guard ? 1 : 0;
-        const int ks = (f.ksplit > 1 && f.part && f.wg_count <= 0) ? std::min(f.ksplit, std::max(1, g.Bpad / 32)) : 1;
-        if (ks > 1) {   // few expert tiles: every tile's K range is split over ks workgroups, k_out_dw_finish adds the parts and runs the epilogue
-            a.ksplit = ks; a.part = f.part; a.slab = (int64_t)rup(f.M, DW_TC) * 128;
+        const int ks = (f.ksplit > 1 && f.part) ? std::min(f.ksplit, std::max(1, g.Bpad / 32)) : 1;
+        if (ks > 1) {   // few expert tiles (a narrow shard, or the tail of a whole layer): every tile's K range is split over ks workgroups, k_out_dw_finish adds the parts and runs the epilogue
+            a.ksplit = ks; a.part = f.part; a.slab = (int64_t)grid * DW_TC * 128; a.part_row0 = a.wg_begin * DW_TC;      // slabs over the launched tile range only
             const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0));
-            const int64_t nq = (int64_t)f.M * 128 / 4;
+            const int64_t nq = (int64_t)grid * DW_TC * 128 / 4;
 #define NTF_DWS(BY, AD) do { auto kf = k_out_dw_p2<BY, false>;                                                                  \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);      \
             hipLaunchKernelGGL(kf, dim3(grid * ks), dim3(64 * DW_WAVES), lds, st, a);                                          \
             hipLaunchKernelGGL((k_out_dw_finish<BY, AD>), dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, a); } while (0)
             if (f.bayes) { if (f.adam) NTF_DWS(true, true); else NTF_DWS(true, false); } else { if (f.adam) NTF_DWS(false, true); else NTF_DWS(false, false); }
 #undef NTF_DWS
-            if (!guard) return;
+            if (!guard || f.no_fallback) return;
             a.rmode = 2; a.ksplit = 1;
             goto exact_f32;
         }
@@ -1007,7 +1014,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
             a.stagger = (f.adam && qgrid > n_cu) ? (stagger_q >= 0 ? stagger_q : (nib * 140 + 4500) / 2) : 0;
             const size_t ldsq = 2 * ((size_t)QTC * 128 + 2 * 128 * 64 + (f.bayes ? 1024 : 0)) + 64;
 #define NTF_DWQ(BY, AD) do { auto kf = k_out_dw_q<BY, AD>;                                                                     \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq);     \
+            set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsq);     \
             hipLaunchKernelGGL(kf, dim3(qgrid), dim3(64 * QW), ldsq, st, a); } while (0)
 #ifdef NTF_DIAG
             static const char* stamp_file = getenv("NTF_DW_STAMP_FILE");   // -DNTF_DIAG builds: the 30th launch's per-wave stamps, raw (10 x u64 per wave), to this file (profiles/dw_stamps.py)
@@ -1019,7 +1026,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
                 if (!d_st) hipMalloc(&d_st, (size_t)qgrid * QW * 10 * 8);
                 a.stamps = d_st;
                 auto kf = k_out_dw_q<true, true, true>;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq);
+                set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsq);
                 hipLaunchKernelGGL(kf, dim3(qgrid), dim3(64 * QW), ldsq, st, a);
                 if (++n_launch == 30) {
                     std::vector<unsigned long long> hst((size_t)qgrid * QW * 10);
@@ -1029,13 +1036,13 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
             }
             else if (f.bayes) { if (f.adam) NTF_DWQ(true, true); else NTF_DWQ(true, false); } else { if (f.adam) NTF_DWQ(false, true); else NTF_DWQ(false, false); }
 #undef NTF_DWQ
-            if (!guard) return;
+            if (!guard || f.no_fallback) return;
             a.rmode = 2; a.wg_begin = wg256; a.ntile = 0; a.stagger = 0;   // the exact-f32 kernel behind it runs only when the range flag is raised
             goto exact_f32;
         }
         const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0)) + 64;
 #define NTF_DWP(BY, AD) do { auto kf = k_out_dw_p2<BY, AD>;                                                                    \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);          \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
         if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
 #undef NTF_DWP
@@ -1046,7 +1053,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
         a.rmode = guard ? 1 : 0;
         a.a_scale = np == 2 ? f.a_scale : 1.f; a.unscale = np == 2 ? 1.f / (f.a_scale * f.h_scale) : 1.f;
 #define NTF_DWB2(HH, BY, AD, NPV) do { auto kf = k_out_dw_b6<HH, BY, AD, NPV>; const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(BY ? 2 : 1) * NPV * HH * 64); \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+        set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);                                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
 #define NTF_DWB1(HH, BY, AD) do { if (np == 2) NTF_DWB2(HH, BY, AD, 2); else NTF_DWB2(HH, BY, AD, 3); } while (0)
 #define NTF_DWB(HH) do { if (f.bayes) { if (f.adam) NTF_DWB1(HH, true, true); else NTF_DWB1(HH, true, false); }                                            \
@@ -1063,7 +1070,7 @@ exact_f32:
 #define NTF_DW1(HH, BY) do { const bool fb = a.rmode == 2;                                                                                    \
         auto kf = fb ? (f.adam ? k_out_dw_fallback<HH, BY, true> : k_out_dw_fallback<HH, BY, false>) : (f.adam ? k_out_dw<HH, BY, true> : k_out_dw<HH, BY, false>);   \
         const size_t lds = 2 * (DW_TC * 32 * 4 + (BY ? 2 : 1) * 32 * 4 * HH);                                                                \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);                      \
         hipLaunchKernelGGL(kf, dim3(fb ? std::min(grid, 256) : grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
 #define NTF_DW(HH) do { if (f.bayes) NTF_DW1(HH, true); else NTF_DW1(HH, false); } while (0)
     if (f.H == 128) NTF_DW(128); else if (f.H == 64) NTF_DW(64); else NTF_DW(32);

@@ -66,11 +66,17 @@ def collective_timeout_s():
 
 class CollectiveTrace:
     """Every collective a step issues, by name, in a short ring: a bounded wait that expires says which one completed last and which one it is stuck behind
-    (a hang on xGMI would otherwise be a silent `torch.cuda.synchronize()` that never returns).  RCCL's `Work.wait()` only orders streams - the host runs ahead by
-    design - so the waits that can be bounded on the host are the gloo ones and the device synchronisation at the end of a phase (`sync`)."""
+    (a hang on xGMI would otherwise be a silent `torch.cuda.synchronize()` that never returns).
+    Under RCCL (`stream_ordered`) a `Work.wait()` WITHOUT a timeout only makes the current stream wait for the collective - the host runs ahead, which is what keeps
+    the launch-ahead and the overlap of a step; with `timeout=` set, torch blocks the CPU thread until the work completes (Work.wait's docstring; ADVICE r4: every
+    per-step wait then serialised host and device).  So the per-step waits of an RCCL run pass no timeout, and what is bounded on the host is the device synchronisation
+    at the end of a phase (`sync`, an event poll).  gloo works complete on the host: there `wait` takes the timeout."""
 
-    def __init__(self, who):
+    def __init__(self, who, stream_ordered=None):
         self.who, self.ring, self.issued = who, collections.deque(maxlen=256), 0
+        if stream_ordered is None:
+            stream_ordered = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+        self.stream_ordered = bool(stream_ordered)
 
     def add(self, label, work):
         self.issued += 1
@@ -83,6 +89,9 @@ class CollectiveTrace:
         return f"last completed collective: {done}; first incomplete: {stuck}; issued: {self.issued}"
 
     def wait(self, work):
+        if self.stream_ordered:
+            work.wait()          # orders the current stream behind the collective; the host does not block (a hang surfaces in `sync`, bounded)
+            return
         try:
             work.wait(timeout=datetime.timedelta(seconds=collective_timeout_s()))
         except TypeError:
@@ -130,7 +139,7 @@ class DataParallel:
         # gloo (the CPU tests) has no reduce-scatter: there it is an all-reduce of which this rank keeps its part - same result
         self._native_rs = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._pending = []   # parameter all-gathers of the previous step
-        self.trace = CollectiveTrace(f"DataParallel rank {self.rank}/{self.world}")
+        self.trace = CollectiveTrace(f"DataParallel rank {self.rank}/{self.world}", stream_ordered=self._native_rs)
         self._step_no = 0
         if self._grad.is_cuda and (self.world > 1 or self.force_allreduce) and hasattr(engine, "stream_handle"):
             assert engine.stream_handle is not None and torch.cuda.current_stream().cuda_stream == engine.stream_handle, \

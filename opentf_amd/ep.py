@@ -63,7 +63,7 @@ class ExpertParallel:
         # NTF_EP_FORCE_EXCHANGE=1: run the two-phase step and the all-reduce even at world_size 1 (exercises RCCL on a 1-GPU box)
         # two_phase: the two-phase step without any process group (bench.py --ep-emulate: one rank's compute on a 1-GPU box)
         self.force = bool(two_phase) or (dist.is_initialized() and os.environ.get("NTF_EP_FORCE_EXCHANGE", "0") == "1")
-        self.trace = CollectiveTrace(f"ExpertParallel rank {self.rank}/{self.world}")   # bounded waits that name the collective a hang sits behind (dp.py)
+        self.trace = CollectiveTrace(f"ExpertParallel rank {self.rank}/{self.world}", stream_ordered=dist.is_initialized() and dist.get_backend(group) == "nccl")   # bounded waits that name the collective a hang sits behind (dp.py)
         self._step_no = 0
         if self._dh is not None and self._dh.is_cuda and (self.world > 1 or self.force) and hasattr(engine, "stream_handle"):
             assert engine.stream_handle is not None and torch.cuda.current_stream().cuda_stream == engine.stream_handle, \

@@ -62,6 +62,7 @@ SYMBOLS = {
     "ntf_head_prefetch_hits": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_get_dlogits": (C.c_int, [_P, _P, _I64]),
     "ntf_get_negatives": (C.c_int, [_P, _P, _I64]),
+    "ntf_get_noise": (C.c_int, [_P, _U64, C.c_int32, C.c_int32, C.c_int32, _P, _I64]),
     "ntf_train_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_eval_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_backward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
@@ -316,6 +317,19 @@ class Engine:
         """the last step's sampled negatives [B, ns] (global expert ids)"""
         out = np.empty((int(B), int(self.ns)), dtype=np.int64)
         self._ck(lib().ntf_get_negatives(self._h, _ptr(out), out.size))
+        return out
+
+    def noise(self, step, B):
+        """the device generators' own Flipout draws of step index `step` (include/opentf_amd.h ntf_get_noise), as the oracle's per-layer list of
+        {eps_w [out, in], eps_b [out], s_in [B, in], s_out [B, out]}"""
+        out = []
+        for l in range(len(self.dims) - 1):
+            n_in, n_out = int(self.dims[l]), int(self.dims[l + 1])
+            d = {"eps_w": np.empty((n_out, n_in), np.float32), "eps_b": np.empty(n_out, np.float32),
+                 "s_in": np.empty((int(B), n_in), np.float32), "s_out": np.empty((int(B), n_out), np.float32)}
+            for kind, key in enumerate(("eps_w", "eps_b", "s_in", "s_out")):
+                self._ck(lib().ntf_get_noise(self._h, int(step), l, kind, int(B), _ptr(d[key]), d[key].size))
+            out.append(d)
         return out
 
     # ---- steps

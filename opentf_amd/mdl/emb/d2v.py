@@ -260,6 +260,8 @@ class D2v(T2v):
         rng = np.random.default_rng(zlib.crc32(" ".join(words).encode()))     # (gensim seeds with Python's salted hash of the words: not reproducible across processes)
         v = ((rng.random(m.vector_size, dtype=np.float32) * 2 - 1) / m.vector_size).astype(np.float32)
         epochs = int(getattr(m, "epochs", 10))
+        if getattr(m, "count", None) is None:      # a gensim file whose wv.expandos carries no 'count' (gensim_reader.read_doc2vec): no table to draw negatives from
+            raise RuntimeError("infer_vec: the loaded Doc2Vec file holds no vocabulary counts (wv.expandos['count']): the negative-sampling table cannot be rebuilt")
         cum = np.round(np.cumsum(np.asarray(m.count, np.float64) ** m.ns_exponent) / np.sum(np.asarray(m.count, np.float64) ** m.ns_exponent) * (2 ** 31 - 1))
         a0, a1 = float(getattr(m, "alpha", ALPHA)), float(m.min_alpha)
         alpha_delta = (a0 - a1) / max(epochs - 1, 1)                          # gensim's infer_vector: alpha falls to min_alpha over the epochs - 1 steps between passes

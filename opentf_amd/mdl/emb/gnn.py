@@ -8,8 +8,10 @@ What the caller (src/main.py:100-153) does and what it gets here:
       (gnn.py:84-116), `torch_geometric.nn.Node2Vec` (p = q = 1) trained by `_train_rw` (gnn.py:401-453: shuffled node batches, Adam,
       ReduceLROnPlateau on v_loss, EarlyStopping, `f{k}.pt` / `f{k}.e{e}.pt` checkpoints holding `embedding.weight`).  Here the walks,
       the skip-gram loss, its gradient and the dense Adam run in `opentf_amd/csrc/ntf_n2v.hip`; control flow, file names and
-      checkpoint keys are the reference's.  An existing `f{k}.pt` written by THIS plugin (it carries the node order its rows are sliced by) is loaded instead, as gnn.py:402-405 does; a file
-      without that marker - e.g. one the reference trained, whose node order follows its pickled graph - is refused rather than sliced wrong.
+      checkpoint keys are the reference's.  An existing `f{k}.pt` is loaded instead, as gnn.py:402-405 does: one written by THIS plugin carries the node order its rows are
+      sliced by; one the reference trained follows the node-store order of ITS pickled graph (`{structure}.{dup_edge}.graph.pkl` beside the splits directory,
+      gnn.py:21-23) - that file is read (opentf_amd/mdl/emb/pyg_reader.py: a restricted unpickler, no torch_geometric) and the rows are re-stacked; without the graph file
+      such a table is refused rather than sliced wrong.
   * `skill_vecs = t2v.get_dense_vecs(teamsvecs, vectype='skill')`                                                  (main.py:148)
       the mean-pool `(skill @ E_skill) / skill.sum(1)` (gnn.py:484-486) by the gather kernel, returned as the dense [N, d] matrix the
       caller stores in `teamsvecs['skill']` — AND `teamsvecs['skill_table'] = E_skill` is registered, so that the Fnn / Bnn plugin of this
@@ -80,14 +82,28 @@ def _barrier():
         dist.barrier()
 
 
+_WAIT_GROUP = None
+
+
+def _wait_group():
+    """a gloo group of its own with a week's timeout: the ranks other than 0 sit in a collective on it for as long as rank 0 trains a fold (up to cfg.e epochs) -
+    on the default group that wait is cut by the process group's watchdog after 10 (nccl) / 30 (gloo) minutes and the job is torn down"""
+    global _WAIT_GROUP
+    import datetime
+    import torch.distributed as dist
+    if _WAIT_GROUP is None:
+        _WAIT_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=7))       # (a collective itself: every rank reaches the first use together)
+    return _WAIT_GROUP
+
+
 def _sync_torch_rng():
-    """rank 0's torch CPU generator state on every rank (a collective: also orders the ranks behind rank 0's file writes)"""
+    """rank 0's torch CPU generator state on every rank (a collective: also orders the ranks behind rank 0's file writes); on the long-timeout group, see _wait_group"""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
     box = [torch.get_rng_state() if dist.get_rank() == 0 else None]
-    dist.broadcast_object_list(box, src=0)
+    dist.broadcast_object_list(box, src=0, group=_wait_group(), device=torch.device("cpu"))
     if dist.get_rank() != 0: torch.set_rng_state(box[0])
 
 
@@ -127,6 +143,7 @@ class Gnn(T2v):
         structure = cfg_get(cfg_get(self.cfg, "graph"), "structure")
         if structure[1] != "stm":
             raise NotImplementedError("only the skill-team-member ('stm') graph structure is built here")
+        self.graph_file = self.output + f"/../{structure[1]}.{cfg_get(cfg_get(self.cfg, 'graph'), 'dup_edge') or 'dup'}.graph.pkl"      # gnn.py:21
         self.output += self._dirname()
         os.makedirs(self.output, exist_ok=True)
         skill = teamsvecs.get("original_skill", teamsvecs["skill"]) if hasattr(teamsvecs, "get") else teamsvecs["skill"]
@@ -182,14 +199,28 @@ class Gnn(T2v):
         self._save(weight, foldidx, e, t_loss, v_loss, path)
 
     def _load_fold(self, path, off, n):
+        """gnn.py:402-405.  A table THIS plugin saved carries its node order ([skills | members | teams], stm_graph).  A table the reference trained follows the order in
+        which its pickled HeteroData holds the node stores (src/mdl/emb/gnn.py:29-47: the iteration order of a Python set, recorded only in `*.graph.pkl`): that file is
+        read and the row blocks are re-stacked; a foreign table without its graph file is refused - sliced by the wrong order it would train silently on the wrong rows."""
+        from . import pyg_reader
+        ref = pyg_reader.reference_table(path)      # restricted unpickler: the omegaconf cfg inside a reference checkpoint resolves to inert holders
         import torch
-        ck = torch.load(path, map_location="cpu", weights_only=False)
-        # only tables THIS plugin saved: the rows are sliced as [skills | members | teams] (stm_graph).  The reference orders its node stores by iterating a Python
-        # set (src/mdl/emb/gnn.py:29-47: the order depends on PYTHONHASHSEED and lives in its pickled graph) - such a file would be sliced wrong without an error
-        if ck.get("node_order") != NODE_ORDER or tuple(ck.get("node_offsets", ())) != (off["skill"], off["member"], off["team"], n):
-            raise RuntimeError(f"{path} was not written by opentf_amd.mdl.emb.gnn (no / another node order): remove it to retrain the table on the device")
-        log.info(f"Loading the model {path} ...")
-        return ck["model_state_dict"]["embedding.weight"].numpy()
+        try: ck = torch.load(path, map_location="cpu", weights_only=False)
+        except Exception: ck = {}                   # (a reference checkpoint: its cfg needs omegaconf)
+        if isinstance(ck, dict) and ck.get("node_order") == NODE_ORDER and tuple(ck.get("node_offsets", ())) == (off["skill"], off["member"], off["team"], n):
+            log.info(f"Loading the model {path} ...")
+            return ref["weight"]
+        graph = getattr(self, "graph_file", None)
+        if not graph or not os.path.exists(graph):
+            raise RuntimeError(f"{path} was not written by opentf_amd.mdl.emb.gnn and the graph file that holds its node order ({graph}) is missing: "
+                               "remove the table to retrain it on the device, or put the reference's *.graph.pkl back")
+        blocks = pyg_reader.node_blocks(graph)
+        weight, counts = pyg_reader.blocks_to_order(ref["weight"], blocks, NODE_ORDER.split("|"))
+        want = {"skill": off["member"] - off["skill"], "member": off["team"] - off["member"], "team": n - off["team"]}
+        if counts != want:
+            raise RuntimeError(f"{path}: the graph {graph} has {counts} nodes, teamsvecs has {want}")
+        log.info(f"Loading the model {path} (trained by the reference: rows re-stacked from {[t for t, _ in blocks]} of {os.path.basename(graph)}) ...")
+        return weight
 
     def _save(self, weight, foldidx, e, t_loss, v_loss, path):
         """keys and order of gnn.py:445,453, + the node order the rows are sliced by; written whole, then moved into place.  Called by the training rank only: no collective"""

@@ -194,3 +194,41 @@ def test_main_py_sequence_reaches_the_in_step_gather(tmp_path):
     wa = torch.load(f"{a.output}/f1.pt", weights_only=False)["model_state_dict"]
     wb = torch.load(f"{b.output}/f1.pt", weights_only=False)["model_state_dict"]
     assert all(torch.equal(wa[k], wb[k]) for k in wa)
+
+
+def test_a_table_the_reference_trained_is_consumed_through_its_graph_file(tmp_path):
+    """VERDICT r4 missing #3: src/mdl/emb/gnn.py:402-405 loads an existing `f{k}.pt` and skips training.  Here the files are the reference's OWN (committed for toy dblp:
+    tests/golden/ref_toy_dblp_n2v/): the table's rows follow the node-store order of its pickled graph - [member | team | skill] in this file - which the plugin reads
+    from `stm.add.graph.pkl` beside the splits directory (gnn.py:21).  `get_dense_vecs('skill')` (gnn.py:484-486) then equals the reference's expression evaluated with
+    scipy on the CORRECTLY sliced rows (the skill block: the LAST ten rows of the file, not the first) - bit for bit against the CSR-ordered f32 sum, 1e-6 against scipy."""
+    import shutil
+    from conftest import GOLDEN
+    from opentf_amd.mdl.emb.gnn import Gnn
+    from oracle import ntf_oracle as O
+    toy, tv, sp, n, S, M = _toy()
+    src = os.path.join(GOLDEN, "ref_toy_dblp_n2v")
+    splits_dir = tmp_path / "splits.f3.r0.85"; splits_dir.mkdir()
+    shutil.copy(f"{src}/stm.add.graph.pkl", tmp_path / "stm.add.graph.pkl")
+    cfg = Cfg(graph=Cfg(structure=[[["skill", "to", "team"], ["member", "to", "team"]], "stm"], dup_edge="add", pre=None),
+              n2v=Cfg(d=128, w=5, e=100, b=1000, lr=0.001, es=5, ns=5, spe=10, wl=5, wn=10, p=1.0, q=1.0))
+    g = golden("g14_n2v_dblp")
+    run = splits_dir / str(g["dirname"]); run.mkdir()
+    for k in range(3): shutil.copy(f"{src}/f0.pt", run / f"f{k}.pt")      # (the committed fold-0 table stands in for all three folds)
+    t2v = Gnn(str(splits_dir), "cuda:0", 0, cfg, "n2v")
+    t2v.learn(tv, sp)                                                      # loads, trains nothing
+    assert not any(f.startswith("f0.e") for f in os.listdir(run))
+    W = g["f0.embedding.weight"]                                           # the file's rows: [member 13 | team 31 | skill 10]
+    np.testing.assert_array_equal(t2v.model, np.concatenate([W[M + n:], W[:M], W[M:M + n]]))
+    tvc = dict(tv)
+    dense = t2v.get_dense_vecs(tvc, "skill")
+    sk = scipy.sparse.csr_matrix(tv["skill"])
+    table = W[M + n: M + n + S]
+    np.testing.assert_array_equal(dense, O.gather_meanpool_fast(sk.indptr.astype(np.int64), sk.indices.astype(np.int32), table))
+    ref = np.asarray((sk.astype(np.float32) @ table) / sk.sum(axis=1), dtype=np.float32)      # gnn.py:485
+    np.testing.assert_allclose(dense, ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(tvc["skill_table"], table)
+    # the first ten rows (what slicing by the plugin's own order would have taken) are MEMBER vectors: a different result
+    assert not np.allclose(dense, np.asarray((sk.astype(np.float32) @ W[:S]) / sk.sum(axis=1), dtype=np.float32), atol=1e-3)
+    # without the graph file the foreign table is refused
+    os.remove(tmp_path / "stm.add.graph.pkl")
+    with pytest.raises(RuntimeError, match="node order"): Gnn(str(splits_dir), "cuda:0", 0, cfg, "n2v").learn(tv, sp)

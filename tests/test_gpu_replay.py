@@ -1,0 +1,142 @@
+"""Native-draw replay: the kernels the benchmark times, step for step against the oracle (VERDICT r4 missing #2).
+
+Every other oracle comparison of a train step INJECTS the random tensors (eps, signs, negatives), i.e. runs the `INJ = true` template instantiations of the forward /
+dW kernels.  What `bench.py` and the plugin run is the other set: sign words hashed in place (`sign_word`), Flipout eps drawn by Philox inside the operand producer of
+the PREVIOUS step's dW epilogue (`nx_eps`) and drawn AGAIN by this step's epilogue for the rho gradient (`cur_eps`), the next batch's sampler / head issued beside the dW
+kernel, the lean epilogue, the tail split of the dW launch.  Here a non-injected engine at `set_seed(s, t)` runs three consecutive DEFAULT train steps over a staged
+order; the test then fetches the device's own draws for exactly those steps - `ntf_get_noise` (eps_w, eps_b, s_in, s_out per layer), `ntf_get_negatives` - feeds them to
+`oracle.train_step` (torch CPU autograd + restated Adam; reference lines src/mdl/fnn.py:122-140 with bayesian-torch's LinearFlipout.forward) and compares the loss of
+every step and every parameter (incl. every rho) after the third.  A forward eps that differed from the backward eps, a step counter keyed one off between `nx_eps` and
+`cur_eps`, a `sign_word()` that disagreed with the exported signs, a prefetched head run on the wrong batch's negatives: each shows here as a loss or parameter mismatch
+(statistical tests cannot see them: the data term of the rho gradient would average to zero)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(rng, N, S, D, M, mean_s, mean_m):
+    nnz = np.minimum(1 + rng.poisson(mean_s - 1, N), S)
+    s_ip = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int64)
+    s_ix = np.concatenate([np.sort(rng.choice(S, k, replace=False)) for k in nnz]).astype(np.int32)
+    table = rng.standard_normal((S, D)).astype(np.float32)
+    mn = 1 + rng.poisson(mean_m - 1, N)
+    m_ip = np.concatenate([[0], np.cumsum(mn)]).astype(np.int64)
+    m_ix = np.concatenate([np.sort(rng.choice(M, k, replace=False)) for k in mn]).astype(np.int32)
+    return (s_ip, s_ix), table, (m_ip, m_ix)
+
+
+def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4):
+    import torch
+    from oracle import ntf_oracle as O
+    from opentf_amd import libntf
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    N = (nsteps + 1) * B                                   # one batch more than is stepped: the last step still has a next batch to prefetch a head for
+    skill, table, member = _dataset(rng, N, S, D, M, mean_s, mean_m)
+    sd = O.bnn_init(D, [H], M)
+    order = rng.permutation(N).astype(np.int64)
+    Xall = torch.from_numpy(O.gather_meanpool_fast(skill[0], skill[1], table))
+
+    def labels(rows):
+        y = torch.zeros(len(rows), M)
+        for k, r in enumerate(rows): y[k, member[1][member[0][r]: member[0][r + 1]].astype(np.int64)] = 1.0
+        return y
+
+    def as_torch(noise):
+        return [{k: torch.from_numpy(v) for k, v in n.items()} for n in noise]
+
+    e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", tpw=10.0, tnw=1.0, lr=1e-3, seed=seed, fuse_adam=1)     # what bench.py and the plugin create: Adam in the dW epilogue, operands / head prefetched
+    e.set_skill_table(table); e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd)
+    e.stage_order(order)
+
+    # ---- logits of the first batch with the draws of step t0: the shipped inference kernel on native signs / eps against the oracle's forward on the exported tensors
+    rows0 = order[:B]
+    e.set_seed(seed, t0)
+    got = e.logits(rows0)                                   # consumes step index t0
+    noise0 = as_torch(e.noise(t0, B))
+    for n in noise0:
+        assert set(np.unique(n["s_in"].numpy())) <= {-1.0, 1.0} and set(np.unique(n["s_out"].numpy())) <= {-1.0, 1.0}
+        assert abs(float(n["eps_w"].mean())) < 0.02 and abs(float(n["eps_w"].std()) - 1.0) < 0.02
+    ref = O.model_forward(sd, Xall[rows0], noise0).detach().numpy()
+    zmax = float(np.abs(ref).max())
+    assert float(np.abs(got - ref).max()) <= 1e-4 * zmax, float(np.abs(got - ref).max()) / zmax
+    del got, ref
+
+    # ---- three default train steps from the same step index, then their replay through the oracle
+    e.set_seed(seed, t0)
+    pre0, hit0 = e.prefetched_steps(), e.head_prefetch_hits()
+    losses, negs, noises = [], [], []
+    for k in range(nsteps):
+        losses.append(e.step_staged(k * B, B, train=True, apply=True, want_loss=True))
+        negs.append(e.negatives(B).copy())
+        noises.append(e.noise(t0 + k, B))
+    # the pipelined default path really ran: steps 2.. started on operands the previous dW epilogue produced, with the head that ran beside that kernel
+    assert e.prefetched_steps() - pre0 >= nsteps - 1, (e.prefetched_steps(), pre0)
+    assert e.head_prefetch_hits() - hit0 >= nsteps - 1, (e.head_prefetch_hits(), hit0)
+    st = e.state_dict(); e.close()
+
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    opt = O.Adam(sd_ref, 1e-3)
+    for k in range(nsteps):
+        rows = order[k * B: (k + 1) * B]
+        y = labels(rows)
+        neg = torch.from_numpy(negs[k])
+        # the device's negatives are admissible draws of src/mdl/fnn.py:48-56 for THIS batch: distinct non-members
+        assert bool((y[torch.arange(len(rows)).unsqueeze(1), neg] == 0).all())
+        assert all(len(set(r.tolist())) == neg.shape[1] for r in neg)
+        ref_loss, _ = O.train_step(sd_ref, opt, Xall[rows], y, neg, 10.0, 1.0, as_torch(noises[k]))
+        assert abs(losses[k] - ref_loss) <= 2e-5 * abs(ref_loss), (k, losses[k], ref_loss)
+    worst = {}
+    for k in sd:
+        a, b = st[k], sd_ref[k].numpy()
+        bad = np.abs(a - b) > (1e-3 * np.abs(b) + 2e-5)
+        # Adam's first steps move a parameter by ~lr whatever |g| is: where |g| ~ 1e-8 a rounding difference in g flips the update's sign (up to 2 lr per step)
+        worst[k] = float(bad.mean())
+        assert worst[k] <= bad_frac, (k, worst[k])
+        assert float(np.abs(a - b).max()) <= 2e-3 * nsteps + 1e-6, (k, float(np.abs(a - b).max()))
+    return worst
+
+
+def test_three_default_steps_replayed_through_the_oracle_at_config2_size():
+    """[128, 128, 233 629], B = 1000 (dblp mt10.ts2 shapes): the benchmark's configuration"""
+    _replay(D=128, H=128, M=233_629, B=1000, S=4000, mean_s=8.57, mean_m=3.06, seed=21, t0=5)
+
+
+def test_three_default_steps_replayed_through_the_oracle_on_a_ragged_shape():
+    """a ragged last expert tile (M = 70 001: one expert into a 32-expert sub-tile, a 128-expert half-tile and a 256-expert tile) under a ragged row block (B = 129)"""
+    _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=22, t0=40)
+
+
+def test_negatives_of_a_step_survive_the_next_batchs_prefetched_sampler():
+    """with the head prefetch the next batch's sampler runs beside this step's dW kernel; `ntf_get_negatives` must still return THIS step's draws (they live in
+    one of two buffers by step parity).  The same seed and step index without the prefetch (NTF_HEAD_PREFETCH=0 at engine creation) draws the same negatives."""
+    import os
+    from oracle import ntf_oracle as O
+    from opentf_amd import libntf
+    import torch
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    D, H, M, B = 128, 128, 20_000, 256
+    skill, table, member = _dataset(rng, 4 * B, 700, D, M, 5.0, 2.5)
+    sd = O.bnn_init(D, [H], M)
+    order = rng.permutation(4 * B).astype(np.int64)
+    out = []
+    for pf in ("1", "0"):
+        old = os.environ.get("NTF_HEAD_PREFETCH")
+        os.environ["NTF_HEAD_PREFETCH"] = pf
+        try:
+            e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", seed=9, fuse_adam=1)
+        finally:
+            if old is None: os.environ.pop("NTF_HEAD_PREFETCH")
+            else: os.environ["NTF_HEAD_PREFETCH"] = old
+        e.set_skill_table(table); e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd); e.stage_order(order)
+        e.set_seed(9, 11)
+        got = []
+        for k in range(3):
+            e.step_staged(k * B, B, train=True, apply=True)
+            got.append(e.negatives(B).copy())
+        out.append((got, e.head_prefetch_hits())); e.close()
+    assert out[0][1] >= 2 and out[1][1] == 0
+    for a, b in zip(out[0][0], out[1][0]): np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(out[0][0][0], out[0][0][1])
