@@ -95,7 +95,7 @@ struct ntf_engine {
 #endif
     int lean = 1;                     // NTF_LEAN=0: the dW epilogue also writes the f32 copy of the next step's sigma * eps (round 3's 64 B per pair; A/B runs)
     int dw_kernel = 1;                // NTF_DW_KERNEL=0: k_out_dw_p2 (one 256-expert workgroup per CU) instead of k_out_dw_q (A/B runs)
-    int dw_tail = 0;                  // NTF_DW_TAIL=1|2|3 (experiment, measured slower - DESIGN.md section 4.0): the last partial round of half-tiles as split-K launches (see dw_launch_whole); 0: the whole layer in ONE k_out_dw_q launch
+    int dw_tail = 0;                  // NTF_DW_TAIL=1|2|3 (-DNTF_DIAG builds only; measured SLOWER): the last partial round of half-tiles as split-K launches (dw_launch_whole)
     int n_cu = 256;
     int dw_ksplit = 0;                // 0: automatic (few expert tiles -> split the dW kernel's K range), else forced (NTF_DW_KSPLIT)
     int32_t* d_range = nullptr;       // fp16x3 range guard (lives behind d_kl[0]): [0] raised for the current step, [1] steps that fell back to the f32 kernels
@@ -225,7 +225,9 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
     if (const char* dk = getenv("NTF_DW_KERNEL")) e->dw_kernel = atoi(dk);
     if (const char* ln = getenv("NTF_LEAN")) e->lean = atoi(ln);
+#ifdef NTF_DIAG
     if (const char* dt = getenv("NTF_DW_TAIL")) e->dw_tail = atoi(dt);
+#endif
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) e->n_cu = ncu; }
     if (const char* hp = getenv("NTF_HEAD_PREFETCH")) e->head_prefetch = atoi(hp);
 #ifdef NTF_DIAG
@@ -768,14 +770,17 @@ static void head_launch(ntf_engine* e, hipStream_t st, const StepCtx& c, char* w
     launch_head(st, a);
 }
 
-// The output layer's dW (+ Adam + next-step operands) of a whole step.  k_out_dw_q runs two 128-expert workgroups per CU, the epilogue of one beside the main loop of the
-// other; its grid of ceil(M / 128) half-tiles is dealt over 2 x CUs slots, and what bounds the launch is the LAST, partial round: at config 2, 1 826 half-tiles over 512
-// slots are 3.57 per slot - 290 slots run a fourth tile of ~130 us while 222 idle, and a CU left with one workgroup keeps neither HBM nor the matrix pipe busy (DESIGN.md
-// section 4.0: 0.46 ms of work in a 0.58-0.61 ms span).  Here the launch is cut at the last whole round: [0, rounds x slots) half-tiles go to k_out_dw_q - every slot the same
-// number of tiles, all ending together - and the rest (the tail) to the split-K form of k_out_dw_p2 (every tile's K range over `ks` workgroups, raw partial slabs in the
-// idle dense-logits buffer) followed by k_out_dw_finish, whose epilogue - the HBM-bound half of a tile - is one thread per four weights over the whole chip.
-// mode (NTF_DW_TAIL): 1 = tail behind the main launch on the same stream, 2 = in front of it, 3 = beside it on the chunk stream.
+// The output layer's dW (+ Adam + next-step operands) of a whole step: ONE k_out_dw_q launch.
+// Round 5 experiment, kept for -DNTF_DIAG builds (NTF_DW_TAIL=1|2|3) because VERDICT r4 asked for it and the numbers are the answer: the launch cut at its last whole
+// round of half-tiles (2 x CUs slots) - [0, rounds x slots) to k_out_dw_q, every slot the same number of tiles, the rest to the split-K form of k_out_dw_p2 +
+// k_out_dw_finish (behind it, in front of it, or beside it on another stream).  Measured at config 2 (profiles/r5_dw_tail.md): the 1 536-tile launch alone 0.528 ms (three
+// rounds cost 0.176 ms each; the fourth, partial round of the one-launch form costs only 0.07 ms: a CU left with one workgroup runs it faster), the tail 0.088 + 0.078 ms -
+// 0.66-0.68 ms against 0.60.  Every launch pays its own ramp (first main loops: HBM idle) and tail (last epilogues: matrix pipe idle), ~0.1 ms; cutting the launch adds one.
 static int dw_launch_whole(ntf_engine* e, const FusedDw& f) {
+#ifndef NTF_DIAG
+    launch_fused_out_dw(e->st, f);
+    return NTF_OK;
+#else
     const int slots = 2 * e->n_cu, total_q = (f.M + 127) / 128, full_q = total_q / slots * slots, tail_q = total_q - full_q;
     const bool can = e->dw_tail > 0 && f.kernel == 1 && f.dz_packed && f.adam && f.ksplit <= 1 && f.wg_count <= 0 && f.H == 128 && full_q > 0 && tail_q > 0 &&
                      tail_q * 10 <= slots * 8 && e->Zout != nullptr;
@@ -799,6 +804,7 @@ static int dw_launch_whole(ntf_engine* e, const FusedDw& f) {
     else { launch_fused_out_dw(e->st, fm); launch_fused_out_dw(e->st, ft); }
     if (f.rflag) { FusedDw fb = f; fb.fallback_only = 1; launch_fused_out_dw(e->st, fb); }
     return NTF_OK;
+#endif
 }
 
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B

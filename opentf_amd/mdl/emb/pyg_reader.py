@@ -25,6 +25,12 @@ class _Holder:
     def __init__(self, *a, **k): pass
     def __setstate__(self, st): self.__dict__.update(st if isinstance(st, dict) else {"_state": st})
     def __call__(self, *a, **k): return None
+    # a pickled dict / list / set SUBCLASS (e.g. a config object) is filled through these: kept as plain data
+    def __setitem__(self, k, v): self.__dict__.setdefault("_items", {})[k] = v
+    def append(self, v): self.__dict__.setdefault("_list", []).append(v)
+    def extend(self, vs): self.__dict__.setdefault("_list", []).extend(vs)
+    def add(self, v): self.__dict__.setdefault("_list", []).append(v)
+    def update(self, *a, **k): self.__dict__.setdefault("_items", {}).update(*a, **k)
 
 
 def _holder(module, name):
