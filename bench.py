@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--ep-emulate", type=int, default=0, metavar="G",
                     help="N = 1 only: run what ONE rank of G runs under --parallel ep (its 1/G of the experts, a global minibatch of G * --batch teams, two-phase "
                          "step, no exchange) - the per-rank compute time behind the scaling projection in DESIGN.md; not the headline")
+    ap.add_argument("--dp-emulate", type=int, default=0, metavar="G",
+                    help="N = 1 only: run what ONE rank of G runs under --parallel dp (north_star's form): its --batch rows of a global minibatch of G * --batch teams through the "
+                         "deferred, chunked dW path (no Adam in the dW epilogue, stand-alone operand producer), Adam on the 1/G shard it would own - WITHOUT the reduce-scatter / "
+                         "all-gather (their bytes are reported): the per-rank compute time of the data-parallel form; not the headline")
     return ap.parse_args()
 
 
@@ -92,7 +96,7 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
     # torch's intra-op pool does not scale to every hardware thread on these elementwise-heavy [B, M] ops: pick the
     # fastest of a few thread counts on a short probe, then time the sample with it (the count used is reported as `cores`)
     best, cores = None, 1
-    for n in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
+    for n in sorted({min(ncpu, t) for t in (16, 32, 64)}):      # (round 5: three candidates instead of six - 16-32 won on every box of the pool; the probe is host time in front of the JSON line)
         torch.set_num_threads(n)
         O.reference_shaped_step(sd, opt, ds["table"], s_ip, s_ix, rng.integers(0, ds["N"], 32), member, cfg)  # warm
         t0 = time.perf_counter()
@@ -126,7 +130,7 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
 def pmc_traffic(family, a, ds):
     """HBM bytes per launch of an output-layer kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
     as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
-    names = {"f32": ["r1_c_pmc_traffic_and_sq.json"], "bf16x6": ["r1_d_pmc_traffic_and_sq.json"]}.get(a.mfma, ["r4_pmc_traffic_and_sq.json", "r3_pmc_traffic_and_sq.json", "r2_pmc_traffic_and_sq.json"])
+    names = {"f32": ["r1_c_pmc_traffic_and_sq.json"], "bf16x6": ["r1_d_pmc_traffic_and_sq.json"]}.get(a.mfma, ["r5_pmc_traffic_and_sq.json", "r4_pmc_traffic_and_sq.json", "r3_pmc_traffic_and_sq.json", "r2_pmc_traffic_and_sq.json"])
     path = next((os.path.join(ROOT, "profiles", n) for n in names if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if not (path and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
             and a.input == "meanpool" and not a.rows and not a.experts):
@@ -146,6 +150,63 @@ def workload_label(a, ds, bayesian, multihot):
     return (f"{names.get(a.dataset, a.dataset)} N={ds['N']} S={ds['S']} M={ds['M']}; {a.model}{' (Flipout)' if bayesian else ''} on " +
             (f"multi-hot skill rows D={ds['S']}, " if multihot else f"mean-pooled skill table d={a.d}, ") +
             f"h=[{a.hidden}], b={a.batch}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3")
+
+
+def plugin_epoch(ds, a, device, headline_value):
+    """The DROP-IN timed, not only the engine (VERDICT r4 missing #4): one fold-epoch of `opentf_amd.mdl.bnn.Bnn.learn` - the replacement of src/mdl/fnn.py:78-170 that
+    src/main.py:155-193 calls - at the headline's shapes, from lil `teamsvecs` as the reference's pipeline hands them over: ingestion (lil -> CSR, uploads), the train phase
+    (loader order, staging, `b`-row steps), the validation phase and one checkpoint.  A sample of the teams (200 train + 100 validation batches): the rate does not
+    depend on the number of batches, and building 2 M-row lil matrices would only be host time."""
+    import shutil, tempfile, time as _t
+    import scipy.sparse
+    from opentf_amd import libntf
+    from opentf_amd.mdl.bnn import Bnn
+
+    class Cfg(dict):
+        def __getattr__(self, k):
+            if k.startswith("__"): raise AttributeError(k)
+            return self.get(k)
+
+    class NoWriter:
+        def __init__(self, log_dir=None): pass
+        def add_scalar(self, **k): pass
+        def close(self): pass
+
+    b = a.batch
+    n_tr, n_va = min(200 * b, ds["N"] * 2 // 3), min(100 * b, ds["N"] // 3)
+    n = n_tr + n_va
+    (s_ip, s_ix), (m_ip, m_ix) = ds["skill"], ds["member"]
+    t0 = _t.perf_counter()
+    skill = scipy.sparse.csr_matrix((np.ones(int(s_ip[n]), np.uint8), s_ix[: int(s_ip[n])], s_ip[: n + 1]), shape=(n, ds["S"])).tolil()
+    member = scipy.sparse.csr_matrix((np.ones(int(m_ip[n]), np.uint8), m_ix[: int(m_ip[n])], m_ip[: n + 1]), shape=(n, ds["M"])).tolil()
+    lil_s = _t.perf_counter() - t0
+    tv = {"skill": skill, "member": member, "loc": None, "skill_table": ds["table"]}
+    splits = {"test": np.empty(0, np.int64), "folds": {0: {"train": np.arange(n_tr), "valid": np.arange(n_tr, n)}}}
+    cfg = Cfg(b=b, e=1, ns=5, nsd=a.nsd, lr=0.001, es=5, h=[a.hidden], spe=None, l="bce", tpw=10, tnw=1, nmc=10)
+    out = tempfile.mkdtemp(prefix="ntf_plugin_epoch_")
+    spans = {}
+    from opentf_amd.mdl import fnn as fnn_mod
+    real = {"tr": libntf.Engine.train_epoch, "ev": libntf.Engine.eval_epoch, "new": Bnn._new_engine, "save": Bnn._save, "order": fnn_mod.index_order}
+
+    def timed(key, fn):
+        def w(*args, **kw):
+            t = _t.perf_counter(); r = fn(*args, **kw); spans[key] = spans.get(key, 0.0) + _t.perf_counter() - t
+            return r
+        return w
+    try:
+        libntf.Engine.train_epoch = timed("train", real["tr"]); libntf.Engine.eval_epoch = timed("valid", real["ev"])
+        Bnn._new_engine = timed("ingest", real["new"]); Bnn._save = timed("checkpoint", real["save"]); fnn_mod.index_order = timed("order", real["order"])
+        m = Bnn(out, f"cuda:{device}", 0, cfg); m.writer = NoWriter
+        t0 = _t.perf_counter(); m.learn(tv, splits, None); wall = _t.perf_counter() - t0
+    finally:
+        libntf.Engine.train_epoch, libntf.Engine.eval_epoch, Bnn._new_engine, Bnn._save, fnn_mod.index_order = real["tr"], real["ev"], real["new"], real["save"], real["order"]
+        shutil.rmtree(out, ignore_errors=True)
+    tr_rate = n_tr / (spans["train"] + spans.get("order", 0.0))      # the loader's order (both phases') counted with the train phase
+    return {"workload": f"opentf_amd.mdl.bnn.Bnn.learn, one fold x one epoch: {n_tr} train + {n_va} validation teams of the headline's dataset as lil teamsvecs + skill_table, b={b}, nsd={a.nsd}",
+            "learn_wall_s": wall, "ingest_s": spans.get("ingest"), "train_phase_s": spans["train"], "loader_order_s": spans.get("order"), "valid_phase_s": spans.get("valid"), "checkpoint_s": spans.get("checkpoint"),
+            "value_is": "train teams / (train_phase_s + loader_order_s): torch's DataLoader draws for the shuffled order, ntf_stage_order, ceil(n / b) ntf_step_staged calls, the epoch-loss read-back",
+            "value": tr_rate, "unit": "teams/s", "ms_per_step": spans["train"] / (-(-n_tr // b)) * 1e3, "ratio_to_headline": tr_rate / headline_value if headline_value else None,
+            "lil_build_s_not_plugin_time": lil_s}
 
 
 class LegSkipped(RuntimeError):
@@ -250,8 +311,9 @@ def main():
     multihot = a.input == "multihot"
     dims = [ds["S"] if multihot else a.d, a.hidden, ds["M"]]
     cfg = {"ns": 5, "nsd": a.nsd, "tpw": 10.0, "tnw": 1.0, "lr": 1e-3}
-    if a.ep_emulate and world > 1: raise SystemExit("--ep-emulate is a single-GPU measurement")
-    G = a.ep_emulate if a.ep_emulate else world
+    if (a.ep_emulate or a.dp_emulate) and world > 1: raise SystemExit("--ep-emulate / --dp-emulate are single-GPU measurements")
+    if a.ep_emulate and a.dp_emulate: raise SystemExit("--ep-emulate and --dp-emulate exclude each other")
+    G = a.ep_emulate or a.dp_emulate or world
     shardable = (not a.no_fused) and can_shard(dims, G)
     if a.parallel == "ep" and (G > 1 or a.force_dist) and not shardable:
         raise SystemExit(f"--parallel ep: {dims} does not shard over {G} GPUs (needs h[-1] in 32/64/128 and >= {G} tiles of 256 experts)")
@@ -265,20 +327,20 @@ def main():
         agree (extra legs at N > 1): called with this rank's "my engine is built" - the leg goes on only when every rank's is (no rank enters a collective alone)"""
         ep = par == "ep"
         shard = expert_shards(model_dims[-1], G)[0 if a.ep_emulate else rank] if ep else None
-        eB = gB if ep else -(-gB // (1 if a.ep_emulate else world))     # rows one engine steps: under ep every rank steps the whole global minibatch
+        eB = gB if ep else -(-gB // (a.dp_emulate or (1 if a.ep_emulate else world)))     # rows one engine steps: under ep every rank steps the whole global minibatch
         with torch.cuda.stream(stream):
             e, built_err = None, None
             try:
                 if leg: inject_failure(leg, "build")
                 e = libntf.Engine(model_dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=eB, ns=5, nsd=a.nsd, tpw=10.0, tnw=1.0,
                                   lr=1e-3, seed=1234, device=local, stream=stream.cuda_stream, fused=not a.no_fused,
-                                  fuse_adam=a.fuse_adam if (world == 1 or ep) else 0, mfma=a.mfma, expert_shard=shard, ep_world=G if ep else 1)
+                                  fuse_adam=a.fuse_adam if ((world == 1 and not a.dp_emulate) or ep) else 0, mfma=a.mfma, expert_shard=shard, ep_world=G if ep else 1)
                 if not multihot: e.set_skill_table(data["table"])
                 e.set_skill_csr(data["skill"]); e.set_member(data["member"])
                 e.load_state_dict(params)
                 if a.nsd == "unigram":   # expert frequency over the training rows (src/mdl/fnn.py:97)
                     e.set_unigram(np.bincount(data["member"][1], minlength=data["M"]) / data["N"])
-                dp = ExpertParallel(e, two_phase=bool(a.ep_emulate)) if ep else DataParallel(e)
+                dp = ExpertParallel(e, two_phase=bool(a.ep_emulate)) if ep else DataParallel(e, emulate_world=a.dp_emulate)
             except Exception as ex:
                 if agree is None: raise
                 built_err = f"{type(ex).__name__}: {ex}"
@@ -326,11 +388,13 @@ def main():
             dt = float(np.median(regions))
             res = {"par": par, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "times": times, "breakdown": bd, "k3": k3,
                    "Mloc": (shard[1] - shard[0]) if ep else model_dims[-1], "engine": e,
-                   "rccl_payload_bytes_per_step": (4 * gB * a.hidden) if ep else (8 * n_params if world > 1 else 0)}
+                   "rccl_payload_bytes_per_step": (4 * gB * a.hidden) if ep else (8 * n_params if world > 1 else 0),
+                   "emulated_bytes": getattr(dp, "emulated_bytes", None)}
             return res
 
     # ---- the headline mode
     if world > 1 and a.parallel == "auto": head_par = "dp"                 # north_star: data parallel, gradients exchanged over RCCL
+    elif a.dp_emulate: head_par = "dp"
     elif (G > 1 or a.force_dist) and a.parallel != "dp" and shardable: head_par = "ep"
     else: head_par = "dp"
     gB = a.batch * G                                       # weak scaling: B teams per GPU
@@ -345,7 +409,7 @@ def main():
 
     gather = None
     with torch.cuda.stream(stream):
-        if (a.gather_bench or (world == 1 and not a.no_gather_bench and not a.ep_emulate)) and rank == 0 and not multihot:
+        if (a.gather_bench or (world == 1 and not a.no_gather_bench and not a.ep_emulate and not a.dp_emulate)) and rank == 0 and not multihot:
             e.kernel_times(enable=True)
             n = ds["N"]
             e.gather_meanpool(n=n, to_host=False); e.kernel_times(enable=True)
@@ -356,7 +420,7 @@ def main():
             t = ms / calls * 1e-3
             gather = {"bound": "hbm", "achieved_algorithmic": bytes_per_team * n / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "bytes_per_team": bytes_per_team, "teams": n, "ms": ms / calls}
-            pm = next((os.path.join(ROOT, "profiles", f) for f in ("r4_pmc_gather.json", "r3_pmc_gather.json", "r2_pmc_gather.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+            pm = next((os.path.join(ROOT, "profiles", f) for f in ("r5_pmc_gather.json", "r4_pmc_gather.json", "r3_pmc_gather.json", "r2_pmc_gather.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
             if pm:
                 for name, v in json.load(open(pm))["kernels"].items():
                     if "k_gather_pool" in name and "hbm_bytes" in v: gather["traffic"] = v["hbm_bytes"]; gather["traffic_source"] = "profiles/" + os.path.basename(pm)
@@ -416,6 +480,21 @@ def main():
             out["value"] = a.steps * a.batch / dt; out["n_gpus"] = 1
             out["ep_emulation"] = {"G": G, "experts": [int(shard[0]), int(shard[1])], "rows_per_step": gB, "ms_per_step": dt / a.steps * 1e3,
                                    "projected_teams_per_s_at_G_gpus": a.steps * gB / dt, "note": "projection = G * this rank's rate; excludes the 4*B*h[-1]-byte all-reduce per step"}
+        if a.dp_emulate:
+            eb = head["emulated_bytes"] or {}; ns_ = max(eb.get("steps", 0), 1)
+            rs, ar, ag = eb.get("reduce_scatter_in", 0) / ns_, eb.get("all_reduce", 0) / ns_, eb.get("all_gather_out", 0) / ns_
+            fam = head["breakdown"] or {}
+            out["metric"] += f" [one rank of {G} under --parallel dp, emulated on one GPU without the exchange]"
+            out["value"] = a.steps * a.batch / dt; out["n_gpus"] = 1
+            # ring reduce-scatter / all-gather over G ranks: every rank sends and receives (G - 1) / G of the buffer; the remainders and the replicated segments are all-reduced (2 (G - 1) / G)
+            wire = ((rs + ag) * (G - 1) / G + ar * 2 * (G - 1) / G)
+            out["dp_emulation"] = {"G": G, "rows_per_rank": a.batch, "global_batch": gB, "ms_per_step": dt / a.steps * 1e3, "projected_teams_per_s_at_G_gpus_before_exchange": a.steps * gB / dt,
+                                   "collective_bytes_per_step": {"reduce_scatter_input": rs, "all_gather_output": ag, "all_reduce": ar, "sent_and_received_per_rank": wire},
+                                   "exchange_ms_at_350_GBps_per_rank": wire / 350e9 * 1e3,
+                                   "overlap_window_ms": {"reduce_scatter_behind": "the dW chunks that follow a chunk's own kernel", "dw_chunks_total": fam.get("out_fused_dw_adam"),
+                                                         "all_gather_behind": "nothing in round 4 (every gather waited for before the head): see DESIGN.md 6.5 for the chunked forward"},
+                                   "note": "compute only: deferred dW in expert chunks (fuse_adam = 0), stand-alone operand producer, Adam on the 1/G shard; the collectives' bytes are tallied, not moved. "
+                                           "350 GB/s = what a rank receives over its seven xGMI links in a ring (MI355X_MICROARCH.md: 7 x ~153 GB/s point to point, a ring uses one link each way)"}
         sys.stdout.flush(); sys.stderr.flush()
         print(json.dumps(out), file=real_stdout, flush=True)
 
@@ -468,7 +547,7 @@ def main():
         if watchdog is not None: watchdog.cancel()
 
     exact_f32 = None
-    if world == 1 and a.mfma == "default" and not a.no_f32_line and not a.no_fused and not a.ep_emulate:
+    if world == 1 and a.mfma == "default" and not a.no_f32_line and not a.no_fused and not a.ep_emulate and not a.dp_emulate:
         # the same workload on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32, a bit-exact f32 fma chain): quoted beside the fp16x3 headline
         with torch.cuda.stream(stream):
             e2 = libntf.Engine(dims, bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=a.batch, ns=5, nsd=a.nsd,
@@ -485,16 +564,17 @@ def main():
             e2.close()
 
     extra_configs = None
-    if world == 1 and rank == 0 and a.dataset == "dblp" and not (a.rows or a.experts or a.no_extra_configs or a.ep_emulate or a.no_fused or multihot) and a.mfma == "default":
+    if world == 1 and rank == 0 and a.dataset == "dblp" and not (a.rows or a.experts or a.no_extra_configs or a.ep_emulate or a.dp_emulate or a.no_fused or multihot) and a.mfma == "default":
         # the "full DBLP" reading of north_star: the UNFILTERED matrix's expert count (M = 5 022 955, 1.29 G parameters, ~75 GB resident); 10 steps.  The step does not
         # depend on the number of teams, so a 200 000-team sample of the 4 877 383 is staged.
         saved = (a.dataset,)
         dsf = make_dataset("dblp_full", d=a.d, seed=0, n_rows=200_000)
         dimsf = [a.d, a.hidden, dsf["M"]]
         a.dataset = "dblp_full"
-        r = run_mode("dp", a.batch, 10, 2, reps_allowed=False, breakdown=False, data=dsf, model_dims=dimsf, params=init_params(dimsf, bayesian, 0)); r["engine"].close()
+        r = run_mode("dp", a.batch, 10, 2, reps_allowed=False, breakdown=True, data=dsf, model_dims=dimsf, params=init_params(dimsf, bayesian, 0)); r["engine"].close()
+        rf, rfo = rooflines(r["times"], a, bayesian, r["eB"], a.hidden, r["Mloc"], dsf, False)      # (traffic: no PMC pass at this size - null)
         extra_configs = {"dblp_full": {"workload": workload_label(a, dsf, bayesian, False), "steps": 10, "ms_per_step": r["dt"] / 10 * 1e3, "value": 10 * a.batch / r["dt"], "unit": "teams/s",
-                                       "mean_loss": r["mean_loss"]}}
+                                       "mean_loss": r["mean_loss"], "roofline": rf, "roofline_other": rfo}}
         a.dataset = saved[0]
         # the team-vector producer in front of this path when the input is doc2vec (src/mdl/emb/d2v.py:69-84): one PV-DM pass (d = 128, window 5, 5 negatives, gensim's
         # defaults as the reference leaves them) over THIS dataset's teams as documents.  The reference's own log of that stage on dblp mt10.ts2
@@ -513,6 +593,12 @@ def main():
                                       "reference_log": {"file": "output/dblp/dblp.v12.json.mt10.ts2/prep.d2v.skill.log", "s_per_pass": 276.4, "raw_words_per_s": 19073021 / 276.4, "workers": 224, "words": 19073021}}
 
     leg_failed = any("error" in v and not str(v["error"]).startswith("skipped before any collective") for v in extra_modes.values() if isinstance(v, dict))
+    if extra_configs is not None and not os.environ.get("NTF_BENCH_NO_PLUGIN_EPOCH"):
+        try:
+            extra_configs["plugin_epoch"] = plugin_epoch(ds, a, local, a.steps * gB / head["dt"])
+        except Exception as ex:      # (the headline must not depend on it)
+            extra_configs["plugin_epoch"] = {"error": f"{type(ex).__name__}: {ex}"}
+
     if rank != 0:
         if world > 1 and not any("error" in v for v in extra_modes.values() if isinstance(v, dict)): dist.destroy_process_group()
         sys.stdout.flush(); sys.stderr.flush()
@@ -520,7 +606,7 @@ def main():
         return
     if a.force_dist and world == 1: dist.destroy_process_group()
     state["exact_f32"], state["extra_configs"] = exact_f32, extra_configs
-    if world == 1 and not a.no_cpu_baseline and not multihot and not a.ep_emulate:   # the CPU leg times the headline (mean-pool) configuration only
+    if world == 1 and not a.no_cpu_baseline and not multihot and not a.ep_emulate and not a.dp_emulate:   # the CPU leg times the headline (mean-pool) configuration only
         state["cpu_baseline"] = cpu_baseline(ds, dims, bayesian, cfg)
     clean = not any("error" in v for v in extra_modes.values() if isinstance(v, dict))
     if world > 1 and clean: dist.destroy_process_group()   # before the JSON line: RCCL prints its version banner when the group goes away

@@ -42,6 +42,7 @@ struct StepCtx {
                              // GLOBAL row position, so a sharded step draws exactly what the single-process step would draw
     bool defer_dw = false;   // leave the output layer's dW kernel to ntf_dw_chunk (data-parallel overlap with the all-reduce)
     bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
+    int ub = 0;              // nsd = unigram_b: which of the two staged per-batch alias tables is THIS batch's
     int part = 0;            // expert-sharded step: 1 = forward + loss (leaves the partial d(hidden)), 2 = the output layer's backward, 3 = the hidden layers' backward (0 = whole step)
 };
 
@@ -81,8 +82,9 @@ struct ntf_engine {
     // negatives, the transposed s_out words, gather -> hidden layer -> h images (k_head) - is issued for the NEXT batch of the staged order on the side stream, behind
     // this step's hidden-layer backward (+ its Adam), i.e. beside the dW kernel, into the other workspace set.  hp = what was issued; a step takes it when it is that batch.
     int head_prefetch = 1;            // NTF_HEAD_PREFETCH=0: everything at the head of its own step (A/B runs)
-    struct { bool valid = false; uint64_t step = 0; const int64_t* rows = nullptr; int B = 0; } hp;
+    struct { bool valid = false; uint64_t step = 0; const int64_t* rows = nullptr; int B = 0; int ub = -1; } hp;      // ub: the unigram_b table slot staged for that batch (-1: none)
     const int64_t* hp_next_rows = nullptr; int hp_next_B = 0;     // the batch that follows in the staged order (ntf_step_staged), 0: unknown
+    const int64_t* hp_next_host = nullptr;                        // ... and its row ids on the host (unigram_b: the per-batch table is built from them)
     bool hidden_adam_done = false;    // this step's Adam of the hidden layers already ran on the side stream (in front of the prefetched head)
     int64_t hp_used = 0;
     float* gemm_slab = nullptr;       // split-K partial sums of the generic GEMM
@@ -114,6 +116,9 @@ struct ntf_engine {
     bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
     // the dW + Adam kernel of a train step also produced the NEXT step's output-layer operands (FusedDw.produce): valid for step pre_step as long as nothing else
     // touched the output layer's parameters or the operand buffers (Wp, split planes); d_kl[2] / d_range[4] hold that step's KL and range flag until it starts
+    int merge_bias = 1;               // NTF_MERGE_BIAS=0: the next step's output-bias operand as k_head's bias workgroups in a launch of their own behind the bias Adam, as in round 4 (A/B runs)
+    uint64_t spec_step = 0;           // step + 1 whose special-entry list (k_special_list) is in that step's workspace set
+    int fix_in_fwd = 1;               // NTF_FIX_IN_FWD=0: the sparse fix-up between the forward and the dW kernel on the main stream, as in round 4 (A/B runs)
     int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
@@ -123,11 +128,11 @@ struct ntf_engine {
     bool pend_valid = false; FusedDw pend; NormalSpec pend_eps_b; float pend_klw_b = 0.f; int pend_chunks = 0;
     // unigram_b staging (sparse per-batch alias table)
     std::vector<int32_t> ub_entries; void* ub_host[2] = {nullptr, nullptr}; void* ub_dev[2] = {nullptr, nullptr}; hipEvent_t ub_ev[2] = {nullptr, nullptr};
-    bool ub_used[2] = {false, false}; size_t ub_cap = 0; int ub_slot = 0, ub_nsup = 0; double ub_total = 0;
+    bool ub_used[2] = {false, false}; size_t ub_cap = 0; int ub_slot = 0; int ub_nsup[2] = {0, 0}; double ub_total[2] = {0, 0};
     uint16_t* pl_mu = nullptr; uint16_t* pl_wp = nullptr;   // bf16 split planes of the output layer's mu / Wp (bf16x6 arithmetic)
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
-    hipStream_t st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the hidden layers' backward runs beside the output layer's dW kernel
+    hipStream_t st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fix = nullptr;   // the hidden layers' backward runs beside the output layer's dW kernel
     hipStream_t st4 = nullptr; hipEvent_t ev_aux = nullptr;   // auxiliary stream: what the step's head needs from the row ids / sign keys only (sampler, s_out words)
     int side_bwd = 1;                 // NTF_SIDE_BWD=0 keeps the whole step on one stream (A/B runs)
     // expert-sharded output layer (ntf_config.expert_lo ..): this engine owns experts [ep_lo, ep_lo + dims[L]) of Mg
@@ -235,6 +240,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
 #endif
     if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
+    if (const char* fx = getenv("NTF_FIX_IN_FWD")) e->fix_in_fwd = atoi(fx);
+    if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
@@ -302,7 +309,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     if (e->st) hipStreamSynchronize(e->st);
     // the side streams are drained and destroyed BEFORE any buffer their kernels may still touch is freed
     if (e->st4) { hipStreamSynchronize(e->st4); hipStreamDestroy(e->st4); hipEventDestroy(e->ev_aux); }
-    if (e->st3) { hipStreamSynchronize(e->st3); hipStreamDestroy(e->st3); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); }
+    if (e->st3) { hipStreamSynchronize(e->st3); hipStreamDestroy(e->st3); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_fix); }
     if (e->st2) { hipStreamSynchronize(e->st2); hipStreamDestroy(e->st2); hipEventDestroy(e->ev_chunk); hipEventDestroy(e->ev_side); }
     dfree(e->P); dfree(e->G); dfree(e->M1); dfree(e->V2);
     dfree(e->m_indptr); dfree(e->m_indices); dfree(e->s_indptr); dfree(e->s_indices); dfree(e->table); dfree(e->Xall);
@@ -679,11 +686,11 @@ static int sample_negatives(ntf_engine* e, const StepCtx& c) {
         launch_ns_alias(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, e->al_prob, e->al_alias, e->al_weight, e->al_total,
                         k0, k1, (uint32_t)c.step, c.row0, e->d_neg_set[c.step & 1]);
     } else if (e->cfg.nsd == NTF_NSD_UNIGRAM_B) {
-        const char* d = static_cast<const char*>(e->ub_dev[e->ub_slot]);
-        const size_t n = (size_t)e->ub_nsup;
+        const char* d = static_cast<const char*>(e->ub_dev[c.ub]);
+        const size_t n = (size_t)e->ub_nsup[c.ub];
         launch_ns_alias_sparse(e->st, c.rows_dev, c.B, M, e->cfg.ns, e->m_indptr, e->m_indices, reinterpret_cast<const int32_t*>(d),
                                reinterpret_cast<const float*>(d + n * 8), reinterpret_cast<const int32_t*>(d + n * 4),
-                               reinterpret_cast<const float*>(d + n * 12), e->ub_nsup, e->ub_total, k0, k1, (uint32_t)c.step, c.row0, e->d_neg_set[c.step & 1]);
+                               reinterpret_cast<const float*>(d + n * 12), e->ub_nsup[c.ub], e->ub_total[c.ub], k0, k1, (uint32_t)c.step, c.row0, e->d_neg_set[c.step & 1]);
     } else FAIL(e, NTF_EINVAL, "bad nsd");
     return NTF_OK;
 }
@@ -691,7 +698,8 @@ static int sample_negatives(ntf_engine* e, const StepCtx& c) {
 // unigram_b (src/mdl/fnn.py:74-76): per-batch expert frequency y.sum(0)/B over the GLOBAL batch rows (host ids).  The table has
 // support only on the batch's experts: sort + count them on the host (a few thousand entries), alias over the support, staged through
 // two pinned buffers so that the host may prepare step t+1 while step t runs.
-static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int n) {
+// `slot`: which of the two staging sets; `st`: the stream the upload is ordered on (the one whose sampler reads the table)
+static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int n, int slot, hipStream_t st) {
     std::vector<int32_t>& ent = e->ub_entries;
     ent.clear();
     for (int i = 0; i < n; ++i) {
@@ -710,10 +718,11 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
     std::vector<float> prob; std::vector<int32_t> alias; double total = 0;
     build_alias(w.data(), nsup, prob, alias, total);
     // staging: [cols | alias | prob | weight] per slot
-    const int slot = e->ub_slot ^= 1;
     const size_t need = (size_t)std::max(nsup, 1) * 16;
     if (e->ub_cap < need) {
         HIPCHK(e, hipStreamSynchronize(e->st));
+        if (e->st4) HIPCHK(e, hipStreamSynchronize(e->st4));      // (a prefetched sampler may still read the old buffers)
+        e->hp.ub = -1;
         for (int k = 0; k < 2; ++k) { if (e->ub_host[k]) hipHostFree(e->ub_host[k]); if (e->ub_dev[k]) hipFree(e->ub_dev[k]); e->ub_host[k] = nullptr; e->ub_dev[k] = nullptr; }
         e->ub_cap = need * 2;
         for (int k = 0; k < 2; ++k) { HIPCHK(e, hipHostMalloc(&e->ub_host[k], e->ub_cap, hipHostMallocDefault)); HIPCHK(e, hipMalloc(&e->ub_dev[k], e->ub_cap)); }
@@ -727,15 +736,23 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
     std::memcpy(h + (size_t)nsup * 8, prob.data(), (size_t)nsup * 4);
     float* hw = reinterpret_cast<float*>(h + (size_t)nsup * 12);
     for (int k = 0; k < nsup; ++k) hw[k] = (float)w[k];
-    HIPCHK(e, hipMemcpyAsync(e->ub_dev[slot], h, (size_t)nsup * 16, hipMemcpyHostToDevice, e->st));
-    HIPCHK(e, hipEventRecord(e->ub_ev[slot], e->st));
-    e->ub_used[slot] = true; e->ub_nsup = nsup; e->ub_total = total;
+    HIPCHK(e, hipMemcpyAsync(e->ub_dev[slot], h, (size_t)nsup * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipEventRecord(e->ub_ev[slot], st));
+    e->ub_used[slot] = true; e->ub_nsup[slot] = nsup; e->ub_total[slot] = total;
     return NTF_OK;
+}
+
+// the batch's special entries (positives + its negatives, sampled or injected) listed for the forward kernel's own fix-up (FusedOut.fix_in_fwd), behind the sampler
+static void list_specials(ntf_engine* e, const StepCtx& c, char* ws) {
+    if (!fused_ok(e) || !c.train || !e->fix_in_fwd || e->layers[e->L - 1].in != 128) return;
+    const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg_set[c.step & 1] : nullptr;
+    launch_fused_special_list(e->st, c.B, e->layers[e->L - 1].in, e->cfg.dims[e->L], ws, c.rows_dev, e->m_indptr, e->m_indices, neg, e->cfg.ns);
+    e->spec_step = c.step + 1;      // (+ 1: 0 = never)
 }
 
 struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } };   // launches and timing scopes follow e->st
 static int side_stream(ntf_engine* e) {
-    if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
+    if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fix, hipEventDisableTiming)); }
     if (!e->st4) { HIPCHK(e, hipStreamCreateWithFlags(&e->st4, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_aux, hipEventDisableTiming)); }
     return NTF_OK;
 }
@@ -817,7 +834,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
     int nslots;
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg_set[c.step & 1] : nullptr;
-    bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false;
+    bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false, early_fork = false;
     // one kernel for gather -> hidden layer -> operand images (ntf_head.hip): one hidden layer of 128 units over a dense / mean-pooled input, native generators, fp16x3 planes
     const bool use_head = fused && e->head && e->L == 2 && c.part <= 1 && !c.inj && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
                           (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
@@ -871,6 +888,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], e->P + lo.off[NTF_P_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                    1.0 / out_nb, e->d_kl); }
         if ((r = sample_negatives(e, c))) return r;
+        list_specials(e, c, e->fws);
         if (c.train && e->cfg.bayesian && e->cfg.mfma != NTF_MFMA_F32 && mfma_np(e) == 2 && lo.in == 128 && e->pl_mu != nullptr) {
             const SignSpec so = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out), si = sign_spec(e, c, e->L - 1, T_S_IN, lo.in);
             if (so.inj == nullptr && si.inj == nullptr) {   // (injected signs: the words are transposed from the packed image k_sign_bits writes on the main stream)
@@ -883,7 +901,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         aux = true;
     }
     if (!use_head && (r = make_input(e, c))) return r;
-    if (!aux && !hp_hit && (r = sample_negatives(e, c))) return r;
+    if (!aux && !hp_hit) { if ((r = sample_negatives(e, c))) return r; list_specials(e, c, e->fws); }
     if (fused) {
         if (!use_head && (r = forward_layers(e, c, false, true))) return r;
         FusedOut f;
@@ -934,6 +952,12 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
+        // Round 5: in a whole train step on the wave-pair forward kernel the sparse fix-up (23 us) leaves the main stream.  The forward kernel handles the special entries
+        // itself (FusedOut.fix_in_fwd: dz, loss terms, d(hidden) terms, from the list k_special_list made beside the sampler), so the dW kernel follows it directly; what is
+        // left of the fix-up - sums of the partials - runs on the side stream in front of the loss reduction and the hidden layers' backward.  The two no-op launches
+        // of a range fallback stay on the main stream (launched on the side stream beside the dW kernel, the exact-f32 forward kernel's 132 KB workgroups would find no
+        // CU until that kernel drains, and stall everything queued behind them - measured: +0.06 ms); only the exact-f32 dW launch waits for the side stream (ev_fix).
+        early_fork = side && c.train && f.dh != nullptr && f.bf16x6 && f.np == 2 && lo.in == 128 && (e->fwd_kernel < 0 || e->fwd_kernel == 5) && e->fix_in_fwd && e->spec_step == c.step + 1;
         if (use_pre && e->lean) {
             // this step's operands came from the previous step's dW epilogue, which (lean) left no f32 copy of sigma * eps: only a step that falls back to the exact-f32 kernels
             // reads one, and makes it here - a capped grid that exits at once unless the range flag is raised (behind the head: k_head may still raise it)
@@ -941,6 +965,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, nullptr,
                                    nullptr, nullptr, nullptr, 0, 3, 1.f, nullptr, range_ptr(e));
         }
+        f.fix_in_fwd = early_fork ? 1 : 0;
 #ifdef NTF_DIAG
         if (e->cosched > 0 && c.train) {
             f.ncg_limit = e->cosched;
@@ -958,6 +983,15 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         } else
 #endif
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
+        if (early_fork) {
+            if ((r = side_stream(e))) return r;
+            HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
+            HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
+            StreamRestore guard{e, e->st};
+            e->st = e->st3;
+            { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
+            HIPCHK(e, hipEventRecord(e->ev_fix, e->st3));
+        } else
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
         nslots = fused_loss_slots(M);
     } else {
@@ -984,8 +1018,10 @@ backward:
     StreamRestore restore{e, e->st};
     if (side) {
         if ((r = side_stream(e))) return r;
-        HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
-        HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
+        if (!early_fork) {      // (early_fork: the side stream left the main stream behind the forward kernel already)
+            HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
+            HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
+        }
         if (loss_side) {
             e->st = e->st3;
             { Scope t(e, F_LOSS);
@@ -1078,6 +1114,14 @@ backward:
 #ifdef NTF_DIAG
             if (e->cosched > 0) { e->cosched_dw = f; e->cosched_have = true; goto dw_done; }      // (this step's dW rides beside the NEXT step's forward kernel: timing only)
 #endif
+            if (early_fork && f.rflag) {
+                // the exact-f32 dW launch of a range fallback reads what the side stream's exact-f32 forward + sparse fix-up leave: it alone waits for them
+                FusedDw fq = f; fq.no_fallback = 1;
+                { Scope t(e, F_OUT_FUSED_DW); if ((r = dw_launch_whole(e, fq))) return r; }
+                HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_fix, 0));
+                FusedDw fb = f; fb.fallback_only = 1;
+                launch_fused_out_dw(e->st, fb);
+            } else
             { Scope t(e, F_OUT_FUSED_DW); if ((r = dw_launch_whole(e, f))) return r; }
         dw_done:;
         } else {
@@ -1141,7 +1185,7 @@ backward:
         const bool can_head = e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
                               (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
         if (e->head_prefetch && can_head && c.fuse_adam && e->cfg.fuse_adam == 1 && e->pre_valid && e->pre_step == c.step + 1 && e->hp_next_B > 0 && !c.inj &&
-            e->cfg.nsd != NTF_NSD_UNIGRAM_B && c.global_B == B && !e->ep) {
+            (e->cfg.nsd != NTF_NSD_UNIGRAM_B || e->hp_next_host != nullptr) && c.global_B == B && !e->ep) {
             e->st = e->st3;
             {   // Adam of the hidden layers: [0, first float of the output layer) - apply_adam then leaves that range alone
                 Scope t(e, F_ADAM);
@@ -1156,13 +1200,21 @@ backward:
             // dW kernel the 30 MB of k_sign_words_T take ~90 us instead of 19 - behind the hidden backward on ONE stream the chain ended 14 us before the dW kernel)
             e->st = e->st4;
             HIPCHK(e, hipStreamWaitEvent(e->st4, e->ev_fork, 0));
+            int ub_next = -1;
+            if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0) {
+                // round 5: the next batch's per-batch alias table (host sort + count of its ~3 k experts, 16 B per slot through the other pinned buffer) is staged here too,
+                // uploaded on the auxiliary stream in front of its sampler
+                ub_next = c.ub ^ 1; n.ub = ub_next;
+                if ((r = set_batch_unigram(e, e->hp_next_host, n.B, ub_next, e->st4))) return r;
+            }
             if ((r = sample_negatives(e, n))) return r;
+            list_specials(e, n, ws_next);
             const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
             { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1); }
             HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
             e->st = e->st3;
             { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr); }
-            e->hp.valid = true; e->hp.step = n.step; e->hp.rows = n.rows_dev; e->hp.B = n.B;
+            e->hp.valid = true; e->hp.step = n.step; e->hp.rows = n.rows_dev; e->hp.B = n.B; e->hp.ub = ub_next;
         }
         HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
         e->st = restore.main;
@@ -1192,12 +1244,15 @@ static int apply_adam(ntf_engine* e) {
         rg[2 * n] = w1; rg[2 * n + 1] = w1 + lo.out; fin[n] = e->fin_pend ? 1 : 0; ++n; rg[2 * n] = r1; rg[2 * n + 1] = r1 + lo.out; fin[n] = e->fin_pend ? 2 : 0; ++n; }
     else { rg[2 * n] = w1; rg[2 * n + 1] = w1 + lo.out; ++n; }
     const bool rotate = e->cfg.bayesian && e->pre_valid && e->pre_step == e->step;   // this step's dW epilogue left the next step's KL / range flag behind the current ones
+    // the prefetched head of the next step left out what depends on the output layer's biases, which this launch updates: their Flipout operand sigma_b eps_b and KL of
+    // the next step.  Round 5: produced by this very launch from the updated values it holds (round 4: k_head's bias workgroups alone in a launch behind it)
+    const bool bias_nx = e->hp.valid && rotate && e->hp.step == e->step && e->merge_bias;
+    NormalSpec nx_eps;
+    if (bias_nx) { StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B; nx_eps = normal_spec(e, nx, e->L - 1, T_EPS_B); }
     launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2), fin, &e->fin_eps, e->fin_klw,
-                       rotate ? e->d_kl : nullptr);
+                       rotate ? e->d_kl : nullptr, bias_nx ? e->bp[e->L - 1] : nullptr, bias_nx ? &nx_eps : nullptr, 1.0 / (double)e->Mg);
     e->pre_rotated = rotate; e->fin_pend = false;
-    if (e->hp.valid && rotate && e->hp.step == e->step) {
-        // the prefetched head left out what depends on the output layer's biases, which this launch has just updated: their Flipout operand sigma_b eps_b and KL of the
-        // next step - k_head's bias workgroups alone, into the scalars the rotation above has just moved into place
+    if (e->hp.valid && rotate && e->hp.step == e->step && !bias_nx) {
         StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B; nx.rows_dev = e->hp.rows; nx.train = true;
         Scope t2(e, F_FLIPOUT_OPERAND);
         head_launch(e, e->st, nx, e->fws_set[nx.step & 1], false, e->d_kl, true, nullptr, false);
@@ -1250,7 +1305,10 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     if ((r = stage_all_inj(e, c))) return r;
     if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && !(inj && inj->neg_idx)) {
         if (!global_rows_host) FAIL(e, NTF_EINVAL, "unigram_b needs the batch rows on the host");
-        if ((r = set_batch_unigram(e, global_rows_host, n_global))) return r;
+        // the previous step's head prefetch may have staged THIS batch's table already (beside its dW kernel): the table is a function of the batch's rows alone
+        if (e->hp.valid && e->hp.ub >= 0 && e->hp.step == c.step && e->hp.rows == c.rows_dev && e->hp.B == B && global_B == B) c.ub = e->hp.ub;
+        else { c.ub = (e->ub_slot ^= 1); if ((r = set_batch_unigram(e, global_rows_host, n_global, c.ub, e->st))) return r; }
+        e->ub_slot = c.ub;
     }
     if ((r = run_step(e, c, true))) return r;
     e->last_B = B; e->last_global_B = global_B; e->neg_step = c.step;
@@ -1303,10 +1361,11 @@ extern "C" int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t
         FAIL(e, NTF_EINVAL, "step_staged: shard / batch outside the staged order");
     // the batch that follows in the staged order (an epoch walks it front to back, src/mdl/fnn.py:118): what the head prefetch works for
     const int64_t no = offset + B; const int nB = (int)std::min<int64_t>(B, n - no);
-    if (train && apply && global_offset == offset && global_B == B && nB >= 1) { e->hp_next_rows = e->d_order + no; e->hp_next_B = nB; } else e->hp_next_B = 0;
+    if (train && apply && global_offset == offset && global_B == B && nB >= 1) { e->hp_next_rows = e->d_order + no; e->hp_next_B = nB; e->hp_next_host = e->h_order.data() + no; }
+    else { e->hp_next_B = 0; e->hp_next_host = nullptr; }
     const int rc = step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, train != 0, apply != 0, true, e->h_order.data() + global_offset, global_B,
                                false, (uint32_t)(offset - global_offset));
-    e->hp_next_B = 0;
+    e->hp_next_B = 0; e->hp_next_host = nullptr;
     return rc;
 }
 
@@ -1379,7 +1438,7 @@ extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int3
         if (e->ep_open == 2 && e->ep_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));   // an abandoned step's side-stream kernel still orders before this one
         e->pend_valid = false; e->ep_open = 0;
         if ((r = stage_rows(e, e->d_order + offset, B, true, &c.rows_dev))) return r;
-        if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0 && (r = set_batch_unigram(e, e->h_order.data() + offset, B))) return r;
+        if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0) { c.ub = (e->ub_slot ^= 1); if ((r = set_batch_unigram(e, e->h_order.data() + offset, B, c.ub, e->st))) return r; }
         if ((r = run_step(e, c, true))) return r;
         e->last_B = B; e->last_global_B = B; e->neg_step = c.step;
         e->ep_ctx = c; e->ep_open = 1;

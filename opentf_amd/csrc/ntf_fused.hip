@@ -362,7 +362,93 @@ struct SpecialArgs {
     const int* rflag;
     int c_lo;              // expert shard: labels and negatives name GLOBAL expert ids, this launch owns [c_lo, c_lo + M)
     const uint16_t* wp_pl; float wp_inv_scale;   // fp16x3 step: sigma * eps as the two fp16 planes the forward kernel multiplied with (k_out_fwd_h3x's tile layout); null: the f32 copy `wp`
+    int dz_in_fwd;         // the forward kernel (k_out_fwd_h3p) handled the special entries itself (dz in dzT, loss terms in its loss partials, d(hidden) terms in its slabs): this
+                           // kernel only sums the partials and reads no weight - unless *rflag is raised (then the f32 kernels ran and the entries are this kernel's)
 };
+
+// The special entries of a team - its positives (member CSR row) and its sampled negatives - as the sparse fix-up visits them: entry `sidx` of the row's
+// npos + ns candidates -> (global expert id or -1, label).  A negative that names a member of the team, or repeats an earlier negative, is dropped (src/mdl/fnn.py:48-56
+// draws distinct non-members; injected indices may not be).
+__device__ __forceinline__ int special_candidate(const int32_t* __restrict__ m_indices, const int64_t* __restrict__ neg, int64_t pb, int npos, int ns, int i, int sidx, float& y) {
+    y = 0.f;
+    if (sidx < npos) { y = 1.f; return m_indices[pb + sidx]; }
+    const int qn = sidx - npos;
+    if (!neg || qn >= ns) return -1;
+    int c = (int)neg[(int64_t)i * ns + qn];
+    for (int k = 0; k < npos; ++k) if (m_indices[pb + k] == c) c = -1;
+    for (int k = 0; k < qn; ++k) if (c >= 0 && (int)neg[(int64_t)i * ns + k] == c) c = -1;
+    return c;
+}
+// The logit z (pre-activation) of one (team i, expert cc) entry by a QUARTER-WAVE of 16 lanes, lane l holding hidden units 8 l .. 8 l + 7 of h (hr) and of h * s_in (hsr):
+// z = h . mu[cc] + mu_b[cc] + s_out(i, cc) ((h s_in) . Wp[cc] + bp[cc]).  ONE function for the sparse fix-up kernel and for the forward kernel's own fix-up of dzT, with
+// the products as explicit fmaf chains, so that both give the same bits.  mu_r / wp_r: the weights it multiplied with (the caller's dh terms); so: the entry's s_out sign.
+template <bool BAYES>
+__device__ __forceinline__ float special_z16(const float* __restrict__ mu, const float* __restrict__ mu_b, const float* __restrict__ wp, const float* __restrict__ bp,
+                                             const uint16_t* __restrict__ wp_pl, float wp_inv_scale, bool wp_planes, const uint32_t* __restrict__ sbits, int nCB,
+                                             uint32_t so_k0, uint32_t so_k1, int so_inj, int i, int cc, int l, const float (&hr)[8], const float (&hsr)[8],
+                                             float (&mu_r)[8], float (&wp_r)[8], float& so) {
+    constexpr int H = 128;
+    float d1 = 0.f, d2 = 0.f;
+    {
+        const float4 a = *reinterpret_cast<const float4*>(mu + (int64_t)cc * H + 8 * l), b = *reinterpret_cast<const float4*>(mu + (int64_t)cc * H + 8 * l + 4);
+        mu_r[0] = a.x; mu_r[1] = a.y; mu_r[2] = a.z; mu_r[3] = a.w; mu_r[4] = b.x; mu_r[5] = b.y; mu_r[6] = b.z; mu_r[7] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { d1 = fmaf(hr[k], mu_r[k], d1); wp_r[k] = 0.f; }
+    if (BAYES) {
+        if (wp_planes) {   // the lane's 8 consecutive hidden units of row cc: 16 bytes from each plane; value = (hi + lo) / scale - exactly what the dense pass multiplied with
+            typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+            const uint16_t* r0 = wp_pl + ((int64_t)(cc >> 5) * 64 + (cc & 31)) * H + 8 * l;     // [tile of 32 rows][plane][row][H]
+            const h8_t hi = *reinterpret_cast<const h8_t*>(r0), lo = *reinterpret_cast<const h8_t*>(r0 + 32 * H);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wp_r[k] = ((float)hi[k] + (float)lo[k]) * wp_inv_scale;
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(wp + (int64_t)cc * H + 8 * l), b = *reinterpret_cast<const float4*>(wp + (int64_t)cc * H + 8 * l + 4);
+            wp_r[0] = a.x; wp_r[1] = a.y; wp_r[2] = a.z; wp_r[3] = a.w; wp_r[4] = b.x; wp_r[5] = b.y; wp_r[6] = b.z; wp_r[7] = b.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d2 = fmaf(hsr[k], wp_r[k], d2);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) d1 += __shfl_xor(d1, o, 64);
+    float z = d1 + mu_b[cc];
+    so = 1.f;
+    if (BAYES) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) d2 += __shfl_xor(d2, o, 64);
+        const uint32_t sw_ = so_inj ? sbits[(int64_t)i * nCB + (cc >> 5)] : sign_word(so_k0, so_k1, (uint32_t)i, (uint32_t)(cc >> 5));
+        so = ((sw_ >> (cc & 31)) & 1u) ? -1.f : 1.f;
+        z += (d2 + bp[cc]) * so;
+    }
+    return z;
+}
+// d loss / d z of a special entry (label y, positive-weight tpw) as the fp16x3 step stores it: the two fp16 planes of dz * scale packed in a dword
+__device__ __forceinline__ float special_dz(float z, float y, float tpw, float inv_B, float& sp, float& sg, float& dact) {
+    bce_terms(z, sp, sg, dact);
+    return tpw * (sg - y) * dact * inv_B;
+}
+__device__ __forceinline__ uint32_t special_dz_packed(float dzt, float scale) { uint32_t pq[3]; split_pair_np<2>(dzt, 0.f, scale, pq); return (pq[0] & 0xFFFFu) | (pq[1] << 16); }
+
+// The special entries of every row of a batch, listed once per step: spec[row][SPEC_W] = global expert id | label << 30 of candidate k (-1: a dropped duplicate, or
+// k >= the row's candidates), spec[Bpad * SPEC_W + row] = the row's candidates npos + ns.  A quarter-wave per row, a lane per candidate.  Runs right behind the sampler
+// (auxiliary stream: for a prefetched head that is beside the previous step's dW kernel); read by the fix-up at the end of k_out_fwd_h3p.
+__global__ __launch_bounds__(256) void k_special_list(const int64_t* __restrict__ rows, int B, int Bpad, const int64_t* __restrict__ m_indptr, const int32_t* __restrict__ m_indices,
+                                                      const int64_t* __restrict__ neg, int ns, int* __restrict__ spec) {
+    const int i = (int)(blockIdx.x * 16 + (threadIdx.x >> 4)), l16 = threadIdx.x & 15;
+    if (i >= B) return;
+    const int64_t team = rows[i];
+    const int64_t pb = m_indptr[team];
+    const int npos = (int)(m_indptr[team + 1] - pb), total = npos + (neg ? ns : 0);
+    float y = 0.f;
+    const int c = l16 < total ? special_candidate(m_indices, neg, pb, npos, ns, i, l16, y) : -1;
+    spec[(int64_t)i * SPEC_W + l16] = c < 0 ? -1 : (c | (y != 0.f ? (1 << 30) : 0));
+    if (l16 == 0) spec[(int64_t)Bpad * SPEC_W + i] = total;
+}
+void launch_fused_special_list(hipStream_t st, int B, int H, int M, void* ws_, const int64_t* rows, const int64_t* m_indptr, const int32_t* m_indices, const int64_t* neg, int ns) {
+    const Geom g = geom(B, M);
+    const WsLayout w = ws_layout(B, H, M);
+    hipLaunchKernelGGL(k_special_list, dim3((B + 15) / 16), dim3(256), 0, st, rows, B, g.Bpad, m_indptr, m_indices, neg, ns, reinterpret_cast<int*>(static_cast<char*>(ws_) + w.spec));
+}
 
 // One wave per team.  H = 128: the wave works as FOUR quarter-waves of 16 lanes x 8 consecutive hidden units, each quarter taking every fourth
 // special entry (and every fourth dh slab): the ~8 dependent dot-product / reduction / BCE chains of a team run four abreast, rows are read as
@@ -403,55 +489,43 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
     const int64_t team = p.rows[i];
     const int64_t pb = p.m_indptr[team];
     const int npos = (int)(p.m_indptr[team + 1] - pb);
-    const int total = npos + (p.neg ? p.ns : 0);
+    // (dz_in_fwd: the wave-pair forward kernel has visited the entries; the dW + Adam kernel may be rewriting the weights beside this kernel by now)
+    const int total = (p.dz_in_fwd && !(p.rflag && *p.rflag)) ? 0 : npos + (p.neg ? p.ns : 0);
     float fix = 0.f;
     for (int s0 = 0; s0 < total; s0 += NQ) {       // wave-uniform trip count: the shuffles below need every lane
         const int sidx = s0 + q;
-        int c = -1; float y = 0.f;
-        if (sidx < npos) { c = p.m_indices[pb + sidx]; y = 1.f; }
-        else if (sidx < total) {
-            const int qn = sidx - npos;
-            c = (int)p.neg[(int64_t)i * p.ns + qn];
-            for (int k = 0; k < npos; ++k) if (p.m_indices[pb + k] == c) c = -1;
-            for (int k = 0; k < qn; ++k) if (c >= 0 && (int)p.neg[(int64_t)i * p.ns + k] == c) c = -1;
-        }
+        float y = 0.f;
+        int c = sidx < total ? special_candidate(p.m_indices, p.neg, pb, npos, p.ns, i, sidx, y) : -1;
         if (c >= 0) c -= p.c_lo;                   // global -> this shard's expert index (entries of other shards fall outside [0, M))
         const bool live = c >= 0 && c < p.M;
         const int cc = live ? c : 0;
-        float mu_r[NV], wp_r[NV], d1 = 0.f, d2 = 0.f;
+        float mu_r[NV], wp_r[NV], z, so = 1.f;
+        if constexpr (QUAD) z = special_z16<BAYES>(p.mu, p.mu_b, p.wp, p.bp, p.wp_pl, p.wp_inv_scale, wp_planes, p.sbits, p.nCB, p.so_k0, p.so_k1, p.so_inj, i, cc, l, hr, hsr, mu_r, wp_r, so);
+        else {
+            float d1 = 0.f, d2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int j = hidx(k);
-            mu_r[k] = 0.f; wp_r[k] = 0.f;
-            if (j < H) { mu_r[k] = p.mu[(int64_t)cc * H + j]; d1 += hr[k] * mu_r[k]; if (BAYES && !wp_planes) { wp_r[k] = p.wp[(int64_t)cc * H + j]; d2 += hsr[k] * wp_r[k]; } }
-        }
-        if constexpr (BAYES && QUAD) {
-            if (wp_planes) {   // the lane's 8 consecutive hidden units of row cc: 16 bytes from each plane; value = (hi + lo) / scale - exactly what the dense pass multiplied with
-                typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-                const uint16_t* r0 = p.wp_pl + ((int64_t)(cc >> 5) * 64 + (cc & 31)) * H + 8 * l;     // [tile of 32 rows][plane][row][H]
-                const h8_t hi = *reinterpret_cast<const h8_t*>(r0), lo = *reinterpret_cast<const h8_t*>(r0 + 32 * H);
-#pragma unroll
-                for (int k = 0; k < NV; ++k) { wp_r[k] = ((float)hi[k] + (float)lo[k]) * p.wp_inv_scale; d2 += hsr[k] * wp_r[k]; }
+            for (int k = 0; k < NV; ++k) {
+                const int j = hidx(k);
+                mu_r[k] = 0.f; wp_r[k] = 0.f;
+                if (j < H) { mu_r[k] = p.mu[(int64_t)cc * H + j]; d1 += hr[k] * mu_r[k]; if (BAYES) { wp_r[k] = p.wp[(int64_t)cc * H + j]; d2 += hsr[k] * wp_r[k]; } }
+            }
+            d1 = group_sum(d1);
+            z = d1 + p.mu_b[cc];
+            if (BAYES) {
+                d2 = group_sum(d2);
+                const uint32_t sw_ = p.so_inj ? p.sbits[(int64_t)i * p.nCB + (cc >> 5)] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(cc >> 5));
+                so = ((sw_ >> (cc & 31)) & 1u) ? -1.f : 1.f;
+                z += (d2 + p.bp[cc]) * so;
             }
         }
-        d1 = group_sum(d1);
-        float z = d1 + p.mu_b[cc];
-        float so = 1.f;
-        if (BAYES) {
-            d2 = group_sum(d2);
-            const uint32_t sw_ = p.so_inj ? p.sbits[(int64_t)i * p.nCB + (cc >> 5)] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(cc >> 5));
-            so = ((sw_ >> (cc & 31)) & 1u) ? -1.f : 1.f;
-            z += (d2 + p.bp[cc]) * so;
-        }
         float sp, sg, dact;
-        bce_terms(z, sp, sg, dact);
+        const float dzt = special_dz(z, y, p.tpw, p.inv_B, sp, sg, dact);
         const float lz = z > 0.f ? z : z * kLeakySlope;
         if (live && l == 0) fix += p.tpw * (sp - lz * y) - p.tnw * sp;
         if (TRAIN && live) {
-            const float dzt = p.tpw * (sg - y) * dact * p.inv_B;
             const float delta = dzt - p.tnw * sg * dact * p.inv_B;
             if (l == 0) {
-                if (packed) { uint32_t pq[3]; split_pair_np<2>(dzt, 0.f, p.dz_pack_scale, pq); reinterpret_cast<uint32_t*>(p.dzT)[dzt_index(c, i, p.Bpad)] = (pq[0] & 0xFFFFu) | (pq[1] << 16); }
+                if (packed) reinterpret_cast<uint32_t*>(p.dzT)[dzt_index(c, i, p.Bpad)] = special_dz_packed(dzt, p.dz_pack_scale);
                 else p.dzT[dzt_index(c, i, p.Bpad)] = dzt;
             }
             if (DH) {
@@ -521,6 +595,9 @@ struct OutFwd6Args {
     int plogit;                      // PROBS: store the logit leaky_relu(z) itself instead (ntf_logits: the quantity the 1e-4 parity bar is stated on)
     unsigned long long* stamps;           // diagnostics (k_out_fwd_h3x<.., ABL = 9>): per wave 8 cycle sums, see NTF_FWD_STAMP
     float h_scale, dz_scale, u_z, u_dh;   // fp16x3 (NP = 2): scales applied to h / dz before their split, and 1/(w scale * h scale), 1/(dz scale * w scale); 1 for bf16x6
+    // k_out_fwd_h3p, enable != 0: the workgroup corrects the special entries (positives, sampled negatives) of ITS rows x ITS experts in dzT itself, behind its tile loop -
+    // the dW kernel can then follow the forward kernel directly, and the sparse fix-up kernel (loss terms, d(hidden)) runs beside it on the side stream
+    struct Fix { const int64_t *rows, *m_indptr, *neg; const int32_t* m_indices; const int* spec; int ns, c_lo, enable; float tpw, wp_inv_scale; } fix;
 };
 // fp16x3 training step: dzT holds, per element, the two fp16 planes of dz * dz_scale packed in one dword (hi | lo << 16) - the split the forward
 // kernel makes anyway for its dh products - so that the dW kernel reads MFMA operands instead of splitting f32 values again
@@ -1371,6 +1448,106 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             __syncthreads();
         }
     };
+    // ---- the special entries (pp.fix): src/mdl/fnn.py:32-46 gives the positives and the sampled negatives of a row the weight tpw (the positives label 1).  Which they are
+    // is listed per row by k_special_list (beside the sampler, off the step's critical path); behind the tile loop every quarter-wave takes four rows, keeps the entries
+    // that fall on THIS workgroup's experts and recomputes their logits (special_z16: the sparse fix-up kernel's own function).
+    auto fix_row_info = [&](int r, int64_t& pb, int& npos, int& total) -> bool {
+        const int irow = rb * BM + r;
+        if (irow >= p.B) { pb = 0; npos = 0; total = 0; return false; }
+        const int64_t team = pp.fix.rows[irow];
+        pb = pp.fix.m_indptr[team]; npos = (int)(pp.fix.m_indptr[team + 1] - pb); total = npos + (pp.fix.neg ? pp.fix.ns : 0);
+        return true;
+    };
+    auto fix_mine = [&](int cv) -> int {          // a listed candidate (global id | label << 30, or -1) -> local id | label << 30 if it is one of this workgroup's experts, else -1
+        if (cv < 0) return -1;
+        const int c = (cv & 0x3FFFFFFF) - pp.fix.c_lo;
+        if (c < 0 || c >= p.M || c < 32 * s_beg || c >= 32 * s_end) return -1;
+        return c | (cv & (1 << 30));
+    };
+    auto fix_cand = [&](int r, int64_t pb, int npos, int total, int sidx) -> int {      // (rows with more than SPEC_W candidates: the rest straight from memory)
+        if (sidx >= total) return -1;
+        float y;
+        const int c = special_candidate(pp.fix.m_indices, pp.fix.neg, pb, npos, pp.fix.ns, rb * BM + r, sidx, y);
+        return fix_mine(c < 0 ? -1 : (c | (y != 0.f ? (1 << 30) : 0)));
+    };
+    // every wave, behind its tile loop.  For each special entry of its rows x this workgroup's experts: the logit again (special_z16), then everything the sparse fix-up
+    // kernel derives from it - the entry's dz (overwritten in dzT), its loss correction (added to this workgroup's loss partial of the row) and its d(hidden) terms (added
+    // to this workgroup's dh slab row) - so that the kernel which follows on the side stream only SUMS partials and never reads the weights the dW + Adam kernel is
+    // updating in place beside it.  A row's entries are one quarter-wave's, visited in candidate order: the sums are deterministic.
+    auto fix_dz = [&]() {
+        if (!pp.fix.enable) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's dzT / slab / loss-partial stores have completed ...
+        __syncthreads();                                          // ... and every other wave's (both roles call fix_dz exactly once)
+        const int g = wave_u * 4 + (lane >> 4), l16 = lane & 15;
+        const bool wp_planes = BAYES && pp.wp_pl != nullptr;
+        // the four rows' lists first (independent loads: one round trip instead of four), then row by row
+        int totals[4], cands[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int irow = rb * BM + g * 4 + rr;
+            totals[rr] = irow < p.B ? pp.fix.spec[(int64_t)p.Bpad * SPEC_W + irow] : 0;
+            cands[rr] = irow < p.B ? pp.fix.spec[(int64_t)irow * SPEC_W + l16] : -1;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = g * 4 + rr, irow = rb * BM + r;
+            const int total = totals[rr];
+            int cand = fix_mine(cands[rr]);
+            float hr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hsr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float lfix = 0.f;
+            uint32_t siw = 0u;          // s_in signs of this lane's 8 hidden units (bit k)
+            bool have_h = false, have_info = false;
+            int64_t pb = 0; int npos = 0, tot2 = 0;
+#pragma unroll 1
+            for (int k0 = 0; k0 < total; k0 += 16) {
+                if (k0 > 0) {        // a row with more than 16 candidates: the rest straight from memory
+                    if (!have_info) { fix_row_info(r, pb, npos, tot2); have_info = true; }
+                    cand = fix_cand(r, pb, npos, total, k0 + l16);
+                }
+                uint32_t m16 = (uint32_t)(__ballot(cand >= 0) >> (16 * (lane >> 4))) & 0xFFFFu;
+                if (m16 && !have_h) {
+                    have_h = true;
+                    const float4 a = *reinterpret_cast<const float4*>(p.h + (int64_t)irow * H + 8 * l16), b = *reinterpret_cast<const float4*>(p.h + (int64_t)irow * H + 8 * l16 + 4);
+                    hr[0] = a.x; hr[1] = a.y; hr[2] = a.z; hr[3] = a.w; hr[4] = b.x; hr[5] = b.y; hr[6] = b.z; hr[7] = b.w;
+                    if (BAYES) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(p.hs + (int64_t)irow * H + 8 * l16), d4 = *reinterpret_cast<const float4*>(p.hs + (int64_t)irow * H + 8 * l16 + 4);
+                        hsr[0] = c4.x; hsr[1] = c4.y; hsr[2] = c4.z; hsr[3] = c4.w; hsr[4] = d4.x; hsr[5] = d4.y; hsr[6] = d4.z; hsr[7] = d4.w;
+                        const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + (l16 >> 2)] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)(l16 >> 2));
+                        siw = (w >> (8 * (l16 & 3))) & 0xFFu;
+                    }
+                }
+                while (m16) {
+                    const int src = __builtin_ctz(m16); m16 &= m16 - 1;
+                    const int cv = __shfl(cand, (lane & 48) + src, 64);
+                    const int c = cv & 0x3FFFFFFF; const float y = (cv >> 30) & 1 ? 1.f : 0.f;
+                    float mu_r[8], wp_r[8], so, sp, sg, dact;
+                    const float z = special_z16<BAYES>(p.mu, p.mu_b, p.wp, p.bp, pp.wp_pl, pp.fix.wp_inv_scale, wp_planes, p.sbits, p.nCB, p.so_k0, p.so_k1, p.so_inj, irow, c, l16, hr, hsr, mu_r, wp_r, so);
+                    const float dzt = special_dz(z, y, pp.fix.tpw, p.inv_B, sp, sg, dact);
+                    const float lz = z > 0.f ? z : z * kLeakySlope;
+                    lfix += pp.fix.tpw * (sp - lz * y) - p.tnw * sp;
+                    const float delta = dzt - p.tnw * sg * dact * p.inv_B;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        dv[k] += delta * mu_r[k];
+                        if (BAYES) dv[k] += delta * so * wp_r[k] * (((siw >> k) & 1u) ? -1.f : 1.f);
+                    }
+                    if (l16 == 0) reinterpret_cast<uint32_t*>(p.dzT)[dzt_index(c, irow, p.Bpad)] = special_dz_packed(dzt, pp.dz_scale);
+                }
+            }
+            if (have_h) {       // (quarter-uniform) this row had entries here: its slab row and loss partial, written by this workgroup's waves above, take the corrections
+                float* sl = p.slab + ((int64_t)cg * p.Bpad + irow) * H + 8 * l16;
+                float cur[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cur[k] = __hip_atomic_load(sl + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1: the row was stored by another wave)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sl[k] = cur[k] + dv[k];
+                if (l16 == 0) {
+                    float* lp = p.lossp + (int64_t)irow * p.NCG + cg;
+                    *lp = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + lfix;
+                }
+            }
+        }
+    };
 
     if (role == 0) {
         // ================================================================ wave A: zT, logits, DMA
@@ -1448,7 +1625,11 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(dzv[q], dz_rsrc, dz_voff, (32 * u + 8 * q) * 128, 0);
         };
         for (int s = s_beg; s <= s_end + 1; ++s) {
+#ifndef H3P_ZFIRST
             if (s - 2 >= s_beg) load_dz(s - 2);
+#else
+            if (s - 2 >= s_beg && s >= s_end) load_dz(s - 2);
+#endif
             if (s - 2 >= s_beg && s >= s_end) store_dz(s - 2);      // (behind the last sub-tiles; otherwise after this step's MFMAs, below)
             if (s < s_end) {
                 mask_past_m(s);
@@ -1480,6 +1661,9 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                 };
 #pragma unroll
                 for (int k = 0; k < BG; ++k) z_load(k, fb[0][k]);
+#ifdef H3P_ZFIRST
+                if (s - 2 >= s_beg) load_dz(s - 2);          // (experiment: the first weight fragments in front of the packed dz in the LDS queue)
+#endif
                 stamp(4);
                 const int sn = min(s + 1, s_end - 1);       // behind the last sub-tile the free stage takes that sub-tile once more
 #pragma unroll
@@ -1523,12 +1707,15 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                         float z = fmaf(X1[r], pp.u_z, bm[r]);
                         if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[r], pp.u_z, bq[r])) ^ ((swu << (31 - cr)) & 0x80000000u));
                         const bool pos = z > 0.f;
-                        l[j] = pos ? z : z * kLeakySlope;
+                        // l >= -21: the product of four 1 + e^-l below must stay finite (four logits of -22.2 reach 3.4e38 - a row with an outlier activation did, at
+                        // step 1 134 of the benchmark's run: softplus inf, then NaN through the compensated sum; the gradients never went through it).  Below -21
+                        // softplus and its slope are under 7.6e-10: the clamp moves the loss and dz by less than that per expert
+                        l[j] = fmaxf(pos ? z : z * kLeakySlope, -21.f);
                         tt[j] = 1.f + __builtin_amdgcn_exp2f(l[j] * -1.4426950408889634f);
                         v[j] = pos ? -tt[j] : tt[j];
                     }
-                    // sum of four softplus(l) = log(tt0 tt1 tt2 tt3) + (l0 + l1 + l2 + l3): one v_log_f32 for four.  The product overflows past sum(-l) = 88, i.e. a mean
-                    // logit below -22 (a pre-activation below -2 200 under leaky_relu); the experts past M are masked at l = -20 for that (tt = 4.9e8)
+                    // sum of four softplus(l) = log(tt0 tt1 tt2 tt3) + (l0 + l1 + l2 + l3): one v_log_f32 for four.  The product would overflow past sum(-l) = 88, i.e. a mean
+                    // logit below -22 (a pre-activation below -2 200 under leaky_relu): l is clamped at -21 above; the experts past M are masked at l = -20 (tt = 4.9e8)
                     lt += fmaf(__builtin_amdgcn_logf((tt[0] * tt[1]) * (tt[2] * tt[3])), 0.6931471805599453f, (l[0] + l[1]) + (l[2] + l[3]));
                     *reinterpret_cast<float4*>(hb + j4 * 1024) = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -1545,6 +1732,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         float lsum = lacc.sum;
         lsum += __shfl_xor(lsum, 32, 64);
         if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+        fix_dz();
         return;
     }
 
@@ -1693,6 +1881,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
         }
     }
+    fix_dz();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1750,6 +1939,9 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     s.dz_pack_scale = (f.train && f.bf16x6 && f.H == 128 && f.np == 2) ? f.dz_scale : 0.f; s.rflag = f.rflag; s.c_lo = f.c_lo;
     s.wp_pl = (f.bayes && f.bf16x6 && f.H == 128 && f.np == 2 && f.wp_pl) ? f.wp_pl : nullptr; s.wp_inv_scale = 1.f / f.w_scale;
+    // the wave-pair forward kernel corrects the special entries of dzT itself (FusedOut.fix_in_fwd): the fix-up kernel then leaves dzT alone unless the step fell back to f32
+    const bool fwd_fixes = f.fix_in_fwd && f.bf16x6 && f.H == 128 && f.np == 2 && f.train && f.dh != nullptr && f.wide == 5 && !f.probs;
+    s.dz_in_fwd = fwd_fixes ? 1 : 0;
     const int grid = g.NRB * g.NCG;
     if (f.bf16x6 && f.H == 128) {
         const int np = f.np == 2 ? 2 : 3;
@@ -1760,6 +1952,8 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
         }
         if (phases & 2) {
             OutFwd6Args a6; a6.stamps = nullptr; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc; a6.plogit = f.plogit;
+            a6.fix.rows = f.rows; a6.fix.m_indptr = f.m_indptr; a6.fix.m_indices = f.m_indices; a6.fix.neg = f.neg; a6.fix.ns = f.ns; a6.fix.c_lo = f.c_lo;
+            a6.fix.enable = fwd_fixes ? 1 : 0; a6.fix.tpw = f.tpw; a6.fix.wp_inv_scale = 1.f / f.w_scale; a6.fix.spec = reinterpret_cast<const int*>(ws + w.spec);
             a6.a.rmode = (guard && np == 2) ? 1 : 0;
             a6.h_scale = np == 2 ? f.h_scale : 1.f; a6.dz_scale = np == 2 ? f.dz_scale : 1.f;
             a6.u_z = np == 2 ? 1.f / (f.w_scale * f.h_scale) : 1.f; a6.u_dh = np == 2 ? 1.f / (f.dz_scale * f.w_scale) : 1.f;
@@ -1846,10 +2040,14 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #else
             constexpr bool skip_fb = false;
 #endif
-            if (guard && np == 2 && !f.probs && !merged_fallback && !skip_fb) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
+            if (guard && np == 2 && !f.probs && !merged_fallback && !skip_fb && !f.split_fallback) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
                 OutFwdArgs af = a; af.rmode = 2;
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
             }
+        }
+        if ((phases & 8) && f.split_fallback && guard && f.np == 2 && !f.probs) {   // ... as a launch of its own (the engine issues it on the side stream, in front of the sparse fix-up)
+            OutFwdArgs af = a; af.rmode = 2;
+            if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
         }
         if ((phases & 4) && !f.probs) {
 #define NTF_SP(BY) do { if (!f.train) hipLaunchKernelGGL((k_out_special<128, BY, false, false>), dim3(f.B), dim3(64), 0, st, s);         \

@@ -725,19 +725,26 @@ void launch_step_scalars(hipStream_t st, double* kl, int take_next) { hipLaunchK
 //   fin[k] = 1 / 2: the range is the output layer's bias / rho_bias, whose raw gradients (sums of dz, of dz * s_out: the dW kernel's by-product) still need the
 //                   Flipout chain rule and the KL terms - k_flipout_grad_finalize's arithmetic, applied (and written back to G) before the update;
 //   rotate != null: thread 0 moves the NEXT step's KL sum and range flag, written by this step's dW epilogue (FusedDw.produce), to the current slots.
-struct AdamRanges { int64_t lo[4], n[4]; int blk0[5]; int cnt; int fin[4]; NormalSpec eps; float klw; double* rotate; };
+//   nx.bp != null (round 5; the ranges with fin = 1 / 2): the launch also is the operand producer of the NEXT step's output bias - from the updated rho_b' the range with
+//                   fin = 2 writes bp' = softplus(rho_b') eps_b' (nx.eps: the generator of step + 1) and both ranges add their parts of KL(mu_b', rho_b') * nx.klw to
+//                   the NEXT step's KL slot (k_head's bias workgroups did this in a launch of their own behind this one).  The rotation then cannot be thread 0's first
+//                   act - adds to the next slot are still coming: the workgroup that finishes LAST (a ticket in the int32 behind the next flag) rotates.
+struct AdamRanges { int64_t lo[4], n[4]; int blk0[5]; int cnt; int fin[4]; NormalSpec eps; float klw; double* rotate;
+                    struct { float* bp; NormalSpec eps; double klw; } nx; };
 __device__ __forceinline__ void fin_mu(float& g, float p, float klw) { g += klw * p; }
 __device__ __forceinline__ void fin_rho(float& g, float r, float z, float klw) {
     const float sg = 1.f / (1.f + expf(-r));  // d softplus / d rho
     const float sigma = softplus_rho(r);
     g = g * z * sg + klw * (sigma - 1.f / sigma) * sg;
 }
+__device__ __forceinline__ void rotate_scalars(double* kl) {      // next step's KL sum and range flag -> current (see k_step_scalars)
+    int32_t* w = reinterpret_cast<int32_t*>(kl);
+    kl[0] = kl[2]; w[2] = w[6]; kl[2] = 0.0; w[6] = 0;
+}
 __global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, float* __restrict__ M1, float* __restrict__ V2, AdamRanges r,
                               float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
-    if (r.rotate && blockIdx.x == 0 && threadIdx.x == 0) {
-        int32_t* w = reinterpret_cast<int32_t*>(r.rotate);
-        r.rotate[0] = r.rotate[2]; w[2] = w[6]; r.rotate[2] = 0.0; w[6] = 0;
-    }
+    const bool produce = r.nx.bp != nullptr;
+    if (r.rotate && !produce && blockIdx.x == 0 && threadIdx.x == 0) rotate_scalars(r.rotate);
     int k = 0;
     while (k + 1 < r.cnt && (int)blockIdx.x >= r.blk0[k + 1]) ++k;
     const int64_t lo = r.lo[k], n = r.n[k];
@@ -745,6 +752,7 @@ __global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, floa
     const int64_t first = (int64_t)((int)blockIdx.x - r.blk0[k]) * blockDim.x + threadIdx.x, stride = (int64_t)(r.blk0[k + 1] - r.blk0[k]) * blockDim.x;
     float *p = P + lo, *m = M1 + lo, *v = V2 + lo, *g = G + lo;
     const int64_t nq = n >> 2;    // lo is a multiple of 4 floats (checked by the launcher): 16-byte accesses
+    float kl_nx = 0.f;
     for (int64_t q = first; q < nq; q += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[q], mm = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
         float4 gg = reinterpret_cast<const float4*>(g)[q];
@@ -758,6 +766,20 @@ __global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, floa
         adam_one(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, b1, b2, eps, bc2_sqrt);
         adam_one(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, b1, b2, eps, bc2_sqrt); adam_one(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, b1, b2, eps, bc2_sqrt);
         reinterpret_cast<float4*>(p)[q] = pp; reinterpret_cast<float4*>(m)[q] = mm; reinterpret_cast<float4*>(v)[q] = vv;
+        if (produce && fin == 1) kl_nx += 0.5f * (pp.x * pp.x) + 0.5f * (pp.y * pp.y) + 0.5f * (pp.z * pp.z) + 0.5f * (pp.w * pp.w);
+        else if (produce && fin == 2) {
+            float z[4], ov[4];
+            const float rv[4] = {pp.x, pp.y, pp.z, pp.w};
+            normal4(r.nx.eps, q, q * 4, n, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float ls;
+                const float sigma = softplus_rho_fast(rv[j], ls);
+                ov[j] = sigma * z[j];
+                kl_nx += -ls + 0.5f * (sigma * sigma) - 0.5f;
+            }
+            *reinterpret_cast<float4*>(r.nx.bp + q * 4) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        }
     }
     for (int64_t e = (nq << 2) + first; e < n; e += stride) {
         float pe = p[e], me = m[e], ve = v[e], ge = g[e];
@@ -770,16 +792,47 @@ __global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, floa
         }
         adam_one(pe, ge, me, ve, lr_over_bc1, b1, b2, eps, bc2_sqrt);
         p[e] = pe; m[e] = me; v[e] = ve;
+        if (produce && fin == 1) kl_nx += 0.5f * (pe * pe);
+        else if (produce && fin == 2) {
+            float z[4];
+            normal4(r.nx.eps, e >> 2, e & ~(int64_t)3, n, z);
+            const int j = (int)(e & 3);
+            const float sigma = softplus_rho(pe);
+            r.nx.bp[e] = sigma * (j == 0 ? z[0] : j == 1 ? z[1] : j == 2 ? z[2] : z[3]);
+            kl_nx += -logf(sigma) + 0.5f * (sigma * sigma) - 0.5f;
+        }
+    }
+    if (produce) {      // (uniform over the launch: every workgroup takes a ticket)
+        __shared__ double red[4];
+        __shared__ int last;
+        const double sred = wave_reduce_sum_d((double)kl_nx);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sred;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t* w = reinterpret_cast<int32_t*>(r.rotate);
+            if (fin) atomicAdd(r.rotate + 2, (red[0] + red[1] + red[2] + red[3]) * r.nx.klw);
+            __threadfence();                                        // the add (a device-scope atomic) has been performed before the ticket is taken
+            last = atomicAdd(w + 7, 1) == (int)gridDim.x - 1;
+            if (last) {
+                // every workgroup's add is in: take the next slot's value through the atomic unit (a plain load could read a stale line of this XCD's L2) and rotate
+                const unsigned long long bits = atomicExch(reinterpret_cast<unsigned long long*>(r.rotate + 2), 0ull);
+                r.rotate[0] = __longlong_as_double((long long)bits);
+                w[2] = atomicExch(w + 6, 0);
+                atomicExch(w + 7, 0);
+            }
+        }
     }
 }
 // lo_hi: n pairs [lo, hi) of float offsets into the flat buffers (P, G, M1, V2 are the buffers' bases, 16-byte aligned); fin (nullable): per range 0 / 1 / 2, see above
 void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,
-                        float eps, float bc1, float bc2_sqrt, const int* fin, const NormalSpec* fin_eps, float fin_klw, double* rotate) {
+                        float eps, float bc1, float bc2_sqrt, const int* fin, const NormalSpec* fin_eps, float fin_klw, double* rotate,
+                        float* nx_bp, const NormalSpec* nx_eps, double nx_klw) {
     int k = 0;
     bool launched = false;
     while (k < n) {
         AdamRanges r; r.cnt = 0; int blocks = 0;
         r.klw = fin_klw; if (fin_eps) r.eps = *fin_eps; r.rotate = launched ? nullptr : rotate;
+        r.nx.bp = (rotate && nx_bp && nx_eps && n <= 4) ? nx_bp : nullptr; if (nx_eps) r.nx.eps = *nx_eps; r.nx.klw = nx_klw;      // (one launch holds every range: the ticket counts its workgroups)
         for (; k < n && r.cnt < 4; ++k) {
             const int64_t lo = lo_hi[2 * k], cnt = lo_hi[2 * k + 1] - lo;
             if (cnt <= 0) continue;

@@ -121,14 +121,19 @@ def _completed(work):
 
 
 class DataParallel:
-    def __init__(self, engine, group=None, overlap=True, shard_optimizer=None):
+    def __init__(self, engine, group=None, overlap=True, shard_optimizer=None, emulate_world=0):
+        """emulate_world = G > 1 (no process group; bench.py --dp-emulate): ONE rank's share of a G-rank step on one GPU - its 1/G of the global minibatch's rows through
+        the deferred / chunked dW path, Adam on the 1/G shard it would own, NO exchange (the reduce-scatter / all-gather calls are skipped, their byte counts tallied in
+        `emulated_bytes`): the per-rank compute time behind a scaling projection, not a measurement of the collectives."""
         self.engine = engine
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.emulate = int(emulate_world) if emulate_world and int(emulate_world) > 1 else 0
+        self.world = self.emulate or (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = 0 if self.emulate else (dist.get_rank(group) if dist.is_initialized() else 0)
+        self.emulated_bytes = {"reduce_scatter_in": 0, "all_reduce": 0, "all_gather_out": 0, "steps": 0}
         self._grad = engine.grad_tensor()  # flat view of the engine's gradient buffer (HBM; aliases, no copy)
         # NTF_DP_FORCE_ALLREDUCE=1: run the collectives even at world_size 1 (exercises RCCL on the aliased buffers on a 1-GPU box)
-        self.force_allreduce = dist.is_initialized() and os.environ.get("NTF_DP_FORCE_ALLREDUCE", "0") == "1"
+        self.force_allreduce = (dist.is_initialized() and os.environ.get("NTF_DP_FORCE_ALLREDUCE", "0") == "1") or bool(self.emulate)
         self.n_chunks = engine.dw_chunks() if (overlap and hasattr(engine, "dw_chunks")) else 0
         if self.n_chunks:
             self._chunk_ranges = [engine.dw_chunk_range(k) for k in range(self.n_chunks)]  # identical on every rank
@@ -137,7 +142,7 @@ class DataParallel:
         self.shard = can_shard if shard_optimizer is None else (bool(shard_optimizer) and can_shard)
         self._param = engine.param_tensor() if self.shard else None
         # gloo (the CPU tests) has no reduce-scatter: there it is an all-reduce of which this rank keeps its part - same result
-        self._native_rs = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._native_rs = (not self.emulate) and dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._pending = []   # parameter all-gathers of the previous step
         self.trace = CollectiveTrace(f"DataParallel rank {self.rank}/{self.world}", stream_ordered=self._native_rs)
         self._step_no = 0
@@ -147,6 +152,9 @@ class DataParallel:
 
     # ---- collectives on [lo, hi) of the flat buffers
     def _all_reduce(self, lo, hi):
+        if self.emulate:
+            self.emulated_bytes["all_reduce"] += 4 * (hi - lo)
+            return _Done()
         return self.trace.add(f"step {self._step_no} all_reduce grad[{lo}:{hi}]",
                               dist.all_reduce(self._grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -156,7 +164,9 @@ class DataParallel:
         part, tail = shard_range(lo, hi, self.world)
         if part:
             mine = (lo + self.rank * part, lo + (self.rank + 1) * part)
-            if self._native_rs:
+            if self.emulate:
+                self.emulated_bytes["reduce_scatter_in"] += 4 * (tail - lo)
+            elif self._native_rs:
                 works.append(self.trace.add(f"step {self._step_no} reduce_scatter grad[{lo}:{tail}]",
                                             dist.reduce_scatter_tensor(self._grad[mine[0]:mine[1]], self._grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
             else:
@@ -169,6 +179,9 @@ class DataParallel:
     def _all_gather(self, lo, hi):
         part, tail = shard_range(lo, hi, self.world)
         if not part:
+            return _Done()
+        if self.emulate:
+            self.emulated_bytes["all_gather_out"] += 4 * (tail - lo)
             return _Done()
         mine = self._param[lo + self.rank * part: lo + (self.rank + 1) * part]
         label = f"step {self._step_no} all_gather param[{lo}:{tail}]"
@@ -197,6 +210,7 @@ class DataParallel:
         """backward of this rank's shard of the batch + gradient exchange + Adam for one global minibatch"""
         e, have_rows = self.engine, hi > lo
         self._step_no += 1
+        self.emulated_bytes["steps"] += 1
         self._finish_gathers()            # the parameters this step reads are complete
         works, owned, gathered = [], [], []
         reduce = (lambda a, b: self._reduce_scatter(a, b, owned, works)) if self.shard else (lambda a, b: works.append(self._all_reduce(a, b)))
@@ -255,7 +269,7 @@ class DataParallel:
             self.trace.sync("the phase's kernels and collectives")      # bounded: the loss read-back below would wait for ever behind a hung collective
         s, _ = self.engine.epoch_loss()  # sum over steps of this rank's share of each batch loss
         t = torch.tensor([s], dtype=torch.float64, device=self._grad.device if self._grad.is_cuda else "cpu")
-        if self.world > 1:
+        if self.world > 1 and not self.emulate:
             self.trace.wait(self.trace.add("phase loss all_reduce", dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
             if t.is_cuda: self.trace.sync("the loss all_reduce")
         return float(t.item()) / max(steps, 1)

@@ -229,3 +229,34 @@ def test_shard_range_properties():
     for lo, hi, w in [(0, 100, 3), (64, 64 + 8_388_608, 8), (128, 128 + 4_738_688, 3), (0, 7, 2), (0, 0, 4), (256, 256 + 13, 5)]:
         part, tail = shard_range(lo, hi, w)
         assert part % 4 == 0 and tail == lo + w * part and lo <= tail <= hi and hi - tail < w * 4 + 4 * w
+
+
+def test_one_rank_of_g_emulated_without_a_process_group():
+    """bench.py --dp-emulate (round 5): `DataParallel(engine, emulate_world=G)` runs rank 0's share of every G-rank step - its rows of each global minibatch through the
+    deferred / chunked path, Adam on the ranges rank 0 would own - without any process group, and tallies the bytes the skipped collectives would carry.  Checked against
+    the real thing: the bytes equal what a world-size-G run hands to reduce-scatter / all-gather / all-reduce, and only rank 0's shard of the optimiser state is touched."""
+    from opentf_amd.dp import DataParallel, shard_bounds, shard_range
+    G = 4
+    sd, X, y, order, gB, noise = _case(True)
+    eng = OracleEngine(sd, X, y, 10.0, 1.0, 1e-2, noise)
+    assert not dist.is_initialized()
+    dp = DataParallel(eng, emulate_world=G)
+    assert dp.world == G and dp.rank == 0 and dp.n_chunks == OracleEngine.N_CHUNKS and dp.shard
+    dp.train_epoch(order, gB)
+    steps = -(-len(order) // gB)
+    eb = dp.emulated_bytes
+    assert eb["steps"] == steps
+    n = eng.pflat.numel()
+    rs = ag = ar = 0
+    for k in range(eng.N_CHUNKS):
+        ow, orr, cnt = eng.dw_chunk_range(k)
+        for lo in ([ow] if orr < 0 else [ow, orr]):
+            part, tail = shard_range(lo, lo + cnt, G)
+            rs += 4 * (tail - lo); ag += 4 * (tail - lo); ar += 4 * (lo + cnt - tail)
+    ar += 4 * sum(hi - lo for lo, hi in eng.rest_ranges())
+    assert eb["reduce_scatter_in"] == rs * steps and eb["all_gather_out"] == ag * steps and eb["all_reduce"] == ar * steps
+    assert 4 * n == rs + ar                                # every gradient float goes through exactly one of the two
+    # rank 0 stepped ITS rows only (the first shard of each global minibatch) and updated ITS shard only: the other ranks' parts of the output layer keep zero moments
+    touched = (eng.m != 0).float().mean().item()
+    assert touched < 1.0 / G + 0.35, touched
+    assert eng.steps == 0 and eng.t == steps               # (epoch_loss was read; one optimiser step per global minibatch)

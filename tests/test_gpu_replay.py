@@ -108,9 +108,11 @@ def test_three_default_steps_replayed_through_the_oracle_on_a_ragged_shape():
     _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=22, t0=40)
 
 
-def test_negatives_of_a_step_survive_the_next_batchs_prefetched_sampler():
+@pytest.mark.parametrize("nsd", ["uniform", "unigram_b"])
+def test_negatives_of_a_step_survive_the_next_batchs_prefetched_sampler(nsd):
     """with the head prefetch the next batch's sampler runs beside this step's dW kernel; `ntf_get_negatives` must still return THIS step's draws (they live in
-    one of two buffers by step parity).  The same seed and step index without the prefetch (NTF_HEAD_PREFETCH=0 at engine creation) draws the same negatives."""
+    one of two buffers by step parity).  The same seed and step index without the prefetch (NTF_HEAD_PREFETCH=0 at engine creation) draws the same negatives.
+    unigram_b (round 5): the next batch's per-batch alias table is staged beside the dW kernel too - same draws, and the head prefetch now hits for that sampler."""
     import os
     from oracle import ntf_oracle as O
     from opentf_amd import libntf
@@ -126,7 +128,7 @@ def test_negatives_of_a_step_survive_the_next_batchs_prefetched_sampler():
         old = os.environ.get("NTF_HEAD_PREFETCH")
         os.environ["NTF_HEAD_PREFETCH"] = pf
         try:
-            e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", seed=9, fuse_adam=1)
+            e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd=nsd, seed=9, fuse_adam=1)
         finally:
             if old is None: os.environ.pop("NTF_HEAD_PREFETCH")
             else: os.environ["NTF_HEAD_PREFETCH"] = old
@@ -140,3 +142,56 @@ def test_negatives_of_a_step_survive_the_next_batchs_prefetched_sampler():
     assert out[0][1] >= 2 and out[1][1] == 0
     for a, b in zip(out[0][0], out[1][0]): np.testing.assert_array_equal(a, b)
     assert not np.array_equal(out[0][0][0], out[0][0][1])
+    if nsd == "unigram_b":      # src/mdl/fnn.py:74-76: negatives are experts of the batch itself (weight y.sum(0) / B), never members of the row
+        for k, neg in enumerate(out[0][0]):
+            rows = order[k * B: (k + 1) * B]
+            support = set(np.concatenate([member[1][member[0][r]: member[0][r + 1]] for r in rows]).tolist())
+            assert set(neg.ravel().tolist()) <= support
+
+
+def test_a_row_with_an_outlier_activation_keeps_the_loss_finite():
+    """Found by the replay work (round 5): k_out_fwd_h3p takes ONE v_log_f32 for four experts' softplus terms - log((1 + e^-l0)(1 + e^-l1)(1 + e^-l2)(1 + e^-l3)) - and
+    that product overflows once four logits of a row average below -22, i.e. pre-activations below -2 200 under leaky_relu: one team with an outlier embedding at step
+    1 134 of the benchmark's own run made the step's loss NaN (inf through the compensated sum; the gradients were right - they never went through it).  The kernel now
+    clamps l at -21 (softplus and its slope below 7.6e-10 there).  Here: one row whose hidden activation is ~2 000 - hundreds of its logits fall below -22 - through the
+    default training step (injected noise) against the oracle: loss finite and equal to 2e-5, every gradient to 3e-4 of its maximum."""
+    import torch
+    from conftest import draw_noise
+    from oracle import ntf_oracle as O
+    from opentf_amd import libntf
+    torch.manual_seed(31)
+    rng = np.random.default_rng(31)
+    D, H, M, B, S = 128, 128, 8000, 128, 300
+    skill, table, member = _dataset(rng, B, S, D, M, 4.0, 2.5)
+    sd = O.bnn_init(D, [H], M)
+    row = 7
+    s0 = int(skill[1][skill[0][row]])                                   # one of row 7's skills: its embedding scaled until the largest hidden activation of the batch reaches ~2 000
+    base = table[s0].copy()
+
+    def hidden_max(a):
+        table[s0] = base * a
+        x = torch.from_numpy(O.gather_meanpool_fast(skill[0], skill[1], table))      # (every row that has this skill moves with it: the largest of them is what is bounded)
+        return float(torch.nn.functional.leaky_relu(x @ sd["layers.0.mu_weight"].T + sd["layers.0.mu_bias"]).abs().max())
+    lo_a, hi_a = 1.0, 1e5
+    for _ in range(60):
+        mid = (lo_a * hi_a) ** 0.5
+        if hidden_max(mid) < 2000.0: lo_a = mid
+        else: hi_a = mid
+    assert 1500.0 < hidden_max(lo_a) < 2100.0
+    X = torch.from_numpy(O.gather_meanpool_fast(skill[0], skill[1], table))
+    y = torch.zeros(B, M)
+    for k in range(B): y[k, member[1][member[0][k]: member[0][k + 1]].astype(np.int64)] = 1.0
+    noise = draw_noise(sd, B); neg = O.ns_uniform(y, 5)
+    z = O.model_forward(sd, X, noise)
+    assert int((z < -22.5).sum()) > 200, (int((z < -22.5).sum()), float(z.min()))     # deep in the overflow region (the hidden activation itself stays inside the fp16 window: 4 094)
+    inj = {"neg_idx": neg.numpy(), "eps_w": [n["eps_w"] for n in noise], "eps_b": [n["eps_b"] for n in noise], "s_in": [n["s_in"] for n in noise], "s_out": [n["s_out"] for n in noise]}
+    ref_loss, ref_grads = O.loss_and_grads(sd, X, y, neg, 10.0, 1.0, noise)
+    e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", tpw=10.0, tnw=1.0, lr=1e-3, fuse_adam=0)
+    e.set_skill_table(table); e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd)
+    loss = e.backward(np.arange(B), inject=inj)
+    assert e.range_fallbacks() == 0                                          # the fp16x3 kernels ran (the activation is inside their window)
+    assert np.isfinite(loss) and abs(loss - ref_loss) <= 2e-5 * abs(ref_loss), (loss, ref_loss)
+    g = e.grads(); e.close()
+    for k in sd:
+        ref = ref_grads[k].numpy()
+        assert float(np.abs(g[k] - ref).max()) <= 3e-4 * float(np.abs(ref).max()), (k, float(np.abs(g[k] - ref).max()), float(np.abs(ref).max()))
