@@ -177,6 +177,15 @@ int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B, int64_t g
 int ntf_dw_chunks(ntf_engine* e, int32_t* n_chunks);
 int ntf_dw_chunk_range(ntf_engine* e, int32_t k, int64_t* off_weight, int64_t* off_rho, int64_t* count);
 int ntf_dw_chunk(ntf_engine* e, int32_t k);
+/* ... and of the step's HEAD (round 5).  Under data parallelism the output layer's parameters arrive by all-gather in the ranges of ntf_dw_chunk_range; a rank need not
+ * wait for all of them before its next step: ntf_step_staged_deferred_cb runs the Flipout operand producer and the forward kernel RANGE BY RANGE (ntf_fwd_ranges: up to
+ * four ranges of whole dW chunks, k0_k1[2 j], k0_k1[2 j + 1] = the dW chunks [k0, k1) of range j; 0 ranges: the model / arithmetic does not allow it - use
+ * ntf_step_staged_deferred) and calls `before_range(j, user)` on the calling thread in front of range j: the caller makes the engine's stream wait for the all-gathers of
+ * that range's chunks there (e.g. torch's Work.wait()), so that RCCL moves range j + 1 while the forward kernel works on range j.  A non-zero return aborts the step
+ * (NTF_ESTATE).  Everything else is ntf_step_staged_deferred.  No counterpart in the reference (src/__config__.yaml:10 "TODO: multiple gpus"). */
+int ntf_fwd_ranges(ntf_engine* e, int32_t B, int32_t* n_ranges, int32_t* k0_k1);
+int ntf_step_staged_deferred_cb(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, float* loss_out,
+                                int (*before_range)(int32_t range, void* user), void* user);
 int ntf_param_segment(ntf_engine* e, int layer, int kind, int64_t* off, int64_t* count);
 
 /* expert-sharded output layer (ntf_config.expert_lo ..): one train step on the whole minibatch order[offset, offset + B) in three phases.

@@ -42,6 +42,7 @@ struct StepCtx {
                              // GLOBAL row position, so a sharded step draws exactly what the single-process step would draw
     bool defer_dw = false;   // leave the output layer's dW kernel to ntf_dw_chunk (data-parallel overlap with the all-reduce)
     bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
+    int (*chunk_cb)(int32_t, void*) = nullptr; void* chunk_user = nullptr;   // data-parallel pipelining: called in front of every forward range (ntf_step_staged_deferred_cb)
     int ub = 0;              // nsd = unigram_b: which of the two staged per-batch alias tables is THIS batch's
     int part = 0;            // expert-sharded step: 1 = forward + loss (leaves the partial d(hidden)), 2 = the output layer's backward, 3 = the hidden layers' backward (0 = whole step)
 };
@@ -118,13 +119,15 @@ struct ntf_engine {
     // touched the output layer's parameters or the operand buffers (Wp, split planes); d_kl[2] / d_range[4] hold that step's KL and range flag until it starts
     int merge_bias = 1;               // NTF_MERGE_BIAS=0: the next step's output-bias operand as k_head's bias workgroups in a launch of their own behind the bias Adam, as in round 4 (A/B runs)
     uint64_t spec_step = 0;           // step + 1 whose special-entry list (k_special_list) is in that step's workspace set
-    int fix_in_fwd = 1;               // NTF_FIX_IN_FWD=0: the sparse fix-up between the forward and the dW kernel on the main stream, as in round 4 (A/B runs)
+    int dp_ranges = 1;                // NTF_DP_RANGES=0: a data-parallel rank waits for every parameter all-gather before its step, as in round 4 (A/B runs, tests)
+    int fix_in_fwd = 0;               // NTF_FIX_IN_FWD=1 (experiment, measured 0.008-0.015 ms SLOWER: DESIGN.md section 4.0): the forward kernel handles the special entries itself, the sparse fix-up leaves the main stream
     int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
     bool pre_rotated = false;         // ... and whose KL / range-flag scalars the previous step's last kernel already moved into place
     bool fin_pend = false; NormalSpec fin_eps; float fin_klw = 0.f;   // the output layer's bias-gradient finalisation rides in the Adam launch that follows (fused-Adam steps)
     // data-parallel pipelining: the output layer's dW kernel deferred by ntf_step_staged_deferred, launched by ntf_dw_chunk
+    int (*cb_fn)(int32_t, void*) = nullptr; void* cb_user = nullptr;   // ntf_step_staged_deferred_cb -> the step's StepCtx
     bool pend_valid = false; FusedDw pend; NormalSpec pend_eps_b; float pend_klw_b = 0.f; int pend_chunks = 0;
     // unigram_b staging (sparse per-batch alias table)
     std::vector<int32_t> ub_entries; void* ub_host[2] = {nullptr, nullptr}; void* ub_dev[2] = {nullptr, nullptr}; hipEvent_t ub_ev[2] = {nullptr, nullptr};
@@ -242,6 +245,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* fx = getenv("NTF_FIX_IN_FWD")) e->fix_in_fwd = atoi(fx);
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
+    if (const char* dr = getenv("NTF_DP_RANGES")) e->dp_ranges = atoi(dr);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
@@ -824,6 +828,32 @@ static int dw_launch_whole(ntf_engine* e, const FusedDw& f) {
 #endif
 }
 
+// Data-parallel pipelining of the step's head (round 5).  The parameters of the output layer arrive by all-gather in the dW chunks' ranges (ntf_dw_chunk_range: 65 536
+// experts each); instead of waiting for all of them, producing the operands of the whole layer and then launching the forward kernel, the step runs the operand producer
+// and the forward kernel RANGE BY RANGE (up to four ranges of whole dW chunks), each behind its own chunks' all-gathers: while the forward kernel works on range j, RCCL
+// moves range j + 1.  fwd_ranges: number of ranges (0: the shape / arithmetic does not allow it); range j = dW chunks [k0, k1), 64-expert tiles [t_lo, t_hi) on `ncg`
+// column groups whose dh slabs / loss partials start at cg_off.
+struct FwdRange { int k0, k1, t_lo, t_hi, ncg, cg_off; };
+static int fwd_ranges(const ntf_engine* e, int B, FwdRange* out, int* ncg_tot) {
+    if (!fused_ok(e) || !e->cfg.bayesian || e->layers[e->L - 1].in != 128 || !e->pl_wp || !e->pl_mu || e->L < 2) return 0;
+    if (!(e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3) || !(e->fwd_kernel < 0 || e->fwd_kernel == 5) || e->ep) return 0;
+    const int M = e->cfg.dims[e->L], tile = fused_dw_tile(), total = (M + tile - 1) / tile, nchunk = (total + 255) / 256;
+    const int nrb = fused_ldb(B) / 128;
+    const int nf = std::min({4, nchunk, nrb});
+    if (nf < 2) return 0;
+    const int T = (M + 63) / 64;
+    int off = 0;
+    for (int j = 0; j < nf; ++j) {
+        FwdRange r;
+        r.k0 = (int)((int64_t)j * nchunk / nf); r.k1 = (int)((int64_t)(j + 1) * nchunk / nf);
+        r.t_lo = std::min(T, r.k0 * 1024); r.t_hi = std::min(T, r.k1 * 1024);      // a dW chunk = 256 tiles of 256 experts = 1 024 tiles of 64
+        r.ncg = std::max(1, std::min(256 / nrb, r.t_hi - r.t_lo)); r.cg_off = off; off += r.ncg;
+        if (out) out[j] = r;
+    }
+    if (ncg_tot) *ncg_tot = off;
+    return nf;
+}
+
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
 static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     int r;
@@ -841,6 +871,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
     const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
     bool hp_hit = false, hp_stale = false;
+    FwdRange fr[4]; int fr_tot = 0;
+    const int nfr = (c.chunk_cb && c.defer_dw && c.train && c.part == 0 && !c.inj && e->dp_ranges) ? fwd_ranges(e, B, fr, &fr_tot) : 0;      // > 0: producer + forward kernel range by range
     if (fused) e->fws = e->fws_set[c.step & 1];     // (every kernel of a step works in ONE of the two workspace sets: a prefetched head of step t + 1 fills the other beside step t's dW kernel)
     if (c.part >= 2) goto backward;   // expert-sharded step, later phases
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
@@ -873,7 +905,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if ((r = side_stream(e))) return r;
         HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
         StreamRestore guard{e, e->st};
-        if (e->cfg.bayesian && !use_pre) {
+        if (e->cfg.bayesian && !use_pre && !nfr) {
             HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
             e->st = e->st3;
             { Scope t(e, F_FLIPOUT_OPERAND);
@@ -913,7 +945,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.dh = e->L > 1 ? e->dAct[(e->L - 1) & 1] : nullptr;
         f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
         if (e->cfg.bayesian) {
-            if (!prod_side && !use_pre) { Scope t(e, F_FLIPOUT_OPERAND);
+            if (!prod_side && !use_pre && !nfr) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
                                      1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e)); }   // + the split planes of Wp and mu
             if (!aux && !use_head) { Scope t(e, F_FLIPOUT_OPERAND);
@@ -982,6 +1014,24 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             } else { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
         } else
 #endif
+        if (nfr) {
+            // range by range: the caller's callback orders this stream behind the all-gathers of the range's parameter chunks; then its operands (eps, sigma eps, the
+            // fp16 planes of sigma eps and mu, its share of the KL) and its forward launch.  The whole-layer exact-f32 launch of a range fallback follows the last range.
+            f.planes_ready = 1; f.split_fallback = 1; f.chunk_ncg_tot = fr_tot;
+            for (int j = 0; j < nfr; ++j) {
+                if (c.chunk_cb(j, c.chunk_user) != 0) FAIL(e, NTF_ESTATE, "step_staged_deferred_cb: the chunk callback reported a failure");
+                const int64_t r0 = (int64_t)fr[j].t_lo * 64, r1 = std::min<int64_t>((int64_t)fr[j].t_hi * 64, M), o0 = r0 * lo.in, n0 = (r1 - r0) * lo.in;
+                { Scope t(e, F_FLIPOUT_OPERAND);
+                  NormalSpec es = normal_spec(e, c, e->L - 1, T_EPS_W); es.qbase += o0 / 4;
+                  const int64_t pl0 = r0 / 32 * (32 * mfma_np(e)) * lo.in;      // the planes of 32-expert tile r0 / 32 (fused_planes_elems layout)
+                  launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT] + o0, f.mu + o0, n0, es, e->Wp[e->L - 1] + o0, 1.0 / out_nw, e->d_kl,
+                                         e->pl_wp + pl0, e->pl_mu + pl0, f.mu + o0, lo.in, mfma_np(e), kW16Scale, range_ptr(e)); }
+                f.chunk_t_lo = fr[j].t_lo; f.chunk_t_hi = fr[j].t_hi; f.chunk_cg_off = fr[j].cg_off; f.chunk_ncg = fr[j].ncg;
+                { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
+            }
+            f.chunk_ncg = 0;
+            { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 8); }
+        } else
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
         if (early_fork) {
             if ((r = side_stream(e))) return r;
@@ -1300,6 +1350,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
     c.defer_dw = defer_dw && train && !apply && fused_ok(e);
     c.row0 = row0;
+    if (c.defer_dw) { c.chunk_cb = e->cb_fn; c.chunk_user = e->cb_user; }
     e->pend_valid = false;
     if ((r = stage_rows(e, rows, B, rows_on_device, &c.rows_dev))) return r;
     if ((r = stage_all_inj(e, c))) return r;
@@ -1377,6 +1428,28 @@ extern "C" int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B
         FAIL(e, NTF_EINVAL, "step_staged_deferred: shard / batch outside the staged order");
     return step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, true, false, true, e->h_order.data() + global_offset, global_B, true,
                        (uint32_t)(offset - global_offset));
+}
+// ---- data-parallel pipelining of the head (see fwd_ranges): the ranges, and the deferred step with a callback in front of every range
+extern "C" int ntf_fwd_ranges(ntf_engine* e, int32_t B, int32_t* n_ranges, int32_t* k0_k1 /* nullable: 2 x 4 ints, dW chunks [k0, k1) of each range */) {
+    if (!e || !n_ranges) return NTF_EINVAL;
+    FwdRange fr[4]; int tot = 0;
+    const int n = (B >= 1 && B <= e->cfg.max_batch && e->dp_ranges) ? fwd_ranges(e, B, fr, &tot) : 0;
+    *n_ranges = n;
+    if (k0_k1) for (int j = 0; j < n; ++j) { k0_k1[2 * j] = fr[j].k0; k0_k1[2 * j + 1] = fr[j].k1; }
+    return NTF_OK;
+}
+extern "C" int ntf_step_staged_deferred_cb(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, float* loss_out,
+                                           int (*before_range)(int32_t range, void* user), void* user) {
+    if (!e) return NTF_EINVAL;
+    const int64_t n = (int64_t)e->h_order.size();
+    if (offset < 0 || B < 1 || offset + B > n || global_offset < 0 || global_offset + global_B > n || offset < global_offset ||
+        offset + B > global_offset + global_B)
+        FAIL(e, NTF_EINVAL, "step_staged_deferred_cb: shard / batch outside the staged order");
+    e->cb_fn = before_range; e->cb_user = user;
+    const int rc = step_common(e, e->d_order + offset, B, global_B, nullptr, loss_out, true, false, true, e->h_order.data() + global_offset, global_B, true,
+                               (uint32_t)(offset - global_offset));
+    e->cb_fn = nullptr; e->cb_user = nullptr;
+    return rc;
 }
 static int dw_chunk_span(ntf_engine* e, int k, int64_t& off_w, int64_t& off_r, int64_t& cnt, int& wg_begin) {
     const LayerInfo& li = e->layers[e->L - 1];

@@ -32,6 +32,10 @@ struct FusedOut {
     int ncg_limit = 0;                              // > 0 (diagnostics, NTF_COSCHED): at most this many column groups, i.e. a forward grid of NRB * ncg_limit workgroups that leaves CUs free
     int fix_in_fwd = 0;                             // np = 2 training step on k_out_fwd_h3p: the forward kernel corrects the special entries of dzT itself (phase 4 then leaves dzT alone)
     int split_fallback = 0;                         // the exact-f32 forward launch behind the split-product kernel is NOT part of phase 2 but a phase of its own (8)
+    // the split-product forward over a RANGE of the experts (k_out_fwd_h3p only; data-parallel ranks launch one range per all-gathered parameter chunk): 64-expert tiles
+    // [chunk_t_lo, chunk_t_hi) on chunk_ncg column groups, whose dh slabs / loss partials are chunk_cg_off .. of chunk_ncg_tot in all.  chunk_ncg_tot > 0 with chunk_ncg = 0:
+    // not a launch of a range but the phases behind them (4: the fix-up sums chunk_ncg_tot partials; 8 with split_fallback: the whole-layer exact-f32 launch)
+    int chunk_t_lo = 0, chunk_t_hi = 0, chunk_cg_off = 0, chunk_ncg = 0, chunk_ncg_tot = 0;
     int planes_ready = 0;
     int h_ready = 0;                                // the zero-padded h, h * s_in and the s_in words are in the workspace already (ntf_head.hip): phase 1 skips k_prep_h
     // inference (train = 0, probs = 1): dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale instead of the loss; the row entropy partials go to the workspace

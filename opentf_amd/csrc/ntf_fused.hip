@@ -24,7 +24,7 @@ int64_t fused_planes_elems(int M, int H) { return ((int64_t)M + 63) / 64 * 64 * 
 bool fused_supported(int H) { return H == 32 || H == 64 || H == 128; }
 int fused_loss_slots(int) { return 0; }
 
-int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)NCG_MAX * BM * H; }
+int64_t fused_dh_slab_floats(int, int H, int) { return (int64_t)4 * NCG_MAX * BM * H; }   // (x 4: up to four range launches of the forward kernel, each with its own column groups)
 
 size_t fused_workspace_bytes(int B, int H, int M) { return ws_layout(B, H, M).total; }
 FusedWsPtrs fused_ws_ptrs(void* ws_, int B, int H, int M) {
@@ -362,6 +362,8 @@ struct SpecialArgs {
     const int* rflag;
     int c_lo;              // expert shard: labels and negatives name GLOBAL expert ids, this launch owns [c_lo, c_lo + M)
     const uint16_t* wp_pl; float wp_inv_scale;   // fp16x3 step: sigma * eps as the two fp16 planes the forward kernel multiplied with (k_out_fwd_h3x's tile layout); null: the f32 copy `wp`
+    int fb_ncg;            // > 0: the split-product forward ran as several range launches (NCG / nslab count THEIR column groups); a step that fell back to the exact-f32 kernels
+                           // has the whole-layer launch's fb_ncg column groups instead
     int dz_in_fwd;         // the forward kernel (k_out_fwd_h3p) handled the special entries itself (dz in dzT, loss terms in its loss partials, d(hidden) terms in its slabs): this
                            // kernel only sums the partials and reads no weight - unless *rflag is raised (then the f32 kernels ran and the entries are this kernel's)
 };
@@ -463,8 +465,9 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
     auto hidx = [&](int k) { return QUAD ? 8 * l + k : l + 64 * k; };      // this lane's k-th hidden unit
     const bool packed = p.dz_pack_scale > 0.f && !(p.rflag && *p.rflag);
     const bool wp_planes = BAYES && QUAD && p.wp_pl != nullptr && !(p.rflag && *p.rflag);   // (a step that fell back to the f32 kernels: its planes are saturated, the f32 copy was made for it)
+    const int ncg = (p.fb_ncg > 0 && p.rflag && *p.rflag) ? p.fb_ncg : p.NCG, nslab = (p.fb_ncg > 0 && p.rflag && *p.rflag) ? p.fb_ncg : p.nslab;
     float rl = 0.f;
-    for (int cg = lane; cg < p.NCG; cg += 64) rl += p.lossp[(int64_t)i * p.NCG + cg];
+    for (int cg = lane; cg < ncg; cg += 64) rl += p.lossp[(int64_t)i * ncg + cg];
     rl = wave_reduce_sum(rl);
     float acc[NV], hr[NV], hsr[NV];
 #pragma unroll
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
         if (j < H) { hr[k] = p.h[(int64_t)i * H + j]; if (BAYES) hsr[k] = p.hs[(int64_t)i * H + j]; }
     }
     if (TRAIN && DH) {
-        for (int cg = q; cg < p.nslab; cg += NQ) {
+        for (int cg = q; cg < nslab; cg += NQ) {
             const float* sl = p.slab + ((int64_t)cg * p.Bpad + i) * H;
 #pragma unroll
             for (int k = 0; k < NV; ++k) { const int j = hidx(k); if (j < H) acc[k] += sl[j]; }
@@ -1429,7 +1432,8 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int cg = bid / p.NRB, rb = bid % p.NRB;
-    const int s_beg = 2 * (int)((int64_t)cg * p.T / p.NCG), s_end = 2 * (int)((int64_t)(cg + 1) * p.T / p.NCG);   // p.T = 64-expert tiles; s = 32-expert sub-tiles
+    const int tspan = p.t_hi - p.t_lo;      // (a launch over a range of the experts: OutFwdArgs.t_lo)
+    const int s_beg = 2 * (p.t_lo + (int)((int64_t)cg * tspan / p.NCG)), s_end = 2 * (p.t_lo + (int)((int64_t)(cg + 1) * tspan / p.NCG));   // 64-expert tiles -> 32-expert sub-tiles
     const int i0 = rb * BM + pair * 32;
     const int i = i0 + il;
     const bool row_ok = i < p.B;
@@ -1535,14 +1539,14 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                 }
             }
             if (have_h) {       // (quarter-uniform) this row had entries here: its slab row and loss partial, written by this workgroup's waves above, take the corrections
-                float* sl = p.slab + ((int64_t)cg * p.Bpad + irow) * H + 8 * l16;
+                float* sl = p.slab + ((int64_t)(cg + p.cg_off) * p.Bpad + irow) * H + 8 * l16;
                 float cur[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) cur[k] = __hip_atomic_load(sl + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1: the row was stored by another wave)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) sl[k] = cur[k] + dv[k];
                 if (l16 == 0) {
-                    float* lp = p.lossp + (int64_t)irow * p.NCG + cg;
+                    float* lp = p.lossp + (int64_t)irow * p.ncg_tot + p.cg_off + cg;
                     *lp = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + lfix;
                 }
             }
@@ -1731,7 +1735,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         stamp_out(s_end - s_beg);
         float lsum = lacc.sum;
         lsum += __shfl_xor(lsum, 32, 64);
-        if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
+        if (half == 0) p.lossp[(int64_t)i * p.ncg_tot + p.cg_off + cg] = p.tnw * lsum;
         fix_dz();
         return;
     }
@@ -1878,7 +1882,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                 const float y2 = Y2[jt][r] * pp.u_dh;
                 v += ((w >> il) & 1u) ? -y2 : y2;
             }
-            p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
+            p.slab[((int64_t)(cg + p.cg_off) * p.Bpad + irow) * H + 32 * jt + il] = v;
         }
     }
     fix_dz();
@@ -1930,9 +1934,11 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     a.tnw = f.tnw; a.inv_B = f.inv_B; a.dzT = f.dzT; a.slab = f.dh_slab; a.lossp = lossp;
     a.so_k0 = f.s_out.k0; a.so_k1 = f.s_out.k1; a.si_k0 = f.s_in.k0; a.si_k1 = f.s_in.k1; a.so_inj = f.s_out.inj != nullptr; a.si_inj = f.s_in.inj != nullptr;
     a.rflag = f.rflag; a.rmode = 0;
+    a.t_lo = 0; a.t_hi = g.T; a.cg_off = 0; a.ncg_tot = g.NCG;
+    const bool ranged = f.chunk_ncg_tot > 0;      // the split-product forward of this step runs (ran) as launches over ranges of the experts (FusedOut.chunk_*)
     SpecialArgs s;
-    s.B = f.B; s.M = f.M; s.Bpad = g.Bpad; s.NCG = g.NCG; s.nCB = g.nCB; s.ns = f.ns;
-    s.nslab = g.NCG;
+    s.B = f.B; s.M = f.M; s.Bpad = g.Bpad; s.NCG = ranged ? f.chunk_ncg_tot : g.NCG; s.nCB = g.nCB; s.ns = f.ns;
+    s.nslab = s.NCG; s.fb_ncg = ranged ? g.NCG : 0;
     s.h = f.h; s.hs = hs; s.mu = f.mu; s.mu_b = f.mu_b; s.wp = f.wp; s.bp = f.bp; s.slab = f.dh_slab; s.lossp = lossp; s.h_mask = f.h_mask;
     s.sbits = sbits; s.sinbits = sinbits; s.rows = f.rows; s.m_indptr = f.m_indptr; s.neg = f.neg; s.m_indices = f.m_indices;
     s.tpw = f.tpw; s.tnw = f.tnw; s.inv_B = f.inv_B; s.dzT = f.dzT; s.dh = f.dh; s.row_fix = f.row_fix;
@@ -1942,7 +1948,9 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     // the wave-pair forward kernel corrects the special entries of dzT itself (FusedOut.fix_in_fwd): the fix-up kernel then leaves dzT alone unless the step fell back to f32
     const bool fwd_fixes = f.fix_in_fwd && f.bf16x6 && f.H == 128 && f.np == 2 && f.train && f.dh != nullptr && f.wide == 5 && !f.probs;
     s.dz_in_fwd = fwd_fixes ? 1 : 0;
-    const int grid = g.NRB * g.NCG;
+    int grid = g.NRB * g.NCG;
+    const bool range_launch = ranged && f.chunk_ncg > 0 && (phases & 2);      // THIS call launches one range
+    if (range_launch) { a.t_lo = f.chunk_t_lo; a.t_hi = f.chunk_t_hi; a.cg_off = f.chunk_cg_off; a.ncg_tot = f.chunk_ncg_tot; a.NCG = f.chunk_ncg; grid = g.NRB * f.chunk_ncg; }
     if (f.bf16x6 && f.H == 128) {
         const int np = f.np == 2 ? 2 : 3;
         if ((phases & 1) && !f.planes_ready) {
@@ -2040,7 +2048,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #else
             constexpr bool skip_fb = false;
 #endif
-            if (guard && np == 2 && !f.probs && !merged_fallback && !skip_fb && !f.split_fallback) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
+            if (guard && np == 2 && !f.probs && !merged_fallback && !skip_fb && !f.split_fallback && !range_launch) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
                 OutFwdArgs af = a; af.rmode = 2;
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
             }

@@ -119,6 +119,9 @@ struct LossAcc {
 
 struct OutFwdArgs {
     int B, M, Bpad, NRB, NCG, T, nCB;
+    // k_out_fwd_h3p on a RANGE of the experts (data-parallel ranks: one launch per all-gathered chunk of the parameters): the launch's NCG column groups walk the
+    // 64-expert tiles [t_lo, t_hi) and write the dh slabs / loss partials cg_off .. cg_off + NCG - 1 of ncg_tot.  Whole layer: t_lo = 0, t_hi = T, cg_off = 0, ncg_tot = NCG
+    int t_lo, t_hi, cg_off, ncg_tot;
     const float *h, *hs, *mu, *mu_b, *wp, *bp;
     const uint32_t *sbits, *sinbits;
     uint32_t so_k0, so_k1, si_k0, si_k1;   // native sign generators; *_inj != 0: read the packed images instead (injected signs)

@@ -143,7 +143,8 @@ class DataParallel:
         self._param = engine.param_tensor() if self.shard else None
         # gloo (the CPU tests) has no reduce-scatter: there it is an all-reduce of which this rank keeps its part - same result
         self._native_rs = (not self.emulate) and dist.is_initialized() and dist.get_backend(group) == "nccl"
-        self._pending = []   # parameter all-gathers of the previous step
+        self._pending = []   # parameter all-gathers of the previous step ...
+        self._pending_chunk = {}   # ... those of the output layer's dW chunks by chunk index: a step whose head is pipelined waits for them range by range
         self.trace = CollectiveTrace(f"DataParallel rank {self.rank}/{self.world}", stream_ordered=self._native_rs)
         self._step_no = 0
         if self._grad.is_cuda and (self.world > 1 or self.force_allreduce) and hasattr(engine, "stream_handle"):
@@ -198,11 +199,17 @@ class DataParallel:
         if hasattr(self.engine, "skip_step"):
             self.engine.skip_step()
 
-    def _finish_gathers(self):
-        touched = bool(self._pending)
+    def _finish_gathers(self, keep_chunks=False):
+        """wait for the parameter all-gathers of the previous step; keep_chunks: all but those of the output layer's dW chunks (the pipelined head waits for them itself)"""
+        touched = bool(self._pending) or bool(self._pending_chunk)
         for w in self._pending:
             self.trace.wait(w)
         self._pending = []
+        if not keep_chunks:
+            for k in sorted(self._pending_chunk):
+                for w in self._pending_chunk[k]:
+                    self.trace.wait(w)
+            self._pending_chunk = {}
         if touched and hasattr(self.engine, "params_touched"):
             self.engine.params_touched()      # the all-gather wrote the parameters through the raw view (include/opentf_amd.h: ntf_params_touched)
 
@@ -211,20 +218,32 @@ class DataParallel:
         e, have_rows = self.engine, hi > lo
         self._step_no += 1
         self.emulated_bytes["steps"] += 1
-        self._finish_gathers()            # the parameters this step reads are complete
+        # Pipelined head (round 5, engine.fwd_ranges): the output layer's operand producer and forward kernel run range by range, each behind the all-gathers of ITS dW
+        # chunks only - RCCL moves the next range while the forward kernel works on this one.  Everything else the step reads (hidden layers, biases: updated on every
+        # rank) is complete before it starts.
+        spans = self.engine.fwd_ranges(hi - lo) if (have_rows and self.n_chunks and self.shard and self._pending_chunk and hasattr(self.engine, "fwd_ranges")) else []
+        self._finish_gathers(keep_chunks=bool(spans))
         works, owned, gathered = [], [], []
+
+        def before_range(j):
+            for k in range(spans[j][0], spans[j][1]):
+                for w in self._pending_chunk.pop(k, ()):
+                    self.trace.wait(w)
         reduce = (lambda a, b: self._reduce_scatter(a, b, owned, works)) if self.shard else (lambda a, b: works.append(self._all_reduce(a, b)))
         if self.n_chunks:
-            if have_rows:
+            if have_rows and spans:
+                e.step_staged_deferred(goff + lo, hi - lo, goff, gB, before_range=before_range)
+                self._finish_gathers()            # (every chunk belongs to a range: nothing is left; kept as the invariant)
+            elif have_rows:
                 e.step_staged_deferred(goff + lo, hi - lo, goff, gB)
             else:
                 self._skip()
             for k, (ow, orr, cnt) in enumerate(self._chunk_ranges):
                 if have_rows:
                     e.dw_chunk(k)                     # queue chunk k's kernel ...
-                reduce(ow, ow + cnt); gathered.append((ow, ow + cnt))   # ... and let RCCL take its gradients as soon as it finishes
+                reduce(ow, ow + cnt); gathered.append((k, ow, ow + cnt))   # ... and let RCCL take its gradients as soon as it finishes
                 if orr >= 0:
-                    reduce(orr, orr + cnt); gathered.append((orr, orr + cnt))
+                    reduce(orr, orr + cnt); gathered.append((k, orr, orr + cnt))
             for rlo, rhi in self._rest:               # hidden layers, biases: small, replicated update
                 works.append(self._all_reduce(rlo, rhi)); owned.append((rlo, rhi))
         else:
@@ -233,14 +252,17 @@ class DataParallel:
             else:
                 self._skip()
             n = self._grad.numel()
-            reduce(0, n); gathered.append((0, n))
+            reduce(0, n); gathered.append((None, 0, n))
         for w in works:
             self.trace.wait(w)
         if not self.shard:
             e.apply()
             return
         e.apply_ranges(sorted(owned))
-        self._pending = [self._all_gather(a, b) for a, b in gathered]
+        for k, a, b in gathered:
+            w = self._all_gather(a, b)
+            if k is None: self._pending.append(w)
+            else: self._pending_chunk.setdefault(k, []).append(w)
 
     def _phase(self, order, global_B, train):
         """One `for batch in loader` phase (src/mdl/fnn.py:118) over `order`; returns the mean batch loss."""

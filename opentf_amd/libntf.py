@@ -18,6 +18,7 @@ INPUT_DENSE, INPUT_MEANPOOL, INPUT_MULTIHOT = 0, 1, 2
 NSD = {None: 0, "": 0, "None": 0, "uniform": 1, "unigram": 2, "unigram_b": 3}
 P_WEIGHT, P_BIAS, P_RHO_WEIGHT, P_RHO_BIAS = 0, 1, 2, 3
 
+_RANGE_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p)
 _LIB_PATH = os.environ.get("NTF_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libopentf_amd.so")   # (NTF_LIB_PATH: A/B builds of the same ABI)
 
 
@@ -62,6 +63,8 @@ SYMBOLS = {
     "ntf_head_prefetch_hits": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_get_dlogits": (C.c_int, [_P, _P, _I64]),
     "ntf_get_negatives": (C.c_int, [_P, _P, _I64]),
+    "ntf_fwd_ranges": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ntf_step_staged_deferred_cb": (C.c_int, [_P, _I64, C.c_int32, _I64, C.c_int32, _P, _RANGE_CB, _P]),
     "ntf_get_noise": (C.c_int, [_P, _U64, C.c_int32, C.c_int32, C.c_int32, _P, _I64]),
     "ntf_train_step": (C.c_int, [_P, _P, _I32, _P, _P]),
     "ntf_eval_step": (C.c_int, [_P, _P, _I32, _P, _P]),
@@ -427,8 +430,30 @@ class Engine:
         return torch.as_tensor(DeviceView(p.value, n.value, self), device=f"cuda:{torch.cuda.current_device()}")
 
     # ---- data-parallel pipelining (see include/opentf_amd.h)
-    def step_staged_deferred(self, offset, B, global_offset, global_B):
-        self._ck(lib().ntf_step_staged_deferred(self._h, int(offset), int(B), int(global_offset), int(global_B), None))
+    def step_staged_deferred(self, offset, B, global_offset, global_B, before_range=None):
+        """before_range(j): called in front of forward range j (see fwd_ranges) - the caller orders the engine's stream behind that range's parameter all-gathers there"""
+        if before_range is None:
+            self._ck(lib().ntf_step_staged_deferred(self._h, int(offset), int(B), int(global_offset), int(global_B), None))
+            return
+        failure = []
+
+        def _cb(j, _user):
+            try:
+                before_range(int(j))
+                return 0
+            except BaseException as ex:      # (never let an exception cross the C frame: report it, re-raise below)
+                failure.append(ex)
+                return 1
+        cb = _RANGE_CB(_cb)
+        rc = lib().ntf_step_staged_deferred_cb(self._h, int(offset), int(B), int(global_offset), int(global_B), None, cb, None)
+        if failure: raise failure[0]
+        self._ck(rc)
+
+    def fwd_ranges(self, B):
+        """[(k0, k1), ...]: the dW chunks of each forward range of a data-parallel step of B rows (empty: the head is not pipelined for this model)"""
+        n = C.c_int32(); spans = (C.c_int32 * 8)()
+        self._ck(lib().ntf_fwd_ranges(self._h, int(B), C.byref(n), spans))
+        return [(int(spans[2 * j]), int(spans[2 * j + 1])) for j in range(n.value)]
 
     def dw_chunks(self):
         n = C.c_int32()

@@ -153,7 +153,8 @@ def test_a_row_with_an_outlier_activation_keeps_the_loss_finite():
     """Found by the replay work (round 5): k_out_fwd_h3p takes ONE v_log_f32 for four experts' softplus terms - log((1 + e^-l0)(1 + e^-l1)(1 + e^-l2)(1 + e^-l3)) - and
     that product overflows once four logits of a row average below -22, i.e. pre-activations below -2 200 under leaky_relu: one team with an outlier embedding at step
     1 134 of the benchmark's own run made the step's loss NaN (inf through the compensated sum; the gradients were right - they never went through it).  The kernel now
-    clamps l at -21 (softplus and its slope below 7.6e-10 there).  Here: one row whose hidden activation is ~2 000 - hundreds of its logits fall below -22 - through the
+    clamps l at -21 (softplus and its slope below 7.6e-10 there).  Here: rows whose hidden activation is ~2 000 under output weights ten times the initial scale - thousands
+    of logits below -22, runs of four among them - through the
     default training step (injected noise) against the oracle: loss finite and equal to 2e-5, every gradient to 3e-4 of its maximum."""
     import torch
     from conftest import draw_noise
@@ -164,6 +165,7 @@ def test_a_row_with_an_outlier_activation_keeps_the_loss_finite():
     D, H, M, B, S = 128, 128, 8000, 128, 300
     skill, table, member = _dataset(rng, B, S, D, M, 4.0, 2.5)
     sd = O.bnn_init(D, [H], M)
+    sd["layers.1.mu_weight"] *= 10.0                                     # (weights of a trained model's scale: with |h| ~ 2 000 a third of the outlier row's pre-activations fall below -2 250)
     row = 7
     s0 = int(skill[1][skill[0][row]])                                   # one of row 7's skills: its embedding scaled until the largest hidden activation of the batch reaches ~2 000
     base = table[s0].copy()
