@@ -441,8 +441,7 @@ def test_bench_multi_rank_launch_on_one_gpu(parallel):
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--validate-on-one-gpu", "--parallel", parallel,
            "--rows", "20000", "--experts", "4096"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root, env={**os.environ, "NTF_BENCH_MIN_TIMED_S": "0.05"})
-    if fail.startswith("ep_weak:build"): assert p.returncode == 0, p.stderr.decode()[-3000:]
-    else: assert p.returncode != 0, "a leg that failed while running must not look like success"
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
