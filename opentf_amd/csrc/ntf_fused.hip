@@ -1629,11 +1629,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(dzv[q], dz_rsrc, dz_voff, (32 * u + 8 * q) * 128, 0);
         };
         for (int s = s_beg; s <= s_end + 1; ++s) {
-#ifndef H3P_ZFIRST
-            if (s - 2 >= s_beg) load_dz(s - 2);
-#else
-            if (s - 2 >= s_beg && s >= s_end) load_dz(s - 2);
-#endif
+            if (s - 2 >= s_beg) load_dz(s - 2);      // (round 5: issued behind the first weight fragments instead, these reads cost the kernel +0.006 ms - profiles/r5_gap_experiments.md)
             if (s - 2 >= s_beg && s >= s_end) store_dz(s - 2);      // (behind the last sub-tiles; otherwise after this step's MFMAs, below)
             if (s < s_end) {
                 mask_past_m(s);
@@ -1665,9 +1661,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
                 };
 #pragma unroll
                 for (int k = 0; k < BG; ++k) z_load(k, fb[0][k]);
-#ifdef H3P_ZFIRST
-                if (s - 2 >= s_beg) load_dz(s - 2);          // (experiment: the first weight fragments in front of the packed dz in the LDS queue)
-#endif
                 stamp(4);
                 const int sn = min(s + 1, s_end - 1);       // behind the last sub-tile the free stage takes that sub-tile once more
 #pragma unroll
