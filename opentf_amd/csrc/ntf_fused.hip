@@ -9,11 +9,12 @@
 //               layout is exactly the A-operand layout of the next MFMA when it sums over the accumulator's rows).
 //               Weight tiles arrive by LDS-DMA (global_load_lds_dwordx4), double buffered, XOR-swizzled on the
 //               source address so that both the ds_read_b128 fragment reads and the DMA writes are conflict free.
-//   k_out_special  one wave per team: sparse fix-up for the positives / sampled negatives (labels stay CSR),
+//   k_out_special  (ntf_special.hip since round 5) one wave per team: sparse fix-up for the positives / sampled negatives (labels stay CSR),
 //               reduction of the per-group dh slabs, leaky_relu' mask.
 //   k_out_dw    dmu = dzT . h, dWp = (dzT*s_out) . (h*s_in) with K = batch, bias gradients from the A operand,
 //               Flipout rho-gradient + KL finalised in the epilogue.
 #include "ntf_fused_common.h"
+#include "ntf_special.h"
 
 namespace ntf {
 
@@ -349,222 +350,6 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd(OutFwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-struct SpecialArgs {
-    int B, M, Bpad, NCG, nCB, ns;
-    int nslab;   // dh slabs to sum (NCG)
-    const float *h, *hs, *mu, *mu_b, *wp, *bp, *slab, *lossp, *h_mask;
-    const uint32_t *sbits, *sinbits;
-    const int64_t *rows, *m_indptr, *neg; const int32_t* m_indices;
-    float tpw, tnw, inv_B;
-    float *dzT, *dh, *row_fix;
-    uint32_t so_k0, so_k1; int so_inj;
-    float dz_pack_scale;   // > 0: dzT holds packed fp16 plane pairs of dz * scale (fp16x3 step) ... unless *rflag is raised (the f32 kernels ran)
-    const int* rflag;
-    int c_lo;              // expert shard: labels and negatives name GLOBAL expert ids, this launch owns [c_lo, c_lo + M)
-    const uint16_t* wp_pl; float wp_inv_scale;   // fp16x3 step: sigma * eps as the two fp16 planes the forward kernel multiplied with (k_out_fwd_h3x's tile layout); null: the f32 copy `wp`
-    int fb_ncg;            // > 0: the split-product forward ran as several range launches (NCG / nslab count THEIR column groups); a step that fell back to the exact-f32 kernels
-                           // has the whole-layer launch's fb_ncg column groups instead
-    int dz_in_fwd;         // the forward kernel (k_out_fwd_h3p) handled the special entries itself (dz in dzT, loss terms in its loss partials, d(hidden) terms in its slabs): this
-                           // kernel only sums the partials and reads no weight - unless *rflag is raised (then the f32 kernels ran and the entries are this kernel's)
-};
-
-// The special entries of a team - its positives (member CSR row) and its sampled negatives - as the sparse fix-up visits them: entry `sidx` of the row's
-// npos + ns candidates -> (global expert id or -1, label).  A negative that names a member of the team, or repeats an earlier negative, is dropped (src/mdl/fnn.py:48-56
-// draws distinct non-members; injected indices may not be).
-__device__ __forceinline__ int special_candidate(const int32_t* __restrict__ m_indices, const int64_t* __restrict__ neg, int64_t pb, int npos, int ns, int i, int sidx, float& y) {
-    y = 0.f;
-    if (sidx < npos) { y = 1.f; return m_indices[pb + sidx]; }
-    const int qn = sidx - npos;
-    if (!neg || qn >= ns) return -1;
-    int c = (int)neg[(int64_t)i * ns + qn];
-    for (int k = 0; k < npos; ++k) if (m_indices[pb + k] == c) c = -1;
-    for (int k = 0; k < qn; ++k) if (c >= 0 && (int)neg[(int64_t)i * ns + k] == c) c = -1;
-    return c;
-}
-// The logit z (pre-activation) of one (team i, expert cc) entry by a QUARTER-WAVE of 16 lanes, lane l holding hidden units 8 l .. 8 l + 7 of h (hr) and of h * s_in (hsr):
-// z = h . mu[cc] + mu_b[cc] + s_out(i, cc) ((h s_in) . Wp[cc] + bp[cc]).  ONE function for the sparse fix-up kernel and for the forward kernel's own fix-up of dzT, with
-// the products as explicit fmaf chains, so that both give the same bits.  mu_r / wp_r: the weights it multiplied with (the caller's dh terms); so: the entry's s_out sign.
-template <bool BAYES>
-__device__ __forceinline__ float special_z16(const float* __restrict__ mu, const float* __restrict__ mu_b, const float* __restrict__ wp, const float* __restrict__ bp,
-                                             const uint16_t* __restrict__ wp_pl, float wp_inv_scale, bool wp_planes, const uint32_t* __restrict__ sbits, int nCB,
-                                             uint32_t so_k0, uint32_t so_k1, int so_inj, int i, int cc, int l, const float (&hr)[8], const float (&hsr)[8],
-                                             float (&mu_r)[8], float (&wp_r)[8], float& so) {
-    constexpr int H = 128;
-    float d1 = 0.f, d2 = 0.f;
-    {
-        const float4 a = *reinterpret_cast<const float4*>(mu + (int64_t)cc * H + 8 * l), b = *reinterpret_cast<const float4*>(mu + (int64_t)cc * H + 8 * l + 4);
-        mu_r[0] = a.x; mu_r[1] = a.y; mu_r[2] = a.z; mu_r[3] = a.w; mu_r[4] = b.x; mu_r[5] = b.y; mu_r[6] = b.z; mu_r[7] = b.w;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { d1 = fmaf(hr[k], mu_r[k], d1); wp_r[k] = 0.f; }
-    if (BAYES) {
-        if (wp_planes) {   // the lane's 8 consecutive hidden units of row cc: 16 bytes from each plane; value = (hi + lo) / scale - exactly what the dense pass multiplied with
-            typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-            const uint16_t* r0 = wp_pl + ((int64_t)(cc >> 5) * 64 + (cc & 31)) * H + 8 * l;     // [tile of 32 rows][plane][row][H]
-            const h8_t hi = *reinterpret_cast<const h8_t*>(r0), lo = *reinterpret_cast<const h8_t*>(r0 + 32 * H);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) wp_r[k] = ((float)hi[k] + (float)lo[k]) * wp_inv_scale;
-        } else {
-            const float4 a = *reinterpret_cast<const float4*>(wp + (int64_t)cc * H + 8 * l), b = *reinterpret_cast<const float4*>(wp + (int64_t)cc * H + 8 * l + 4);
-            wp_r[0] = a.x; wp_r[1] = a.y; wp_r[2] = a.z; wp_r[3] = a.w; wp_r[4] = b.x; wp_r[5] = b.y; wp_r[6] = b.z; wp_r[7] = b.w;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) d2 = fmaf(hsr[k], wp_r[k], d2);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) d1 += __shfl_xor(d1, o, 64);
-    float z = d1 + mu_b[cc];
-    so = 1.f;
-    if (BAYES) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) d2 += __shfl_xor(d2, o, 64);
-        const uint32_t sw_ = so_inj ? sbits[(int64_t)i * nCB + (cc >> 5)] : sign_word(so_k0, so_k1, (uint32_t)i, (uint32_t)(cc >> 5));
-        so = ((sw_ >> (cc & 31)) & 1u) ? -1.f : 1.f;
-        z += (d2 + bp[cc]) * so;
-    }
-    return z;
-}
-// d loss / d z of a special entry (label y, positive-weight tpw) as the fp16x3 step stores it: the two fp16 planes of dz * scale packed in a dword
-__device__ __forceinline__ float special_dz(float z, float y, float tpw, float inv_B, float& sp, float& sg, float& dact) {
-    bce_terms(z, sp, sg, dact);
-    return tpw * (sg - y) * dact * inv_B;
-}
-__device__ __forceinline__ uint32_t special_dz_packed(float dzt, float scale) { uint32_t pq[3]; split_pair_np<2>(dzt, 0.f, scale, pq); return (pq[0] & 0xFFFFu) | (pq[1] << 16); }
-
-// The special entries of every row of a batch, listed once per step: spec[row][SPEC_W] = global expert id | label << 30 of candidate k (-1: a dropped duplicate, or
-// k >= the row's candidates), spec[Bpad * SPEC_W + row] = the row's candidates npos + ns.  A quarter-wave per row, a lane per candidate.  Runs right behind the sampler
-// (auxiliary stream: for a prefetched head that is beside the previous step's dW kernel); read by the fix-up at the end of k_out_fwd_h3p.
-__global__ __launch_bounds__(256) void k_special_list(const int64_t* __restrict__ rows, int B, int Bpad, const int64_t* __restrict__ m_indptr, const int32_t* __restrict__ m_indices,
-                                                      const int64_t* __restrict__ neg, int ns, int* __restrict__ spec) {
-    const int i = (int)(blockIdx.x * 16 + (threadIdx.x >> 4)), l16 = threadIdx.x & 15;
-    if (i >= B) return;
-    const int64_t team = rows[i];
-    const int64_t pb = m_indptr[team];
-    const int npos = (int)(m_indptr[team + 1] - pb), total = npos + (neg ? ns : 0);
-    float y = 0.f;
-    const int c = l16 < total ? special_candidate(m_indices, neg, pb, npos, ns, i, l16, y) : -1;
-    spec[(int64_t)i * SPEC_W + l16] = c < 0 ? -1 : (c | (y != 0.f ? (1 << 30) : 0));
-    if (l16 == 0) spec[(int64_t)Bpad * SPEC_W + i] = total;
-}
-void launch_fused_special_list(hipStream_t st, int B, int H, int M, void* ws_, const int64_t* rows, const int64_t* m_indptr, const int32_t* m_indices, const int64_t* neg, int ns) {
-    const Geom g = geom(B, M);
-    const WsLayout w = ws_layout(B, H, M);
-    hipLaunchKernelGGL(k_special_list, dim3((B + 15) / 16), dim3(256), 0, st, rows, B, g.Bpad, m_indptr, m_indices, neg, ns, reinterpret_cast<int*>(static_cast<char*>(ws_) + w.spec));
-}
-
-// One wave per team.  H = 128: the wave works as FOUR quarter-waves of 16 lanes x 8 consecutive hidden units, each quarter taking every fourth
-// special entry (and every fourth dh slab): the ~8 dependent dot-product / reduction / BCE chains of a team run four abreast, rows are read as
-// 32-byte pieces (round 2: 55 -> ~20 us per step at B = 1000).  Other widths keep one entry at a time over the whole wave (NV values per lane).
-template <int H, bool BAYES, bool TRAIN, bool DH>
-__global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
-    constexpr bool QUAD = (H == 128);
-    constexpr int NQ = QUAD ? 4 : 1;                 // entries in flight
-    constexpr int NV = QUAD ? 8 : (H + 63) / 64;     // hidden units per lane
-    const int i = blockIdx.x, lane = threadIdx.x;
-    const int q = QUAD ? (lane >> 4) : 0, l = QUAD ? (lane & 15) : lane;
-    auto hidx = [&](int k) { return QUAD ? 8 * l + k : l + 64 * k; };      // this lane's k-th hidden unit
-    const bool packed = p.dz_pack_scale > 0.f && !(p.rflag && *p.rflag);
-    const bool wp_planes = BAYES && QUAD && p.wp_pl != nullptr && !(p.rflag && *p.rflag);   // (a step that fell back to the f32 kernels: its planes are saturated, the f32 copy was made for it)
-    const int ncg = (p.fb_ncg > 0 && p.rflag && *p.rflag) ? p.fb_ncg : p.NCG, nslab = (p.fb_ncg > 0 && p.rflag && *p.rflag) ? p.fb_ncg : p.nslab;
-    float rl = 0.f;
-    for (int cg = lane; cg < ncg; cg += 64) rl += p.lossp[(int64_t)i * ncg + cg];
-    rl = wave_reduce_sum(rl);
-    float acc[NV], hr[NV], hsr[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int j = hidx(k);
-        acc[k] = 0.f; hr[k] = 0.f; hsr[k] = 0.f;
-        if (j < H) { hr[k] = p.h[(int64_t)i * H + j]; if (BAYES) hsr[k] = p.hs[(int64_t)i * H + j]; }
-    }
-    if (TRAIN && DH) {
-        for (int cg = q; cg < nslab; cg += NQ) {
-            const float* sl = p.slab + ((int64_t)cg * p.Bpad + i) * H;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) { const int j = hidx(k); if (j < H) acc[k] += sl[j]; }
-        }
-    }
-    auto group_sum = [&](float v) {    // sum over the lanes that share one entry: a quarter (16 lanes) or the whole wave
-        if (!QUAD) return wave_reduce_sum(v);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
-    };
-    const int64_t team = p.rows[i];
-    const int64_t pb = p.m_indptr[team];
-    const int npos = (int)(p.m_indptr[team + 1] - pb);
-    // (dz_in_fwd: the wave-pair forward kernel has visited the entries; the dW + Adam kernel may be rewriting the weights beside this kernel by now)
-    const int total = (p.dz_in_fwd && !(p.rflag && *p.rflag)) ? 0 : npos + (p.neg ? p.ns : 0);
-    float fix = 0.f;
-    for (int s0 = 0; s0 < total; s0 += NQ) {       // wave-uniform trip count: the shuffles below need every lane
-        const int sidx = s0 + q;
-        float y = 0.f;
-        int c = sidx < total ? special_candidate(p.m_indices, p.neg, pb, npos, p.ns, i, sidx, y) : -1;
-        if (c >= 0) c -= p.c_lo;                   // global -> this shard's expert index (entries of other shards fall outside [0, M))
-        const bool live = c >= 0 && c < p.M;
-        const int cc = live ? c : 0;
-        float mu_r[NV], wp_r[NV], z, so = 1.f;
-        if constexpr (QUAD) z = special_z16<BAYES>(p.mu, p.mu_b, p.wp, p.bp, p.wp_pl, p.wp_inv_scale, wp_planes, p.sbits, p.nCB, p.so_k0, p.so_k1, p.so_inj, i, cc, l, hr, hsr, mu_r, wp_r, so);
-        else {
-            float d1 = 0.f, d2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int j = hidx(k);
-                mu_r[k] = 0.f; wp_r[k] = 0.f;
-                if (j < H) { mu_r[k] = p.mu[(int64_t)cc * H + j]; d1 += hr[k] * mu_r[k]; if (BAYES) { wp_r[k] = p.wp[(int64_t)cc * H + j]; d2 += hsr[k] * wp_r[k]; } }
-            }
-            d1 = group_sum(d1);
-            z = d1 + p.mu_b[cc];
-            if (BAYES) {
-                d2 = group_sum(d2);
-                const uint32_t sw_ = p.so_inj ? p.sbits[(int64_t)i * p.nCB + (cc >> 5)] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(cc >> 5));
-                so = ((sw_ >> (cc & 31)) & 1u) ? -1.f : 1.f;
-                z += (d2 + p.bp[cc]) * so;
-            }
-        }
-        float sp, sg, dact;
-        const float dzt = special_dz(z, y, p.tpw, p.inv_B, sp, sg, dact);
-        const float lz = z > 0.f ? z : z * kLeakySlope;
-        if (live && l == 0) fix += p.tpw * (sp - lz * y) - p.tnw * sp;
-        if (TRAIN && live) {
-            const float delta = dzt - p.tnw * sg * dact * p.inv_B;
-            if (l == 0) {
-                if (packed) reinterpret_cast<uint32_t*>(p.dzT)[dzt_index(c, i, p.Bpad)] = special_dz_packed(dzt, p.dz_pack_scale);
-                else p.dzT[dzt_index(c, i, p.Bpad)] = dzt;
-            }
-            if (DH) {
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    const int j = hidx(k);
-                    if (j < H) {
-                        acc[k] += delta * mu_r[k];
-                        if (BAYES) {
-                            const float si = ((p.sinbits[(int64_t)i * (H / 32) + (j >> 5)] >> (j & 31)) & 1u) ? -1.f : 1.f;
-                            acc[k] += delta * so * wp_r[k] * si;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (QUAD) {   // quarters -> one
-        fix += __shfl_xor(fix, 16, 64); fix += __shfl_xor(fix, 32, 64);
-#pragma unroll
-        for (int k = 0; k < NV; ++k) { acc[k] += __shfl_xor(acc[k], 16, 64); acc[k] += __shfl_xor(acc[k], 32, 64); }
-    }
-    if (lane == 0) p.row_fix[i] = rl + fix;
-    if (TRAIN && DH && q == 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int j = hidx(k);
-            if (j < H) {
-                float v = acc[k];
-                if (p.h_mask) v *= (p.h_mask[(int64_t)i * H + j] > 0.f) ? 1.f : kLeakySlope;
-                p.dh[(int64_t)i * H + j] = v;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // forward + loss + dz + dh of the output layer in bf16x6 arithmetic (H = 128).
 // Weights arrive pre-split: k_split_planes writes, per 32-expert tile, the three bf16 planes [32 rows][H] of mu (and of Wp); a tile
@@ -1895,7 +1680,7 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
             set_max_lds(reinterpret_cast<const void*>(kf), (int)lds); \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a);                                                    \
         }                                                                                                                 \
-        if (phases & 4) hipLaunchKernelGGL((k_out_special<H, BAYES, TR, DHF>), dim3(f.B), dim3(64), 0, st, s);            \
+        if (phases & 4) launch_out_special(st, H, BAYES, TR, DHF, s);                                                     \
     } while (0)
     if (!f.train) NTF_LAUNCH_FWD(false, false);
     else if (dh) NTF_LAUNCH_FWD(true, true);
@@ -2051,11 +1836,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
             if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
         }
         if ((phases & 4) && !f.probs) {
-#define NTF_SP(BY) do { if (!f.train) hipLaunchKernelGGL((k_out_special<128, BY, false, false>), dim3(f.B), dim3(64), 0, st, s);         \
-            else if (f.dh) hipLaunchKernelGGL((k_out_special<128, BY, true, true>), dim3(f.B), dim3(64), 0, st, s);                       \
-            else hipLaunchKernelGGL((k_out_special<128, BY, true, false>), dim3(f.B), dim3(64), 0, st, s); } while (0)
-            if (f.bayes) NTF_SP(true); else NTF_SP(false);
-#undef NTF_SP
+            launch_out_special(st, 128, f.bayes != 0, f.train != 0, f.dh != nullptr, s);
         }
         return;
     }
