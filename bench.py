@@ -152,6 +152,19 @@ def workload_label(a, ds, bayesian, multihot):
             f"h=[{a.hidden}], b={a.batch}/GPU, ns=5 {a.nsd}, tpw 10 tnw 1, Adam lr 1e-3")
 
 
+class Cfg(dict):
+    """attribute-dict standing in for the omegaconf DictConfig the reference passes (module level: the plugin pickles it into its checkpoints)"""
+    def __getattr__(self, k):
+        if k.startswith("__"): raise AttributeError(k)
+        return self.get(k)
+
+
+class NoWriter:
+    def __init__(self, log_dir=None): pass
+    def add_scalar(self, **k): pass
+    def close(self): pass
+
+
 def plugin_epoch(ds, a, device, headline_value):
     """The DROP-IN timed, not only the engine (VERDICT r4 missing #4): one fold-epoch of `opentf_amd.mdl.bnn.Bnn.learn` - the replacement of src/mdl/fnn.py:78-170 that
     src/main.py:155-193 calls - at the headline's shapes, from lil `teamsvecs` as the reference's pipeline hands them over: ingestion (lil -> CSR, uploads), the train phase
@@ -161,16 +174,6 @@ def plugin_epoch(ds, a, device, headline_value):
     import scipy.sparse
     from opentf_amd import libntf
     from opentf_amd.mdl.bnn import Bnn
-
-    class Cfg(dict):
-        def __getattr__(self, k):
-            if k.startswith("__"): raise AttributeError(k)
-            return self.get(k)
-
-    class NoWriter:
-        def __init__(self, log_dir=None): pass
-        def add_scalar(self, **k): pass
-        def close(self): pass
 
     b = a.batch
     n_tr, n_va = min(200 * b, ds["N"] * 2 // 3), min(100 * b, ds["N"] // 3)
