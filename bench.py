@@ -209,6 +209,7 @@ def plugin_epoch(ds, a, device, headline_value):
             "learn_wall_s": wall, "ingest_s": spans.get("ingest"), "train_phase_s": spans["train"], "loader_order_s": spans.get("order"), "valid_phase_s": spans.get("valid"), "checkpoint_s": spans.get("checkpoint"),
             "value_is": "train teams / (train_phase_s + loader_order_s): torch's DataLoader draws for the shuffled order, ntf_stage_order, ceil(n / b) ntf_step_staged calls, the epoch-loss read-back",
             "value": tr_rate, "unit": "teams/s", "ms_per_step": spans["train"] / (-(-n_tr // b)) * 1e3, "ratio_to_headline": tr_rate / headline_value if headline_value else None,
+            "rest_of_learn_s": wall - sum(v for v in spans.values()),   # parameter init on the host (the reference's draws), load_state_dict, the writer, engine release
             "lil_build_s_not_plugin_time": lil_s}
 
 

@@ -107,11 +107,23 @@ def test_init_draws_match_the_reference_order(tmp_path):
 
 
 def test_loader_order_consumes_rng_like_dataloader():
-    from opentf_amd.mdl.fnn import index_order
-    torch.manual_seed(3); a = index_order(23, 5, True); a2 = index_order(7, 5, False)
+    from opentf_amd.mdl import fnn as F
+    torch.manual_seed(3); a = F.index_order(23, 5, True); a2 = F.index_order(7, 5, False)
     torch.manual_seed(3); b = np.concatenate(O.index_batches(23, 5, True)); b2 = np.concatenate(O.index_batches(7, 5, False))
     assert np.array_equal(a, b) and np.array_equal(a2, b2) and sorted(a) == list(range(23))
-    assert torch.rand(1).item() == torch.rand(1).item() or True  # generators advanced identically up to here (checked by equality above)
+    # against the loader the reference builds (src/mdl/fnn.py:95-96: DataLoader over the dataset with its batch size), order AND the global generator afterwards;
+    # both the direct draws and the through-the-DataLoader path index_order falls back to when its one-time check disagrees
+    assert F._direct_matches_loader()
+    for n, bs, shuffle in [(1, 4, True), (999, 1000, True), (1000, 1000, False), (4097, 128, True), (4097, 128, False)]:
+        torch.manual_seed(11)
+        ref = torch.cat([t for t in torch.utils.data.DataLoader(torch.arange(n), batch_size=bs, shuffle=shuffle)]).numpy(); st = torch.get_rng_state()
+        for fn in (lambda: F.index_order(n, bs, shuffle), lambda: F._loader_order(n, shuffle)):
+            torch.manual_seed(11)
+            got = fn()
+            assert got.dtype == np.int64 and np.array_equal(got, ref) and torch.equal(torch.get_rng_state(), st), (n, bs, shuffle)
+    assert len(F.index_order(0, 5, False)) == 0
+    with pytest.raises(ValueError):
+        F.index_order(0, 5, True)
 
 
 def test_topk_to_coo_matches_reference_topk_sparse():
