@@ -189,7 +189,8 @@ def plugin_epoch(ds, a, device, headline_value):
     out = tempfile.mkdtemp(prefix="ntf_plugin_epoch_")
     spans = {}
     from opentf_amd.mdl import fnn as fnn_mod
-    real = {"tr": libntf.Engine.train_epoch, "ev": libntf.Engine.eval_epoch, "new": Bnn._new_engine, "save": Bnn._save, "order": fnn_mod.index_order}
+    real = {"tr": libntf.Engine.train_epoch, "ev": libntf.Engine.eval_epoch, "new": Bnn._new_engine, "save": Bnn._save, "order": fnn_mod.index_order,
+            "init": Bnn.init, "load": libntf.Engine.load_state_dict, "close": libntf.Engine.close}
 
     def timed(key, fn):
         def w(*args, **kw):
@@ -199,17 +200,20 @@ def plugin_epoch(ds, a, device, headline_value):
     try:
         libntf.Engine.train_epoch = timed("train", real["tr"]); libntf.Engine.eval_epoch = timed("valid", real["ev"])
         Bnn._new_engine = timed("ingest", real["new"]); Bnn._save = timed("checkpoint", real["save"]); fnn_mod.index_order = timed("order", real["order"])
+        Bnn.init = timed("init", real["init"]); libntf.Engine.load_state_dict = timed("load", real["load"]); libntf.Engine.close = timed("close", real["close"])
         m = Bnn(out, f"cuda:{device}", 0, cfg); m.writer = NoWriter
         t0 = _t.perf_counter(); m.learn(tv, splits, None); wall = _t.perf_counter() - t0
     finally:
         libntf.Engine.train_epoch, libntf.Engine.eval_epoch, Bnn._new_engine, Bnn._save, fnn_mod.index_order = real["tr"], real["ev"], real["new"], real["save"], real["order"]
+        Bnn.init, libntf.Engine.load_state_dict, libntf.Engine.close = real["init"], real["load"], real["close"]
         shutil.rmtree(out, ignore_errors=True)
     tr_rate = n_tr / (spans["train"] + spans.get("order", 0.0))      # the loader's order (both phases') counted with the train phase
     return {"workload": f"opentf_amd.mdl.bnn.Bnn.learn, one fold x one epoch: {n_tr} train + {n_va} validation teams of the headline's dataset as lil teamsvecs + skill_table, b={b}, nsd={a.nsd}",
             "learn_wall_s": wall, "ingest_s": spans.get("ingest"), "train_phase_s": spans["train"], "loader_order_s": spans.get("order"), "valid_phase_s": spans.get("valid"), "checkpoint_s": spans.get("checkpoint"),
             "value_is": "train teams / (train_phase_s + loader_order_s): torch's DataLoader draws for the shuffled order, ntf_stage_order, ceil(n / b) ntf_step_staged calls, the epoch-loss read-back",
             "value": tr_rate, "unit": "teams/s", "ms_per_step": spans["train"] / (-(-n_tr // b)) * 1e3, "ratio_to_headline": tr_rate / headline_value if headline_value else None,
-            "rest_of_learn_s": wall - sum(v for v in spans.values()),   # parameter init on the host (the reference's draws), load_state_dict, the writer, engine release
+            "param_init_on_host_s": spans.get("init"), "param_upload_s": spans.get("load"), "engine_release_s": spans.get("close"),   # init: the reference's own torch CPU draws (same seed -> same weights)
+            "rest_of_learn_s": wall - sum(v for v in spans.values()),
             "lil_build_s_not_plugin_time": lil_s}
 
 
@@ -217,8 +221,10 @@ class LegSkipped(RuntimeError):
     """an extra leg of an N > 1 run that the ranks agreed not to enter (some rank could not build its engine)"""
 
 
-def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
-    """roofline objects of the two output-layer kernels from their HIP-event times in the timed region: (dominant, other)"""
+def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep, evt_steps=None, adam_in_dw=True):
+    """roofline objects of the two output-layer kernels from their HIP-event times in the timed region: (dominant, other).  A data-parallel rank launches the forward
+    kernel range by range and the dW kernel chunk by chunk (`launches_per_step` > 1): the figures below are then a STEP's launches together - the whole layer's work over the
+    sum of their times - and say so."""
     gemm = 2.0 * eB * H * Mloc  # one [rows,H]x[H,experts]-sized product of a launch
     k = 2 if bayesian else 1
     # per timed scope: the unfused families launch one GEMM per Flipout half (k launches), the fused ones a single kernel
@@ -228,9 +234,12 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
     out = []
     for fam in sorted(cand, key=lambda f: -cand[f][0]):
         ms, calls = cand[fam]
-        t = ms / calls * 1e-3
+        lps = max(1, int(round(calls / evt_steps[fam]))) if (evt_steps and evt_steps.get(fam)) else 1
+        t = (ms / evt_steps[fam] if lps > 1 else ms / calls) * 1e-3
+        part = {"launches_per_step": lps, "ms_per_step_all_launches": t * 1e3,
+                "note": f"{lps} launches of this family a step (ranges / chunks of the layer, and the conditional exact-f32 launch where there is one): achieved = the layer's work / the sum of their times; avg_ms is one launch"} if lps > 1 else {}
         traffic, src = (None, None) if ep else pmc_traffic(fam, a, ds)
-        fused_adam = fam == "out_fused_dw_adam" and a.fuse_adam == 1 and not a.no_fused and a.mfma != "f32"
+        fused_adam = fam == "out_fused_dw_adam" and a.fuse_adam == 1 and adam_in_dw and not a.no_fused and a.mfma != "f32"
         if fused_adam:
             # dW + Adam (+ the next step's operands) in one kernel: HBM-bound.  Algorithmic bytes: the packed dz read once (4 B per row and expert of
             # the padded [256-expert tile, 128-row block] grid) + per weight 24 B read (mu, rho, four Adam moments) + 24 B written (mu, rho, moments) + 8 B of
@@ -242,7 +251,7 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
             out.append({"bound": "hbm", "kernel": fam, "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": src and f"per-launch mean of the separate rocprofv3 --pmc passes committed as profiles/{src} (FETCH_SIZE doubled per MI355X_MICROARCH.md), not counted in this run",
                         "avg_ms": ms / calls, "launches": calls, "bytes_per_launch": nbytes, "bytes_def": f"4 B x {Bpad} x {Mpad} (packed dz) + {per_w} B x {H} x {Mloc} (Adam in place + next-step operands)",
-                        "mfma_tflops_algorithmic": flops_per_launch[fam] / t / 1e12})
+                        "mfma_tflops_algorithmic": flops_per_launch[fam] / t / 1e12, **part})
             continue
         ach = flops_per_launch[fam] / t / 1e12
         # arithmetic of the kernel: "bf16x6" = every f32 operand split exactly into 3 bf16 values, a product = 6 bf16 MFMA products
@@ -256,7 +265,7 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep):
         out.append({"bound": "mfma", "kernel": fam, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                     "traffic_source": src and f"per-launch mean of the separate rocprofv3 --pmc passes committed as profiles/{src} (FETCH_SIZE doubled per MI355X_MICROARCH.md), not counted in this run",
                     "avg_ms": ms / calls, "launches": calls, "flops_per_launch": flops_per_launch[fam], "arithmetic": arith, "hw_mfma_tflops": ach * nprod,
-                    "power_note": "peak is the nominal 2.4 GHz figure; at the 1400 W package limit a dense fp16 MFMA stream on changing random operands sustains 1.595 GHz = 0.66 of it (profiles/r3_power_and_clocks.md, measured once, not in this run)" if nprod > 1 else None})
+                    "power_note": "peak is the nominal 2.4 GHz figure; at the 1400 W package limit a dense fp16 MFMA stream on changing random operands sustains 1.595 GHz = 0.66 of it (profiles/r3_power_and_clocks.md, measured once, not in this run)" if nprod > 1 else None, **part})
     return (out[0] if out else None), (out[1] if len(out) > 1 else None)
 
 
@@ -362,9 +371,13 @@ def main():
             no_events = bool(os.environ.get("NTF_BENCH_NO_EVENTS"))
             times = {}
 
-            def collect(next_mode):
+            evt_steps = {}      # steps whose launches of a family carried events: a chunked / ranged step (data parallel) launches a kernel several times per step
+
+            def collect(next_mode, nsteps=0):
                 for fam, (ms, calls) in e.kernel_times(enable=next_mode).items():
-                    if calls > 0: times[fam] = (times.get(fam, (0.0, 0))[0] + ms, times.get(fam, (0.0, 0))[1] + calls)
+                    if calls > 0:
+                        times[fam] = (times.get(fam, (0.0, 0))[0] + ms, times.get(fam, (0.0, 0))[1] + calls)
+                        evt_steps[fam] = evt_steps.get(fam, 0) + nsteps
             e.kernel_times(enable=0 if no_events else 3)
             regions, mean_loss, off = [], None, warmup * gB
             while len(regions) < reps_max:
@@ -377,7 +390,7 @@ def main():
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
                 if world > 1: dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank sees the same region time, hence takes the same decision below
                 regions.append(float(t.item())); off += steps * gB
-                collect(0 if no_events else (4 if len(regions) % 2 else 3))      # (a single region: the forward kernel only - its partner comes from the breakdown pass below)
+                collect(0 if no_events else (4 if len(regions) % 2 else 3), steps)      # (a single region: the forward kernel only - its partner comes from the breakdown pass below)
                 if sum(regions) >= float(os.environ.get("NTF_BENCH_MIN_TIMED_S", "2.0")): break                                # every rank sees the same (max-reduced) times, hence takes the same decision
             collect(0)
             bd, k3 = None, 0
@@ -388,9 +401,9 @@ def main():
                 full = e.kernel_times(enable=False)
                 bd = {f: round(v[0] / k3, 4) for f, v in full.items() if v[1] > 0}
                 for fam in ("out_fused_fwd_loss_dh", "out_fused_dw_adam", "out_fwd_gemm", "out_bwd_dw_gemm"):      # a run of ONE timed region saw one of the two kernels only
-                    if fam not in times and fam in full and full[fam][1] > 0: times[fam] = full[fam]
+                    if fam not in times and fam in full and full[fam][1] > 0: times[fam] = full[fam]; evt_steps[fam] = k3
             dt = float(np.median(regions))
-            res = {"par": par, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "times": times, "breakdown": bd, "k3": k3,
+            res = {"par": par, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
                    "Mloc": (shard[1] - shard[0]) if ep else model_dims[-1], "engine": e,
                    "rccl_payload_bytes_per_step": (4 * gB * a.hidden) if ep else (8 * n_params if world > 1 else 0),
                    "emulated_bytes": getattr(dp, "emulated_bytes", None)}
@@ -456,7 +469,7 @@ def main():
     def _emit(final):
         B, H, M = a.batch, a.hidden, ds["M"]
         ep = head["ep"]; dt = head["dt"]
-        roof, roof_other = rooflines(head["times"], a, bayesian, head["eB"], H, head["Mloc"], ds, ep)
+        roof, roof_other = rooflines(head["times"], a, bayesian, head["eB"], H, head["Mloc"], ds, ep, head.get("evt_steps"), head.get("adam_in_dw", True))
         spread = (max(head["regions"]) - min(head["regions"])) / dt if len(head["regions"]) > 1 else None
         devices = [torch.cuda.get_device_name(local)]
         out = {
@@ -576,7 +589,7 @@ def main():
         dimsf = [a.d, a.hidden, dsf["M"]]
         a.dataset = "dblp_full"
         r = run_mode("dp", a.batch, 10, 2, reps_allowed=False, breakdown=True, data=dsf, model_dims=dimsf, params=init_params(dimsf, bayesian, 0)); r["engine"].close()
-        rf, rfo = rooflines(r["times"], a, bayesian, r["eB"], a.hidden, r["Mloc"], dsf, False)      # (traffic: no PMC pass at this size - null)
+        rf, rfo = rooflines(r["times"], a, bayesian, r["eB"], a.hidden, r["Mloc"], dsf, False, r.get("evt_steps"), r.get("adam_in_dw", True))      # (traffic: no PMC pass at this size - null)
         extra_configs = {"dblp_full": {"workload": workload_label(a, dsf, bayesian, False), "steps": 10, "ms_per_step": r["dt"] / 10 * 1e3, "value": 10 * a.batch / r["dt"], "unit": "teams/s",
                                        "mean_loss": r["mean_loss"], "roofline": rf, "roofline_other": rfo}}
         a.dataset = saved[0]

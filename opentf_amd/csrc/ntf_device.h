@@ -137,8 +137,13 @@ __device__ __forceinline__ void bce_terms(float z, float& sp, float& sg, float& 
 __device__ __forceinline__ void adam_step(float& p, float g, float& m, float& v, float lr_over_bc1, float b1, float b2, float eps, float inv_bc2_sqrt) {
     m = m + (1.f - b1) * (g - m);
     v = v * b2 + (1.f - b2) * g * g;
+#ifdef NTF_ADAM_IEEE      // diagnostic builds only (profiles/r5_ep_tolerance.md): round 3's correctly rounded square root and division
+    const float denom = fmaf(sqrtf(v), inv_bc2_sqrt, eps);
+    p = p - (lr_over_bc1 * m) / denom;
+#else
     const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, eps);
     p = p - (lr_over_bc1 * m) * __builtin_amdgcn_rcpf(denom);
+#endif
 }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {

@@ -1299,6 +1299,10 @@ static int apply_adam(ntf_engine* e) {
     const bool bias_nx = e->hp.valid && rotate && e->hp.step == e->step && e->merge_bias;
     NormalSpec nx_eps;
     if (bias_nx) { StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B; nx_eps = normal_spec(e, nx, e->L - 1, T_EPS_B); }
+#ifdef NTF_DIAG
+    static const int diag_skip = getenv("NTF_SKIP") ? atoi(getenv("NTF_SKIP")) : 0;     // timing only (results garbage): 1 - no launch here; 2 - the rotation alone
+    if (diag_skip == 1 && bias_nx) {} else if (diag_skip == 2 && bias_nx) launch_step_scalars(e->st, e->d_kl, 1); else
+#endif
     launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2), fin, &e->fin_eps, e->fin_klw,
                        rotate ? e->d_kl : nullptr, bias_nx ? e->bp[e->L - 1] : nullptr, bias_nx ? &nx_eps : nullptr, 1.0 / (double)e->Mg);
     e->pre_rotated = rotate; e->fin_pend = false;

@@ -139,6 +139,10 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
 }
 
 void launch_out_special(hipStream_t st, int H, bool bayes, bool train, bool dh, const SpecialArgs& s) {
+#ifdef NTF_DIAG
+    static const int diag_skip = getenv("NTF_SKIP") ? atoi(getenv("NTF_SKIP")) : 0;     // timing only (results garbage): 4 - no sparse fix-up launch
+    if (diag_skip == 4 && train) return;
+#endif
 #define NTF_SPK(HH, BY) do { if (!train) hipLaunchKernelGGL((k_out_special<HH, BY, false, false>), dim3(s.B), dim3(64), 0, st, s);         \
         else if (dh) hipLaunchKernelGGL((k_out_special<HH, BY, true, true>), dim3(s.B), dim3(64), 0, st, s);                                  \
         else hipLaunchKernelGGL((k_out_special<HH, BY, true, false>), dim3(s.B), dim3(64), 0, st, s); } while (0)

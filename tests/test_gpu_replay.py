@@ -26,7 +26,7 @@ def _dataset(rng, N, S, D, M, mean_s, mean_m):
     return (s_ip, s_ix), table, (m_ip, m_ix)
 
 
-def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4):
+def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, nsd="uniform"):
     import torch
     from oracle import ntf_oracle as O
     from opentf_amd import libntf
@@ -46,8 +46,9 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4):
     def as_torch(noise):
         return [{k: torch.from_numpy(v) for k, v in n.items()} for n in noise]
 
-    e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", tpw=10.0, tnw=1.0, lr=1e-3, seed=seed, fuse_adam=1)     # what bench.py and the plugin create: Adam in the dW epilogue, operands / head prefetched
+    e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd=nsd, tpw=10.0, tnw=1.0, lr=1e-3, seed=seed, fuse_adam=1)     # what bench.py and the plugin create: Adam in the dW epilogue, operands / head prefetched
     e.set_skill_table(table); e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd)
+    if nsd == "unigram": e.set_unigram(np.bincount(member[1], minlength=M) / N)      # src/mdl/fnn.py:82
     e.stage_order(order)
 
     # ---- logits of the first batch with the draws of step t0: the shipped inference kernel on native signs / eps against the oracle's forward on the exported tensors
@@ -106,6 +107,12 @@ def test_three_default_steps_replayed_through_the_oracle_at_config2_size():
 def test_three_default_steps_replayed_through_the_oracle_on_a_ragged_shape():
     """a ragged last expert tile (M = 70 001: one expert into a 32-expert sub-tile, a 128-expert half-tile and a 256-expert tile) under a ragged row block (B = 129)"""
     _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=22, t0=40)
+
+
+@pytest.mark.parametrize("nsd", ["unigram_b", "unigram"])
+def test_three_default_steps_replayed_through_the_oracle_with_the_frequency_samplers(nsd):
+    """`unigram_b` is the sampler of every Bnn run the reference commits (its per-batch alias table staged one batch ahead, in the head prefetch); `unigram` the dataset-wide one"""
+    _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=23, t0=17, nsd=nsd)
 
 
 @pytest.mark.parametrize("nsd", ["uniform", "unigram_b"])
