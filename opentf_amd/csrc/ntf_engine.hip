@@ -120,6 +120,9 @@ struct ntf_engine {
     int merge_bias = 1;               // NTF_MERGE_BIAS=0: the next step's output-bias operand as k_head's bias workgroups in a launch of their own behind the bias Adam, as in round 4 (A/B runs)
     uint64_t spec_step = 0;           // step + 1 whose special-entry list (k_special_list) is in that step's workspace set
     int dp_ranges = 1;                // NTF_DP_RANGES=0: a data-parallel rank waits for every parameter all-gather before its step, as in round 4 (A/B runs, tests)
+    int ep_head_prefetch = -1;        // NTF_EP_HEAD_PREFETCH: an expert shard's phase 3 issues the next batch's head behind its hidden backward, beside its dW kernel (phase 2).  -1 (default): when the
+                                      // dW kernel outlasts the backward (B x 8 <= the shard's experts: ranks of 2-4 at config 2; 1.27 against 1.33 ms at a rank of 4, neutral at 8 where both end together);
+                                      // 0 never; 2 always; 1 always, with the sampler / sign words on the auxiliary stream from the end of phase 1 (beside the whole dW kernel: slower, 1.34 against 1.30 at 8)
     int fix_in_fwd = 0;               // NTF_FIX_IN_FWD=1 (experiment, measured 0.008-0.015 ms SLOWER: DESIGN.md section 4.0): the forward kernel handles the special entries itself, the sparse fix-up leaves the main stream
     int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
@@ -245,6 +248,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* fx = getenv("NTF_FIX_IN_FWD")) e->fix_in_fwd = atoi(fx);
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
+    if (const char* eh = getenv("NTF_EP_HEAD_PREFETCH")) e->ep_head_prefetch = atoi(eh);
     if (const char* dr = getenv("NTF_DP_RANGES")) e->dp_ranges = atoi(dr);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
@@ -855,6 +859,54 @@ static int fwd_ranges(const ntf_engine* e, int B, FwdRange* out, int* ncg_tot) {
 }
 
 // forward + loss (+ backward into G when train).  Loss = sum_rows(...)/global_B + KL * (B/global_B)/global_B
+// Head prefetch (round 4; expert shards: round 5).  Everything the NEXT batch of the staged order needs before its forward kernel and that does not depend on the output layer:
+// Adam of the hidden layers (their gradients are complete), then gather -> hidden layer -> h images (k_head) on `head_st`; the negative sampler, the special-entry list and
+// the transposed s_out words - rows and sign keys only - on the auxiliary stream, which waits for `aux_after` (an event already recorded on a stream that is behind this
+// step's forward kernel).  Into the OTHER workspace set, with the KL terms and the range flag in the NEXT step's slots (beside what this step's dW epilogue puts there).
+// The caller has checked that the next step's operands are being produced by this step's dW epilogue (pre_valid / pre_step) and that k_head serves the shape.
+static int prefetch_next_head(ntf_engine* e, const StepCtx& c, hipStream_t head_st, hipEvent_t aux_after) {
+    int r;
+    const LayerInfo& lo = e->layers[e->L - 1];
+    const int M = e->cfg.dims[e->L];
+    StreamRestore restore{e, e->st};
+    e->st = head_st;
+    {   // Adam of the hidden layers: [0, first float of the output layer) - apply_adam then leaves that range alone
+        Scope t(e, F_ADAM);
+        const double b1 = 0.9, b2 = 0.999, tt = (double)(e->adam_t + 1);
+        const int64_t rg[2] = {0, lo.off[NTF_P_WEIGHT]};
+        launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, 1, e->lr, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)), (float)std::sqrt(1.0 - std::pow(b2, tt)));
+        e->hidden_adam_done = true;
+    }
+    StepCtx n; n.rows_dev = e->hp_next_rows; n.B = e->hp_next_B; n.global_B = e->hp_next_B; n.step = c.step + 1; n.train = true; n.row0 = 0;
+    char* ws_next = e->fws_set[n.step & 1];
+    // the sampler and the s_out words need the rows and the sign key only: on the auxiliary stream, from the fork on (beside the hidden backward; beside the HBM-bound
+    // dW kernel the 30 MB of k_sign_words_T take ~90 us instead of 19 - behind the hidden backward on ONE stream the chain ended 14 us before the dW kernel)
+    e->st = e->st4;
+    HIPCHK(e, hipStreamWaitEvent(e->st4, aux_after, 0));
+    int ub_next = -1;
+    if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0) {
+        // round 5: the next batch's per-batch alias table (host sort + count of its ~3 k experts, 16 B per slot through the other pinned buffer) is staged here too,
+        // uploaded on the auxiliary stream in front of its sampler
+        ub_next = c.ub ^ 1; n.ub = ub_next;
+        if ((r = set_batch_unigram(e, e->hp_next_host, n.B, ub_next, e->st4))) return r;
+    }
+    if ((r = sample_negatives(e, n))) return r;
+    list_specials(e, n, ws_next);
+    const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
+    { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1); }
+    HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
+    e->st = head_st;
+    { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr); }
+    e->hp.valid = true; e->hp.step = n.step; e->hp.rows = n.rows_dev; e->hp.B = n.B; e->hp.ub = ub_next;
+    return NTF_OK;
+}
+static bool head_prefetch_possible(const ntf_engine* e, const StepCtx& c, int B) {
+    const bool can_head = e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
+                          (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
+    return e->head_prefetch && can_head && c.fuse_adam && e->cfg.fuse_adam == 1 && e->pre_valid && e->pre_step == c.step + 1 && e->hp_next_B > 0 && !c.inj &&
+           (e->cfg.nsd != NTF_NSD_UNIGRAM_B || e->hp_next_host != nullptr) && c.global_B == B;
+}
+
 static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     int r;
     const int B = c.B, M = e->cfg.dims[e->L];
@@ -1232,44 +1284,26 @@ backward:
         // complete), the negative sampler, the transposed s_out words and k_head - into the other workspace set, with the KL terms and the range flag in the NEXT step's
         // slots (beside what this step's dW epilogue puts there).  What stays between the dW kernel and the next forward kernel: Adam of the output biases (+ the
         // rotation of the scalars), the bias operand (apply_adam) and the two range-fallback launches.  Taken by run_step when the next call IS that batch (hp_hit).
-        const bool can_head = e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
-                              (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
-        if (e->head_prefetch && can_head && c.fuse_adam && e->cfg.fuse_adam == 1 && e->pre_valid && e->pre_step == c.step + 1 && e->hp_next_B > 0 && !c.inj &&
-            (e->cfg.nsd != NTF_NSD_UNIGRAM_B || e->hp_next_host != nullptr) && c.global_B == B && !e->ep) {
+        if (head_prefetch_possible(e, c, B) && !e->ep) {
+            if ((r = prefetch_next_head(e, c, e->st3, e->ev_fork))) return r;
             e->st = e->st3;
-            {   // Adam of the hidden layers: [0, first float of the output layer) - apply_adam then leaves that range alone
-                Scope t(e, F_ADAM);
-                const double b1 = 0.9, b2 = 0.999, tt = (double)(e->adam_t + 1);
-                const int64_t rg[2] = {0, lo.off[NTF_P_WEIGHT]};
-                launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, 1, e->lr, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)), (float)std::sqrt(1.0 - std::pow(b2, tt)));
-                e->hidden_adam_done = true;
-            }
-            StepCtx n; n.rows_dev = e->hp_next_rows; n.B = e->hp_next_B; n.global_B = e->hp_next_B; n.step = c.step + 1; n.train = true; n.row0 = 0;
-            char* ws_next = e->fws_set[n.step & 1];
-            // the sampler and the s_out words need the rows and the sign key only: on the auxiliary stream, from the fork on (beside the hidden backward; beside the HBM-bound
-            // dW kernel the 30 MB of k_sign_words_T take ~90 us instead of 19 - behind the hidden backward on ONE stream the chain ended 14 us before the dW kernel)
-            e->st = e->st4;
-            HIPCHK(e, hipStreamWaitEvent(e->st4, e->ev_fork, 0));
-            int ub_next = -1;
-            if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0) {
-                // round 5: the next batch's per-batch alias table (host sort + count of its ~3 k experts, 16 B per slot through the other pinned buffer) is staged here too,
-                // uploaded on the auxiliary stream in front of its sampler
-                ub_next = c.ub ^ 1; n.ub = ub_next;
-                if ((r = set_batch_unigram(e, e->hp_next_host, n.B, ub_next, e->st4))) return r;
-            }
-            if ((r = sample_negatives(e, n))) return r;
-            list_specials(e, n, ws_next);
-            const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
-            { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1); }
-            HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
-            e->st = e->st3;
-            { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr); }
-            e->hp.valid = true; e->hp.step = n.step; e->hp.rows = n.rows_dev; e->hp.B = n.B; e->hp.ub = ub_next;
         }
         HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
         e->st = restore.main;
         HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (e->hp.valid && e->hp.step == c.step + 1) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));
+    }
+    const int ep_hp = !e->ep ? 0 : e->ep_head_prefetch >= 0 ? e->ep_head_prefetch : ((int64_t)B * 8 <= (int64_t)M ? 2 : 0);
+    if (ep_hp && c.part == 3 && head_prefetch_possible(e, c, B)) {
+        // ---- expert shards (round 5): phase 3 - the hidden layers' backward, on the stream that waited for the d(hidden) exchange - runs beside this shard's dW kernel (phase 2,
+        // side stream).  Where that kernel outlasts the backward (ranks of 2-4: fewer rows, more experts per rank) the stream would idle until the join: the next batch's head
+        // (hidden Adam, k_head; sampler and sign words on the auxiliary stream) goes there.  At a rank of 8 backward and dW end together (profiles/r5_ep/rank_of_8_step_timeline.txt)
+        // and a narrow shard's split-K dW launch is ONE round of workgroups on every CU - no ramp, no tail: what is issued beside it only slows it (the s_out words take 0.32 ms
+        // instead of 0.03 when they start with the kernel) - hence the rule in ep_head_prefetch's comment.  Same kernels on the same inputs either way (tests/test_gpu_ep.py).
+        if ((r = side_stream(e))) return r;
+        if (!e->ep_side || ep_hp == 2) HIPCHK(e, hipEventRecord(e->ev_fork, e->st));     // (ep_side: recorded behind phase 1, ntf_step_staged_ep; 2: the auxiliary stream starts here, behind the backward)
+        if ((r = prefetch_next_head(e, c, e->st, e->ev_fork))) return r;
+        HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));
     }
     return NTF_OK;
 }
@@ -1515,9 +1549,17 @@ extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int3
         if (e->ep_open == 2 && e->ep_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));   // an abandoned step's side-stream kernel still orders before this one
         e->pend_valid = false; e->ep_open = 0;
         if ((r = stage_rows(e, e->d_order + offset, B, true, &c.rows_dev))) return r;
-        if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0) { c.ub = (e->ub_slot ^= 1); if ((r = set_batch_unigram(e, e->h_order.data() + offset, B, c.ub, e->st))) return r; }
+        if (e->cfg.nsd == NTF_NSD_UNIGRAM_B && e->cfg.ns > 0) {
+            // (phase 3 of the previous step may have staged THIS batch's table beside its dW kernel, as step_common's head prefetch does)
+            if (e->hp.valid && e->hp.ub >= 0 && e->hp.step == c.step && e->hp.rows == c.rows_dev && e->hp.B == B) c.ub = e->hp.ub;
+            else { c.ub = (e->ub_slot ^= 1); if ((r = set_batch_unigram(e, e->h_order.data() + offset, B, c.ub, e->st))) return r; }
+            e->ub_slot = c.ub;
+        }
         if ((r = run_step(e, c, true))) return r;
         e->last_B = B; e->last_global_B = B; e->neg_step = c.step;
+        // the batch that follows in the staged order: what phase 3's head prefetch works for
+        { const int64_t no = offset + B; const int nB = (int)std::min<int64_t>(B, n - no);
+          if (nB >= 1) { e->hp_next_rows = e->d_order + no; e->hp_next_B = nB; e->hp_next_host = e->h_order.data() + no; } else { e->hp_next_B = 0; e->hp_next_host = nullptr; } }
         e->ep_ctx = c; e->ep_open = 1;
         // phase 2 (this shard's dW kernel) on the side stream, beside the exchange and phase 3: one rank of 2 runs 1.684 -> 1.626 ms, of 4 1.605 -> 1.584, of 8
         // unchanged (its split-K dW launch is a single round: no idle tail to fill)
@@ -1537,6 +1579,7 @@ extern "C" int ntf_step_staged_ep(ntf_engine* e, int64_t offset, int32_t B, int3
             HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
         } else if ((r = run_step(e, c, false))) return r;
         if (phase == 3) {
+            e->hp_next_B = 0; e->hp_next_host = nullptr;
             if (e->ep_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
             if ((r = apply_adam(e))) return r;
         }

@@ -759,7 +759,9 @@ __global__ void k_sin_words_T(const uint32_t* __restrict__ sinbits, int Bpad, ui
 #endif
 constexpr int QW = 4;            // waves per workgroup
 constexpr int QTC = 32 * QW;     // experts per workgroup
-template <bool BAYES, bool ADAM, bool STAMP = false>
+// SPLIT (round 5): the split-K form for few expert tiles - a narrow expert shard under a wide minibatch: workgroup = (tile, K range), raw partial sums into the slabs
+// k_out_dw_finish adds up (the layout k_out_dw_p2's split launch writes: an accumulator's element is addressed by its expert row and hidden unit, not by the kernel).
+template <bool BAYES, bool ADAM, bool STAMP = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * QW, 2) void k_out_dw_q(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128, NJT = 4, NP = 2;
@@ -772,9 +774,12 @@ __global__ __launch_bounds__(64 * QW, 2) void k_out_dw_q(DwArgs p) {
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
     if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) return;   // the step runs in exact f32: the kernel launched behind this one
-    const int c0 = (p.wg_begin + (int)blockIdx.x) * QTC;
+    const int ntile_s = SPLIT ? (int)gridDim.x / p.ksplit : 0;
+    const int ksi = SPLIT ? (int)blockIdx.x / ntile_s : 0;                  // which K range (the splits of one tile sit ntile_s workgroups apart)
+    const int c0 = (p.wg_begin + (SPLIT ? (int)blockIdx.x % ntile_s : (int)blockIdx.x)) * QTC;
     const int crow = wave * 32 + il, c = c0 + crow;
     const int nib = p.Bpad / 32;
+    const int ib0 = SPLIT ? (int)((int64_t)ksi * nib / p.ksplit) : 0, ib1 = SPLIT ? (int)((int64_t)(ksi + 1) * nib / p.ksplit) : nib;
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char* hb = reinterpret_cast<const char*>(p.hb);
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(64 * QW, 2) void k_out_dw_q(DwArgs p) {
         return t;
     };
 #pragma unroll
-    for (int n = 0; n < NA + NB; ++n) stage_piece(0, 0, n);
+    for (int n = 0; n < NA + NB; ++n) stage_piece(ib0, 0, n);
     f32x16 acc1[NJT], acc2[NJT];
 #pragma unroll
     for (int j = 0; j < NJT; ++j)
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(64 * QW, 2) void k_out_dw_q(DwArgs p) {
     __syncthreads();
     auto k_block = [&](int ib, auto more_c) {
         constexpr bool MORE = decltype(more_c)::value;
-        const int buf = ib & 1;
+        const int buf = (ib - ib0) & 1;
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + TA;
         uint32_t word = 0u;
@@ -912,13 +917,31 @@ __global__ __launch_bounds__(64 * QW, 2) void k_out_dw_q(DwArgs p) {
     };
     if (STAMP) { st_t[1] = __builtin_amdgcn_s_memrealtime(); c_prev = cyc(); }
     if (DWQ_PRIO) __builtin_amdgcn_s_setprio(DWQ_PRIO);   // the main loop is the latency-bound one of a SIMD's two waves (one in-order MFMA stream); its partner streams an epilogue
-    for (int ib = 0; ib < nib - 1; ++ib) k_block(ib, std::true_type{});
-    k_block(nib - 1, std::false_type{});
+    for (int ib = ib0; ib < ib1 - 1; ++ib) k_block(ib, std::true_type{});
+    k_block(ib1 - 1, std::false_type{});
     if (DWQ_PRIO) __builtin_amdgcn_s_setprio(0);
     if (STAMP) st_t[2] = __builtin_amdgcn_s_memrealtime();
     sum1 += __shfl_xor(sum1, 32, 64);
     sum2 += __shfl_xor(sum2, 32, 64);
     const float inv_a = 1.f / p.a_scale;
+    if constexpr (SPLIT) {    // raw partial sums of this K range (bias sums behind the slabs); k_out_dw_finish adds the ranges and runs the epilogue
+        if (half == 0 && c < p.M) {
+            float* pb = p.part + (int64_t)p.ksplit * 2 * p.slab; const int64_t Mp = p.slab / 128; const int cl = c - p.part_row0;
+            pb[(int64_t)(ksi * 2) * Mp + cl] = sum1 * inv_a; if (BAYES) pb[(int64_t)(ksi * 2 + 1) * Mp + cl] = sum2 * inv_a;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cr = c0 + wave * 32 + rowmap(r, half);
+            if (cr >= p.M) continue;
+            const int64_t il0 = (int64_t)(cr - p.part_row0) * H + NJT * il;
+            float s1[NJT], s2[NJT];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) { s1[jt] = acc1[jt][r] * p.unscale; s2[jt] = acc2[jt][r] * p.unscale; }
+            st_vec<NJT>(p.part + (int64_t)(ksi * 2) * p.slab + il0, s1);
+            if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + il0, s2);
+        }
+        return;
+    }
     if (half == 0 && c < p.M) { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
 
     // epilogue: accumulator row r of lane (il, half) = expert c0 + 32 wave + rowmap(r, half), hidden units 4 il .. 4 il + 3
@@ -986,6 +1009,25 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     if (f.bf16x6 && f.np == 2 && f.dz_packed) {   // fp16x3 step, H = 128: the forward kernel left packed plane pairs in dzT
         a.a_scale = f.a_scale; a.unscale = 1.f / (f.a_scale * f.h_scale); a.rmode = guard ? 1 : 0;
         const int ks = (f.ksplit > 1 && f.part) ? std::min(f.ksplit, std::max(1, g.Bpad / 32)) : 1;
+        if (ks > 1 && f.kernel == 1) {   // ... on half-tile workgroups, two per CU (k_out_dw_q<.., SPLIT>): the narrow expert shards' launch since round 5
+            a.sinT = reinterpret_cast<const uint32_t*>(ws + w.sinT);
+            const int total_q = (f.M + QTC - 1) / QTC, qb = f.wg_count > 0 ? 2 * f.wg_begin : 0;
+            const int qgrid = f.wg_count > 0 ? std::min(2 * f.wg_count, total_q - qb) : total_q;
+            const int wg256 = a.wg_begin;
+            a.wg_begin = qb;
+            a.ksplit = ks; a.part = f.part; a.slab = (int64_t)qgrid * QTC * 128; a.part_row0 = qb * QTC;
+            const size_t ldsq = 2 * ((size_t)QTC * 128 + 2 * 128 * 64 + (f.bayes ? 1024 : 0)) + 64;
+            const int64_t nq = (int64_t)qgrid * QTC * 128 / 4;
+#define NTF_DWQS(BY, AD) do { auto kf = k_out_dw_q<BY, false, false, true>;                                                    \
+            set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsq);     \
+            hipLaunchKernelGGL(kf, dim3(qgrid * ks), dim3(64 * QW), ldsq, st, a);                                              \
+            hipLaunchKernelGGL((k_out_dw_finish<BY, AD>), dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, a); } while (0)
+            if (f.bayes) { if (f.adam) NTF_DWQS(true, true); else NTF_DWQS(true, false); } else { if (f.adam) NTF_DWQS(false, true); else NTF_DWQS(false, false); }
+#undef NTF_DWQS
+            if (!guard || f.no_fallback) return;
+            a.rmode = 2; a.ksplit = 1; a.wg_begin = wg256; a.part_row0 = 0;
+            goto exact_f32;
+        }
         if (ks > 1) {   // few expert tiles (a narrow shard, or the tail of a whole layer): every tile's K range is split over ks workgroups, k_out_dw_finish adds the parts and runs the epilogue
             a.ksplit = ks; a.part = f.part; a.slab = (int64_t)grid * DW_TC * 128; a.part_row0 = a.wg_begin * DW_TC;      // slabs over the launched tile range only
             const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0));

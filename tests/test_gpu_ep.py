@@ -84,8 +84,11 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("case", sorted(CASES))
-def test_expert_shards_compute_the_single_engine_step(case):
+@pytest.mark.parametrize("case", sorted(CASES) + ["bnn_uniform_g3+head_prefetch", "bnn_unigram_b_g2+head_prefetch", "bnn_uniform_g3+head_prefetch_late"])
+def test_expert_shards_compute_the_single_engine_step(case, monkeypatch):
+    case, _, variant = case.partition("+")
+    ep_hp = variant.startswith("head_prefetch")      # a shard's phase 3 issuing the next batch's head (by default only where the dW kernel outlasts the backward: DESIGN.md section 6.3)
+    monkeypatch.setenv("NTF_EP_HEAD_PREFETCH", {"head_prefetch": "1", "head_prefetch_late": "2"}.get(variant, "0"))      # (unset = by shape: these shards are wide enough for it; both ends are pinned here)
     bayesian, mkdims, nsd, G, B, multihot = CASES[case][:6]
     fuse_adam = CASES[case][6] if len(CASES[case]) > 6 else 1
     ds = make_dataset("dblp", d=128, seed=3, n_rows=1500, n_experts=3000)
@@ -108,8 +111,14 @@ def test_expert_shards_compute_the_single_engine_step(case):
         else: np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=2e-6, err_msg=k)   # d(hidden) is summed in another order
 
     # --- a short epoch on top, then an evaluation phase
+    hits0 = [e.head_prefetch_hits() for e in eng]
     l_full = _full_epoch(full, order, B); l_ep = _ep_epoch(eng, order, B)
     assert abs(l_ep - l_full) <= 1e-5 * abs(l_full), (l_ep, l_full)
+    if ep_hp and bayesian and len(dims) == 3 and not multihot and fuse_adam == 1:
+        # (NTF_EP_HEAD_PREFETCH=1: a shard's phase 3 issues the next batch's head beside its dW kernel, as the single engine's side stream does: batches 2 and 3 of the epoch took it)
+        assert all(e.head_prefetch_hits() - h == 2 for e, h in zip(eng, hits0)), [e.head_prefetch_hits() - h for e, h in zip(eng, hits0)]
+    else:
+        assert all(e.head_prefetch_hits() == h for e, h in zip(eng, hits0))
     a, b = _gathered(eng, exact_replicas=not multihot), full.state_dict()
     for k in b:
         # Adam normalises every gradient element by its own running magnitude: where a gradient is ~0, a last-bit difference of the summed d(hidden) (another
@@ -172,10 +181,13 @@ def test_wide_minibatch_on_a_narrow_shard():
         else: np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("dw_kernel", ["q", "p2"])
 @pytest.mark.parametrize("bayesian", [True, False])
-def test_split_k_weight_gradient_kernel_equals_the_unsplit_one(bayesian, monkeypatch):
+def test_split_k_weight_gradient_kernel_equals_the_unsplit_one(bayesian, dw_kernel, monkeypatch):
     """few expert tiles: the dW kernel's K (batch) range is split over workgroups and k_out_dw_finish runs the epilogue (gradient finalisation, fused Adam);
-    same sums in another order -> same update up to rounding, with and without the fused Adam, and the gradients themselves"""
+    same sums in another order -> same update up to rounding, with and without the fused Adam, and the gradients themselves.  Both split forms: half-tile workgroups
+    (k_out_dw_q<.., SPLIT>: the default since round 5) and the one-workgroup-per-CU kernel (NTF_DW_KERNEL=0)"""
+    if dw_kernel == "p2": monkeypatch.setenv("NTF_DW_KERNEL", "0")
     ds = make_dataset("dblp", d=128, seed=6, n_rows=3000, n_experts=1300)     # 6 tiles of 256 experts, the last one ragged
     dims = [128, 128, ds["M"]]
     order = np.random.default_rng(1).permutation(ds["N"])[:1500].astype(np.int64)
