@@ -509,7 +509,8 @@ def main():
                                    "collective_bytes_per_step": {"reduce_scatter_input": rs, "all_gather_output": ag, "all_reduce": ar, "sent_and_received_per_rank": wire},
                                    "exchange_ms_at_350_GBps_per_rank": wire / 350e9 * 1e3,
                                    "overlap_window_ms": {"reduce_scatter_behind": "the dW chunks that follow a chunk's own kernel", "dw_chunks_total": fam.get("out_fused_dw_adam"),
-                                                         "all_gather_behind": "nothing in round 4 (every gather waited for before the head): see DESIGN.md 6.5 for the chunked forward"},
+                                                         "all_gather_behind": ("the next step's head, range by range: the forward kernel of range j runs while the chunks of range j + 1 arrive (3 of 4 ranges; DESIGN.md 6.5)"
+                                                                               if os.environ.get("NTF_DP_RANGES", "1") != "0" else "nothing (NTF_DP_RANGES=0: every gather waited for before the head, as in round 4)")},
                                    "note": "compute only: deferred dW in expert chunks (fuse_adam = 0), stand-alone operand producer, Adam on the 1/G shard; the collectives' bytes are tallied, not moved. "
                                            "350 GB/s = what a rank receives over its seven xGMI links in a ring (MI355X_MICROARCH.md: 7 x ~153 GB/s point to point, a ring uses one link each way)"}
         sys.stdout.flush(); sys.stderr.flush()

@@ -172,7 +172,10 @@ int ntf_step_staged(ntf_engine* e, int64_t offset, int32_t B, int64_t global_off
  * the host can all-reduce the gradients of chunk k while chunk k+1 is being computed.  ntf_dw_chunks: n for this model (0 when the
  * fused output-layer path does not apply: nothing is deferred then).  ntf_dw_chunk_range: where chunk k's gradients sit in the flat
  * gradient buffer (offsets in floats; off_rho = -1 for Fnn) - a pure function of the model shape, identical on every rank.
- * After the last chunk the whole gradient buffer is complete.  ntf_param_segment: where a parameter sits in the flat buffers. */
+ * After the last chunk the whole gradient buffer is complete - on the engine's stream: the hidden layers' backward of a deferred step runs on a side stream beside the
+ * chunks (round 5) and is joined behind the LAST ntf_dw_chunk, so work queued on the engine's stream after that call (the caller's collectives) sees every gradient;
+ * ntf_get_grad / ntf_apply / ntf_apply_ranges / ntf_epoch_loss / ntf_synchronize / the next step join it themselves if the chunks were abandoned.
+ * ntf_param_segment: where a parameter sits in the flat buffers. */
 int ntf_step_staged_deferred(ntf_engine* e, int64_t offset, int32_t B, int64_t global_offset, int32_t global_B, float* loss_out);
 int ntf_dw_chunks(ntf_engine* e, int32_t* n_chunks);
 int ntf_dw_chunk_range(ntf_engine* e, int32_t k, int64_t* off_weight, int64_t* off_rho, int64_t* count);

@@ -119,6 +119,7 @@ struct ntf_engine {
     // touched the output layer's parameters or the operand buffers (Wp, split planes); d_kl[2] / d_range[4] hold that step's KL and range flag until it starts
     int merge_bias = 1;               // NTF_MERGE_BIAS=0: the next step's output-bias operand as k_head's bias workgroups in a launch of their own behind the bias Adam, as in round 4 (A/B runs)
     uint64_t spec_step = 0;           // step + 1 whose special-entry list (k_special_list) is in that step's workspace set
+    int dp_side_bwd = 1;              // NTF_DP_SIDE_BWD=0: a deferred-dW (data-parallel) step runs its hidden layers' backward on the main stream in front of the dW chunks, as in round 4 (A/B runs)
     int dp_ranges = 1;                // NTF_DP_RANGES=0: a data-parallel rank waits for every parameter all-gather before its step, as in round 4 (A/B runs, tests)
     int ep_head_prefetch = -1;        // NTF_EP_HEAD_PREFETCH: an expert shard's phase 3 issues the next batch's head behind its hidden backward, beside its dW kernel (phase 2).  -1 (default): when the
                                       // dW kernel outlasts the backward (B x 8 <= the shard's experts: ranks of 2-4 at config 2; 1.27 against 1.33 ms at a rank of 4, neutral at 8 where both end together);
@@ -127,6 +128,7 @@ struct ntf_engine {
     int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
+    bool join_pending = false;        // a deferred-dW step (data parallel) left its hidden layers' backward running on the side stream: joined (join_side) behind the last dW chunk, or by whatever reads its results first
     bool pre_rotated = false;         // ... and whose KL / range-flag scalars the previous step's last kernel already moved into place
     bool fin_pend = false; NormalSpec fin_eps; float fin_klw = 0.f;   // the output layer's bias-gradient finalisation rides in the Adam launch that follows (fused-Adam steps)
     // data-parallel pipelining: the output layer's dW kernel deferred by ntf_step_staged_deferred, launched by ntf_dw_chunk
@@ -156,6 +158,7 @@ struct ntf_engine {
         }                                                                                                 \
     } while (0)
 #define FAIL(e, code, msg) do { (e)->err = (msg); return (code); } while (0)
+static int join_side(ntf_engine* e);
 
 struct Scope {
     ntf_engine* e; int fam; hipEvent_t a = nullptr, b = nullptr;
@@ -250,6 +253,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
     if (const char* eh = getenv("NTF_EP_HEAD_PREFETCH")) e->ep_head_prefetch = atoi(eh);
     if (const char* dr = getenv("NTF_DP_RANGES")) e->dp_ranges = atoi(dr);
+    if (const char* ds = getenv("NTF_DP_SIDE_BWD")) e->dp_side_bwd = atoi(ds);
     if (const char* sb = getenv("NTF_SIDE_BWD")) e->side_bwd = atoi(sb);   // A/B runs and tests: 1 = never split the dW kernel's K range, n = force n, unset = by the tile count
     if (cfg->stream) e->st = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&e->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return NTF_EHIP; } e->own_stream = true; }
@@ -491,6 +495,7 @@ extern "C" int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int
     int64_t off, n; int r = param_span(e, layer, kind, off, n); if (r) return r;
     if (count != n) FAIL(e, NTF_EINVAL, "grad: element count mismatch");
     HIPCHK(e, hipSetDevice(e->cfg.device));
+    if ((r = join_side(e))) return r;
     HIPCHK(e, hipStreamSynchronize(e->st));
     return fetch_segment(e, e->G + off, layer, kind, host, n);
 }
@@ -864,6 +869,10 @@ static int fwd_ranges(const ntf_engine* e, int B, FwdRange* out, int* ncg_tot) {
 // the transposed s_out words - rows and sign keys only - on the auxiliary stream, which waits for `aux_after` (an event already recorded on a stream that is behind this
 // step's forward kernel).  Into the OTHER workspace set, with the KL terms and the range flag in the NEXT step's slots (beside what this step's dW epilogue puts there).
 // The caller has checked that the next step's operands are being produced by this step's dW epilogue (pre_valid / pre_step) and that k_head serves the shape.
+static int join_side(ntf_engine* e) {
+    if (e->join_pending) { HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0)); e->join_pending = false; }
+    return NTF_OK;
+}
 static int prefetch_next_head(ntf_engine* e, const StepCtx& c, hipStream_t head_st, hipEvent_t aux_after) {
     int r;
     const LayerInfo& lo = e->layers[e->L - 1];
@@ -921,7 +930,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const bool use_head = fused && e->head && e->L == 2 && c.part <= 1 && !c.inj && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
                           (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
     // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
-    const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && !c.defer_dw && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
+    // (round 5: also of a deferred-dW step - a data-parallel rank's - whose dW chunks the host launches right behind this call: the join then waits behind the last chunk, join_side)
+    const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && (!c.defer_dw || e->dp_side_bwd) && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
     bool hp_hit = false, hp_stale = false;
     FwdRange fr[4]; int fr_tot = 0;
     const int nfr = (c.chunk_cb && c.defer_dw && c.train && c.part == 0 && !c.inj && e->dp_ranges) ? fwd_ranges(e, B, fr, &fr_tot) : 0;      // > 0: producer + forward kernel range by range
@@ -1290,7 +1300,8 @@ backward:
         }
         HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
         e->st = restore.main;
-        HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
+        if (c.defer_dw) e->join_pending = true;      // the dW chunks come next on the main stream, beside this chain
+        else HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (e->hp.valid && e->hp.step == c.step + 1) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));
     }
     const int ep_hp = !e->ep ? 0 : e->ep_head_prefetch >= 0 ? e->ep_head_prefetch : ((int64_t)B * 8 <= (int64_t)M ? 2 : 0);
@@ -1384,6 +1395,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     if (e->ep && global_B != B) FAIL(e, NTF_EINVAL, "expert-sharded engine: every shard steps the whole minibatch (global_B == B)");
     if (e->ep_open == 2 && e->ep_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
     e->ep_open = 0;
+    if ((r = join_side(e))) return r;       // (an abandoned deferred step's side-stream chain still orders before this one)
     StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
     c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
     c.defer_dw = defer_dw && train && !apply && fused_ok(e);
@@ -1402,6 +1414,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     if ((r = run_step(e, c, true))) return r;
     e->last_B = B; e->last_global_B = global_B; e->neg_step = c.step;
     if (train && apply && (r = apply_adam(e))) return r;
+    if (loss_out && (r = join_side(e))) return r;      // (the loss reduction of a deferred step runs on the side stream)
     if ((r = read_loss(e, loss_out))) return r;
     hipError_t s = hipGetLastError();
     if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
@@ -1420,12 +1433,14 @@ extern "C" int ntf_backward(ntf_engine* e, const int64_t* rows, int32_t B, int32
 extern "C" int ntf_apply(ntf_engine* e) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (int r = join_side(e)) return r;
     return apply_adam(e);
 }
 
 extern "C" int ntf_apply_ranges(ntf_engine* e, const int64_t* lo_hi, int32_t n) {
     if (!e || (n > 0 && !lo_hi) || n < 0) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (int r = join_side(e)) return r;
     return apply_adam_ranges(e, lo_hi, n);
 }
 
@@ -1528,6 +1543,7 @@ extern "C" int ntf_dw_chunk(ntf_engine* e, int32_t k) {
                                          e->G + li.off[NTF_P_RHO_BIAS], li.out, e->pend_eps_b, e->pend_klw_b);
         }
         e->pend_valid = false;
+        if ((r = join_side(e))) return r;       // the hidden layers' gradients (side stream, beside the chunks) are complete for whatever the caller queues next on this stream
     }
     hipError_t s = hipGetLastError();
     if (s != hipSuccess) FAIL(e, NTF_EHIP, std::string("kernel launch: ") + hipGetErrorString(s));
@@ -1622,6 +1638,7 @@ extern "C" int ntf_epoch_loss(ntf_engine* e, double* sum, int64_t* steps) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     double s = 0; int64_t k = 0;
+    if (int r = join_side(e)) return r;
     HIPCHK(e, hipMemcpyAsync(&s, e->d_acc, 8, hipMemcpyDeviceToHost, e->st));
     HIPCHK(e, hipMemcpyAsync(&k, e->d_acc_steps, 8, hipMemcpyDeviceToHost, e->st));
     HIPCHK(e, hipMemsetAsync(e->d_acc, 0, 8, e->st));
@@ -1865,12 +1882,14 @@ extern "C" int ntf_moment_buffers(ntf_engine* e, void** dev_m1, void** dev_v2, i
 extern "C" int ntf_synchronize(ntf_engine* e) {
     if (!e) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (int r = join_side(e)) return r;
     HIPCHK(e, hipStreamSynchronize(e->st));
     return NTF_OK;
 }
 extern "C" int ntf_kernel_times(ntf_engine* e, int enable, const char** names, double* ms, int64_t* calls, int cap) {
     if (!e) return NTF_EINVAL;
     hipSetDevice(e->cfg.device);
+    join_side(e);
     drain_times(e);
     int n = std::min(cap, (int)F_COUNT);
     for (int i = 0; i < n; ++i) { if (names) names[i] = kFamNames[i]; if (ms) ms[i] = e->fam_ms[i]; if (calls) calls[i] = e->fam_calls[i]; }

@@ -31,11 +31,12 @@ python3 $B --no-gather-bench --steps 50 --warmup 10 > $O/ab_default_b.json 2>> $
 for G in 2 4 8; do python3 $R/bench.py --steps 20 --warmup 4 --ep-emulate $G --no-extra-configs > $O/bench_ep_rank_of_$G.json 2>> $O/bench.err; done
 for G in 2 4 8; do python3 $R/bench.py --steps 30 --warmup 5 --dp-emulate $G > $O/bench_dp_rank_of_$G.json 2>> $O/bench.err; done
 NTF_DP_RANGES=0 python3 $R/bench.py --steps 30 --warmup 5 --dp-emulate 8 > $O/bench_dp_rank_of_8_NTF_DP_RANGES_0.json 2>> $O/bench.err
+NTF_DP_SIDE_BWD=0 python3 $R/bench.py --steps 30 --warmup 5 --dp-emulate 8 > $O/bench_dp_rank_of_8_NTF_DP_SIDE_BWD_0.json 2>> $O/bench.err
 export NTF_BENCH_MIN_TIMED_S=0.01
 # kernel trace (every dispatch: the step timeline) + stats of the default run
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --no-gather-bench --steps 200 --warmup 10 > $O/stats.log 2>&1
+rm -rf $O/stats; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --no-gather-bench --steps 200 --warmup 10 > $O/stats.log 2>&1
 # ... and of one data-parallel rank of 8 (the ranged forward launches, the chunked dW, Adam on the owned shard)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dp8 -- python3 $R/bench.py --steps 60 --warmup 5 --dp-emulate 8 > $O/stats_dp8.log 2>&1
+rm -rf $O/stats_dp8; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dp8 -- python3 $R/bench.py --steps 60 --warmup 5 --dp-emulate 8 > $O/stats_dp8.log 2>&1
 # PMC passes (each on its own, no tracing)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_write.log 2>&1
