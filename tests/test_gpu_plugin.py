@@ -304,6 +304,50 @@ def test_pipelined_data_parallel_step_on_rccl_world1():
         os.environ.pop("NTF_DP_FORCE_ALLREDUCE", None); os.environ.pop("NTF_DP_RANGES", None)
 
 
+@pytest.mark.parametrize("side", ["1", "0"])
+def test_deferred_step_joins_its_side_stream_for_whoever_reads_first(side, monkeypatch):
+    """Round 5: a deferred-dW step (ntf_step_staged_deferred, a data-parallel rank's) runs its hidden layers' backward and loss reduction on the side stream, beside the dW
+    chunks the caller launches next; the join follows the LAST ntf_dw_chunk - or whatever reads the gradients / the loss first.  Gradients read (a) right behind the deferred
+    call with NO chunk launched (hidden layers: the reader joins), (b) behind the last chunk, and (c) after abandoning the chunks and stepping again, are those of the plain
+    backward of the same batch, bit for bit; the epoch loss accumulates the same sum.  NTF_DP_SIDE_BWD=0 keeps round 4's order on one stream."""
+    from opentf_amd import libntf
+    from opentf_amd.synth import init_params, zipf_csr
+    monkeypatch.setenv("NTF_DP_SIDE_BWD", side)
+    M, S, N, B = 140_000, 3_000, 6_000, 500     # 3 expert chunks of 65 536
+    s_ip, s_ix = zipf_csr(N, S, 8.57, 1); m_ip, m_ix = zipf_csr(N, M, 3.06, 2)
+    table = np.random.default_rng(0).standard_normal((S, 128), dtype=np.float32)
+    sd = init_params([128, 128, M], True, 0)
+    order = np.random.default_rng(1).integers(0, N, 2 * B)
+
+    def mk():
+        e = libntf.Engine([128, 128, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd="uniform", seed=5, fuse_adam=0)
+        e.set_skill_table(table); e.set_skill_csr((s_ip, s_ix)); e.set_member((m_ip, m_ix)); e.load_state_dict(sd)
+        e.stage_order(order); e.epoch_loss()
+        return e
+    ref = mk()
+    ref.step_staged(0, B, train=True, apply=False); g_ref = ref.grads(); l_ref, _ = ref.epoch_loss()
+    ref.step_staged(B, B, train=True, apply=False); g_ref2 = ref.grads(); ref.close()
+    hidden = [k for k in g_ref if k.startswith("layers.0.")]
+
+    e = mk()
+    assert e.dw_chunks() == 3
+    e.step_staged_deferred(0, B, 0, B)
+    g = e.grads()                                       # (a) no chunk launched: the reader joins the side stream
+    for k in hidden: assert np.array_equal(g[k], g_ref[k]), k
+    for k in range(3): e.dw_chunk(k)
+    g = e.grads()                                       # (b) behind the last chunk: every gradient
+    for k in g_ref: assert np.array_equal(g[k], g_ref[k]), k
+    l, steps = e.epoch_loss()
+    assert steps == 1 and l == l_ref
+    e.step_staged_deferred(0, B, 0, B)                  # (c) abandoned: the next step orders itself behind the chain that is still running
+    e.set_seed(5, 1)                                    # (the reference's second step drew with step index 1)
+    e.step_staged_deferred(B, B, B, B)
+    for k in range(3): e.dw_chunk(k)
+    g = e.grads()
+    for k in g_ref2: assert np.array_equal(g[k], g_ref2[k]), k
+    e.close()
+
+
 def test_expert_parallel_step_on_rccl_world1():
     """The expert-sharded step as the N-GPU bench runs it - phase 1, RCCL all-reduce of the engine-owned d(hidden) buffer on the engine's stream,
     phase 2, the epoch-end gather of the output layer - exercised on one GPU (world_size 1: the shard is the whole layer, the collective forced):
