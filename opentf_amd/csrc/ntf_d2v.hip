@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -66,25 +67,31 @@ __device__ __forceinline__ float d2v_sigmoid_table(float f) {
 // rows other waves add to: read past the CU's vector cache
 __device__ __forceinline__ float d2v_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+constexpr int D2V_TOP = 1024;       // cumulative table, first level: the last entry of each of <= 1024 equal buckets, in LDS (round 5: the bisection in memory was 13-16 dependent round trips a position;
+                                    // now ~5: PV-DM 61.5 -> 55.2 ms a pass.  Fetching a unit's six syn1neg rows up front instead of one by one was tried with it: 95 ms - the registers cost two waves per SIMD)
+
 // the negative-sampling unit: input x (registers), predicted word `word`; returns `work` in w[], adds g x to the rows of syn1neg it touches
 template <int NV>
-__device__ __forceinline__ void d2v_unit(const D2vArgs& a, const float (&x)[NV], int word, float alpha, int64_t doc, int pos, int unit, int lane, float (&w)[NV],
-                                         float& lsum, float& lcnt) {
+__device__ __forceinline__ void d2v_unit(const D2vArgs& a, const uint32_t* __restrict__ top, int top_n, int top_s, const float (&x)[NV], int word, float alpha, int64_t doc, int pos, int unit,
+                                         int lane, float (&w)[NV], float& lsum, float& lcnt) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) w[k] = 0.f;
     // lane k < 8 holds draw k: two Philox words of four draws each
     const uint4 r4 = d2v_draw(a, doc, pos, unit, SLOT_NEG0 + ((lane >> 2) & 1));
     const uint32_t rk = (lane & 3) == 0 ? r4.x : (lane & 3) == 1 ? r4.y : (lane & 3) == 2 ? r4.z : r4.w;
-    // bisect_left(cum_table, r % cum_table[-1])
+    // bisect_left(cum_table, r % cum_table[-1]): the bucket through the LDS level (the first bucket whose last entry is >= v holds the answer), then inside it
     int tgt;
     {
         const uint32_t v = rk % a.cum_table[a.n_vocab - 1];
-        int64_t lo = 0, hi = a.n_vocab;
+        int blo = 0, bhi = top_n;
+        while (blo < bhi) { const int mid = (blo + bhi) >> 1; if (top[mid] < v) blo = mid + 1; else bhi = mid; }
+        int64_t lo = (int64_t)blo * top_s, hi = min((int64_t)(blo + 1) * top_s, a.n_vocab);
+        if (blo >= top_n) { lo = a.n_vocab; hi = a.n_vocab; }        // (v is below cum_table[-1]: never taken)
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.cum_table[mid] < v) lo = mid + 1; else hi = mid; }
         tgt = (int)lo;
     }
     for (int k = 0; k <= a.negative; ++k) {
-        const int t = k == 0 ? word : __shfl(tgt, k - 1, 64);
+        const int t = __builtin_amdgcn_readfirstlane(k == 0 ? word : __shfl(tgt, k - 1, 64));      // (wave-uniform: row addresses in scalar registers)
         if (k > 0 && t == word) continue;
         const float label = k == 0 ? 1.f : 0.f;
         float* row = a.syn1neg + (int64_t)t * a.d;
@@ -101,11 +108,22 @@ __device__ __forceinline__ void d2v_unit(const D2vArgs& a, const float (&x)[NV],
     }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
+// DW > 0 (round 5): PV-DM with window == DW adds to a word vector ONCE per kept position instead of once per (position, window word).  A word at kept position m is a
+// window word of positions m - DW .. m + DW: a wave that walks the document front to back holds the sums of its own pending additions to the rows of positions
+// i - DW .. i + DW in registers (pend[2 DW + 1]: NV values a lane, shifted by one per position), reads a window row as memory + pending - exactly what the row would hold
+// had the additions been made (gensim's sequential order inside a document; other waves' additions arrive through memory as before) - and makes ONE atomic row add when the
+// position leaves the reach of every later window.  Per position: 1 + 6 atomic row adds instead of ~5 + 6 (the kernel runs at 0.8 of the chip's f32 atomic rate).  Two kept
+// positions inside one reach that hold the SAME word would each miss the other's pending sum: the wave then flushes what it holds and finishes the document the plain way.
+// (occupancy: the plain kernel fits six waves per SIMD in 78 registers when asked to - PV-DBOW 268 -> 253 ms a pass; the deferred one needs its 127: held to five or six it spills and loses 20 %)
+template <int NV, int DW = 0>
+__global__ __launch_bounds__(256, DW > 0 ? 1 : (NV <= 2 ? 6 : 5)) void k_d2v_epoch(D2vArgs a, int dm) {
     __shared__ int s_kept[4][D2V_RING];
+    __shared__ uint32_t s_top[D2V_TOP];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     int* kept = s_kept[wv_id];
+    const int top_s = (int)((a.n_vocab + D2V_TOP - 1) / D2V_TOP), top_n = (int)((a.n_vocab + top_s - 1) / top_s);     // buckets of top_s entries; top[k] = the last entry of bucket k
+    for (int k = threadIdx.x; k < top_n; k += blockDim.x) s_top[k] = a.cum_table[min((int64_t)(k + 1) * top_s, a.n_vocab) - 1];
+    __syncthreads();
     const int64_t first = a.serial ? 0 : (int64_t)blockIdx.x * 4 + wv_id;
     const int64_t stride = a.serial ? 1 : (int64_t)gridDim.x * 4;
     if (a.serial && (blockIdx.x != 0 || wv_id != 0)) return;
@@ -123,7 +141,20 @@ __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
         float* drow = a.dv + doc * a.d;
 #pragma unroll
         for (int q = 0; q < NV; ++q) dreg[q] = drow[lane + 64 * q];
-        for (int i = 0;; ++i) {
+        constexpr int NPEND = DW > 0 ? 2 * DW + 1 : 1;
+        float pend[NPEND][NV];             // DW > 0: index j <-> kept position i - DW + j
+        bool defer = DW > 0;
+#pragma unroll
+        for (int j = 0; j < NPEND; ++j)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) pend[j][q] = 0.f;
+        auto flush_row = [&](int m, const float (&v)[NV]) {
+            float* r = a.wv + (int64_t)__builtin_amdgcn_readfirstlane(kept[m & (D2V_RING - 1)]) * a.d;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) unsafeAtomicAdd(r + lane + 64 * q, v[q]);
+        };
+        int i = 0;
+        for (;; ++i) {
             while (K < i + a.window + 1 && base < L && K < D2V_MAX_DOC) {
                 const int p = base + lane;
                 int wd = 0; bool keep = false;
@@ -136,29 +167,82 @@ __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
                 __builtin_amdgcn_wave_barrier();
             }
             if (i >= K) break;
-            const int b = (int)(d2v_draw(a, doc, i, 0, SLOT_WINDOW).x % (uint32_t)a.window), word = kept[i & (D2V_RING - 1)];
+            const int b = (int)(d2v_draw(a, doc, i, 0, SLOT_WINDOW).x % (uint32_t)a.window), word = __builtin_amdgcn_readfirstlane(kept[i & (D2V_RING - 1)]);
             // (K is final here whenever it bounds the window: K < i + window + 1 only once every raw word has been scanned or the cap is reached)
             const int lo = max(0, i - a.window + b), hi = min(K, i + a.window + 1 - b);
             float work[NV];
-            if (dm) {
+            if (DW > 0 && dm) {
+                if (defer) {
+                    // the same word at two kept positions of this reach?  lane j holds the word of position i - DW + j (a different negative number where there is none)
+                    const int mj = i - DW + lane;
+                    const int wj = (lane < NPEND && mj >= 0 && mj < K) ? kept[mj & (D2V_RING - 1)] : -1 - lane;
+                    bool dup = false;
+#pragma unroll
+                    for (int o = 1; o < NPEND; ++o) dup |= (__shfl(wj, (lane + o) & 63, 64) == wj) && lane + o < NPEND;
+                    if (__ballot(dup) != 0ull) {
+#pragma unroll
+                        for (int j = 0; j < NPEND; ++j) {
+                            const int m = i - DW + j;
+                            if (m >= 0 && m < K) flush_row(m, pend[j]);
+#pragma unroll
+                            for (int q = 0; q < NV; ++q) pend[j][q] = 0.f;
+                        }
+                        defer = false;
+                    }
+                }
+                float l1[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) l1[q] = dreg[q];
+#pragma unroll
+                for (int j = 0; j < NPEND; ++j) {
+                    const int m = i - DW + j;
+                    if (j == DW || m < lo || m >= hi) continue;
+                    const float* r = a.wv + (int64_t)__builtin_amdgcn_readfirstlane(kept[m & (D2V_RING - 1)]) * a.d;
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) l1[q] += d2v_ld(r + lane + 64 * q) + pend[j][q];
+                }
+                const float inv = 1.f / (float)(hi - lo);               // (hi - lo - 1) window words + the doc tag
+#pragma unroll
+                for (int q = 0; q < NV; ++q) l1[q] *= inv;
+                d2v_unit<NV>(a, s_top, top_n, top_s, l1, word, alpha, doc, i, 0, lane, work, lsum, lcnt);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) dreg[q] += work[q];
+#pragma unroll
+                for (int j = 0; j < NPEND; ++j) {
+                    const int m = i - DW + j;
+                    if (j == DW || m < lo || m >= hi) continue;
+                    if (defer) {
+#pragma unroll
+                        for (int q = 0; q < NV; ++q) pend[j][q] += work[q];
+                    } else flush_row(m, work);
+                }
+                // position i - DW is in no later window: its row takes the sum; every slot moves one down
+                if (defer && i - DW >= 0) flush_row(i - DW, pend[0]);
+#pragma unroll
+                for (int j = 0; j + 1 < NPEND; ++j)
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) pend[j][q] = pend[j + 1][q];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) pend[NPEND - 1][q] = 0.f;
+            } else if (dm) {
                 float l1[NV];
 #pragma unroll
                 for (int q = 0; q < NV; ++q) l1[q] = dreg[q];
                 for (int m = lo; m < hi; ++m) {
                     if (m == i) continue;
-                    const float* r = a.wv + (int64_t)kept[m & (D2V_RING - 1)] * a.d;
+                    const float* r = a.wv + (int64_t)__builtin_amdgcn_readfirstlane(kept[m & (D2V_RING - 1)]) * a.d;
 #pragma unroll
                     for (int q = 0; q < NV; ++q) l1[q] += d2v_ld(r + lane + 64 * q);
                 }
                 const float inv = 1.f / (float)(hi - lo);               // (hi - lo - 1) window words + the doc tag
 #pragma unroll
                 for (int q = 0; q < NV; ++q) l1[q] *= inv;
-                d2v_unit<NV>(a, l1, word, alpha, doc, i, 0, lane, work, lsum, lcnt);
+                d2v_unit<NV>(a, s_top, top_n, top_s, l1, word, alpha, doc, i, 0, lane, work, lsum, lcnt);
 #pragma unroll
                 for (int q = 0; q < NV; ++q) dreg[q] += work[q];
                 for (int m = lo; m < hi; ++m) {
                     if (m == i) continue;
-                    float* r = a.wv + (int64_t)kept[m & (D2V_RING - 1)] * a.d;
+                    float* r = a.wv + (int64_t)__builtin_amdgcn_readfirstlane(kept[m & (D2V_RING - 1)]) * a.d;
 #pragma unroll
                     for (int q = 0; q < NV; ++q) unsafeAtomicAdd(r + lane + 64 * q, work[q]);
                 }
@@ -166,18 +250,25 @@ __global__ __launch_bounds__(256) void k_d2v_epoch(D2vArgs a, int dm) {
                 int u = 0;
                 for (int m = lo; m < hi; ++m) {
                     if (m == i) continue;
-                    float* r = a.wv + (int64_t)kept[m & (D2V_RING - 1)] * a.d;
+                    float* r = a.wv + (int64_t)__builtin_amdgcn_readfirstlane(kept[m & (D2V_RING - 1)]) * a.d;
                     float x[NV];
 #pragma unroll
                     for (int q = 0; q < NV; ++q) x[q] = d2v_ld(r + lane + 64 * q);
-                    d2v_unit<NV>(a, x, word, alpha, doc, i, 1 + u, lane, work, lsum, lcnt);
+                    d2v_unit<NV>(a, s_top, top_n, top_s, x, word, alpha, doc, i, 1 + u, lane, work, lsum, lcnt);
 #pragma unroll
                     for (int q = 0; q < NV; ++q) unsafeAtomicAdd(r + lane + 64 * q, work[q]);
                     ++u;
                 }
-                d2v_unit<NV>(a, dreg, word, alpha, doc, i, 0, lane, work, lsum, lcnt);
+                d2v_unit<NV>(a, s_top, top_n, top_s, dreg, word, alpha, doc, i, 0, lane, work, lsum, lcnt);
 #pragma unroll
                 for (int q = 0; q < NV; ++q) dreg[q] += work[q];
+            }
+        }
+        if (DW > 0 && dm && defer) {      // the document has ended at i = K: index j still stands for position i - DW + j; those below K hold sums
+#pragma unroll
+            for (int j = 0; j < DW; ++j) {
+                const int m = i - DW + j;
+                if (m >= 0 && m < K) flush_row(m, pend[j]);
             }
         }
 #pragma unroll
@@ -273,6 +364,15 @@ extern "C" int ntf_d2v_train_epoch(ntf_d2v* h, int32_t dm, int32_t window, int32
     const int64_t want = (h->n_docs + 3) / 4;
     const dim3 grid(serial ? 1u : (unsigned)std::min<int64_t>(want, 256 * 16)), block(serial ? 64 : 256);
     if (device_ms) { if (!h->ev0) { DCHK(h, hipEventCreate(&h->ev0)); DCHK(h, hipEventCreate(&h->ev1)); } DCHK(h, hipEventRecord(h->ev0, h->st)); }
+    // PV-DM at the reference's window (src/mdl/emb/__config__.yaml: w = 5): word-vector additions deferred to one per kept position (k_d2v_epoch<.., 5>); NTF_D2V_DEFER=0: the plain kernel
+    static const bool defer_ok = !(getenv("NTF_D2V_DEFER") && atoi(getenv("NTF_D2V_DEFER")) == 0);
+    if (dm && window == 5 && defer_ok && h->d >= 128) {     // (d = 64: the rows are 256 B and the plain kernel's shorter chain wins - 45.7 against 49.4 ms; d = 128 / 192 / 256: 55 / 78 / 98 against 66 / 102 / 133)
+        switch (h->d / 64) {
+            case 2: hipLaunchKernelGGL((k_d2v_epoch<2, 5>), grid, block, 0, h->st, a, dm); break;
+            case 3: hipLaunchKernelGGL((k_d2v_epoch<3, 5>), grid, block, 0, h->st, a, dm); break;
+            default: hipLaunchKernelGGL((k_d2v_epoch<4, 5>), grid, block, 0, h->st, a, dm); break;
+        }
+    } else
     switch (h->d / 64) {
         case 1: hipLaunchKernelGGL(k_d2v_epoch<1>, grid, block, 0, h->st, a, dm); break;
         case 2: hipLaunchKernelGGL(k_d2v_epoch<2>, grid, block, 0, h->st, a, dm); break;

@@ -41,5 +41,13 @@ rm -rf $O/stats_dp8; rocprofv3 --kernel-trace --stats --output-format csv -d $O/
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 $B --no-gather-bench --steps 3 --warmup 1 > $O/pmc_sq.log 2>&1
+# doc2vec (round 5: PV-DM's word-vector additions deferred to one per kept position): passes, kernel stats, and the bytes through the fabric, with and without (NTF_D2V_DEFER=0)
+python3 $R/profiles/d2v_pass.py > $O/d2v_passes.txt 2>&1
+NTF_D2V_DEFER=0 python3 $R/profiles/d2v_pass.py > $O/d2v_passes_NTF_D2V_DEFER_0.txt 2>&1
+rm -rf $O/d2v_stats $O/d2v_pmc_fetch $O/d2v_pmc_write $O/d2v_pmc_tcc
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/d2v_stats -- python3 $R/profiles/d2v_pass.py > $O/d2v_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/d2v_pmc_fetch -- python3 $R/profiles/d2v_pass.py > $O/d2v_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/d2v_pmc_write -- python3 $R/profiles/d2v_pass.py > $O/d2v_pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum --output-format csv -d $O/d2v_pmc_tcc -- python3 $R/profiles/d2v_pass.py > $O/d2v_pmc_tcc.log 2>&1
 find $O -name "*.db" -delete 2>/dev/null; find $O -name "*_agent_info.csv" -delete 2>/dev/null
 du -sh $O | tail -1

@@ -1,4 +1,4 @@
-"""three doc2vec passes over the bench's dblp-shaped corpus (the program profiled for profiles/r3_d2v_kernel_stats.csv)"""
+"""three doc2vec passes over the bench's dblp-shaped corpus (the program profiled for profiles/r3_d2v_kernel_stats.csv); D2V_DIM=64|128|192|256: the vector width (default 128)"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ from opentf_amd.synth import make_dataset          # noqa: E402
 ds = make_dataset("dblp", d=128, seed=0)
 ptr, idx = ds["skill"][0], ds["skill"][1]
 keys, count, si, cum, wi = P.build_vocab(idx)
-wv, dv = P.initial_vectors(len(ptr) - 1, len(keys), 128, 0)
+wv, dv = P.initial_vectors(len(ptr) - 1, len(keys), int(os.environ.get("D2V_DIM", "128")), 0)
 net = libntf.Doc2Vec(ptr, wi, si, cum, wv, dv, seed=0)
 prog = P.job_progress(ptr)
 for dm in (1, 1, 1, 0):
