@@ -118,13 +118,11 @@ struct ntf_engine {
     // the dW + Adam kernel of a train step also produced the NEXT step's output-layer operands (FusedDw.produce): valid for step pre_step as long as nothing else
     // touched the output layer's parameters or the operand buffers (Wp, split planes); d_kl[2] / d_range[4] hold that step's KL and range flag until it starts
     int merge_bias = 1;               // NTF_MERGE_BIAS=0: the next step's output-bias operand as k_head's bias workgroups in a launch of their own behind the bias Adam, as in round 4 (A/B runs)
-    uint64_t spec_step = 0;           // step + 1 whose special-entry list (k_special_list) is in that step's workspace set
     int dp_side_bwd = 1;              // NTF_DP_SIDE_BWD=0: a deferred-dW (data-parallel) step runs its hidden layers' backward on the main stream in front of the dW chunks, as in round 4 (A/B runs)
     int dp_ranges = 1;                // NTF_DP_RANGES=0: a data-parallel rank waits for every parameter all-gather before its step, as in round 4 (A/B runs, tests)
     int ep_head_prefetch = -1;        // NTF_EP_HEAD_PREFETCH: an expert shard's phase 3 issues the next batch's head behind its hidden backward, beside its dW kernel (phase 2).  -1 (default): when the
                                       // dW kernel outlasts the backward (B x 8 <= the shard's experts: ranks of 2-4 at config 2; 1.27 against 1.33 ms at a rank of 4, neutral at 8 where both end together);
                                       // 0 never; 2 always; 1 always, with the sampler / sign words on the auxiliary stream from the end of phase 1 (beside the whole dW kernel: slower, 1.34 against 1.30 at 8)
-    int fix_in_fwd = 0;               // NTF_FIX_IN_FWD=1 (experiment, measured 0.008-0.015 ms SLOWER: DESIGN.md section 4.0): the forward kernel handles the special entries itself, the sparse fix-up leaves the main stream
     int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
@@ -140,7 +138,7 @@ struct ntf_engine {
     uint16_t* pl_mu = nullptr; uint16_t* pl_wp = nullptr;   // bf16 split planes of the output layer's mu / Wp (bf16x6 arithmetic)
     hipStream_t st2 = nullptr;        // side stream: Adam of finished expert chunks runs beside the dW kernel of the next chunk
     hipEvent_t ev_chunk = nullptr, ev_side = nullptr;
-    hipStream_t st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fix = nullptr;   // the hidden layers' backward runs beside the output layer's dW kernel
+    hipStream_t st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the hidden layers' backward runs beside the output layer's dW kernel
     hipStream_t st4 = nullptr; hipEvent_t ev_aux = nullptr;   // auxiliary stream: what the step's head needs from the row ids / sign keys only (sampler, s_out words)
     int side_bwd = 1;                 // NTF_SIDE_BWD=0 keeps the whole step on one stream (A/B runs)
     // expert-sharded output layer (ntf_config.expert_lo ..): this engine owns experts [ep_lo, ep_lo + dims[L]) of Mg
@@ -249,7 +247,6 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
 #endif
     if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
-    if (const char* fx = getenv("NTF_FIX_IN_FWD")) e->fix_in_fwd = atoi(fx);
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
     if (const char* eh = getenv("NTF_EP_HEAD_PREFETCH")) e->ep_head_prefetch = atoi(eh);
     if (const char* dr = getenv("NTF_DP_RANGES")) e->dp_ranges = atoi(dr);
@@ -321,7 +318,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     if (e->st) hipStreamSynchronize(e->st);
     // the side streams are drained and destroyed BEFORE any buffer their kernels may still touch is freed
     if (e->st4) { hipStreamSynchronize(e->st4); hipStreamDestroy(e->st4); hipEventDestroy(e->ev_aux); }
-    if (e->st3) { hipStreamSynchronize(e->st3); hipStreamDestroy(e->st3); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_fix); }
+    if (e->st3) { hipStreamSynchronize(e->st3); hipStreamDestroy(e->st3); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); }
     if (e->st2) { hipStreamSynchronize(e->st2); hipStreamDestroy(e->st2); hipEventDestroy(e->ev_chunk); hipEventDestroy(e->ev_side); }
     dfree(e->P); dfree(e->G); dfree(e->M1); dfree(e->V2);
     dfree(e->m_indptr); dfree(e->m_indices); dfree(e->s_indptr); dfree(e->s_indices); dfree(e->table); dfree(e->Xall);
@@ -755,17 +752,9 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
     return NTF_OK;
 }
 
-// the batch's special entries (positives + its negatives, sampled or injected) listed for the forward kernel's own fix-up (FusedOut.fix_in_fwd), behind the sampler
-static void list_specials(ntf_engine* e, const StepCtx& c, char* ws) {
-    if (!fused_ok(e) || !c.train || !e->fix_in_fwd || e->layers[e->L - 1].in != 128) return;
-    const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg_set[c.step & 1] : nullptr;
-    launch_fused_special_list(e->st, c.B, e->layers[e->L - 1].in, e->cfg.dims[e->L], ws, c.rows_dev, e->m_indptr, e->m_indices, neg, e->cfg.ns);
-    e->spec_step = c.step + 1;      // (+ 1: 0 = never)
-}
-
 struct StreamRestore { ntf_engine* e; hipStream_t main; ~StreamRestore() { e->st = main; } };   // launches and timing scopes follow e->st
 static int side_stream(ntf_engine* e) {
-    if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fix, hipEventDisableTiming)); }
+    if (!e->st3) { HIPCHK(e, hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
     if (!e->st4) { HIPCHK(e, hipStreamCreateWithFlags(&e->st4, hipStreamNonBlocking)); HIPCHK(e, hipEventCreateWithFlags(&e->ev_aux, hipEventDisableTiming)); }
     return NTF_OK;
 }
@@ -900,7 +889,6 @@ static int prefetch_next_head(ntf_engine* e, const StepCtx& c, hipStream_t head_
         if ((r = set_batch_unigram(e, e->hp_next_host, n.B, ub_next, e->st4))) return r;
     }
     if ((r = sample_negatives(e, n))) return r;
-    list_specials(e, n, ws_next);
     const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
     { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1); }
     HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
@@ -925,7 +913,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const double out_nw = (double)e->Mg * lo.in, out_nb = (double)e->Mg;   // element counts of the WHOLE output layer (= lo.nw(), lo.out unless expert-sharded)
     int nslots;
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg_set[c.step & 1] : nullptr;
-    bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false, early_fork = false;
+    bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false;
     // one kernel for gather -> hidden layer -> operand images (ntf_head.hip): one hidden layer of 128 units over a dense / mean-pooled input, native generators, fp16x3 planes
     const bool use_head = fused && e->head && e->L == 2 && c.part <= 1 && !c.inj && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
                           (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
@@ -982,7 +970,6 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], e->P + lo.off[NTF_P_BIAS], lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                    1.0 / out_nb, e->d_kl); }
         if ((r = sample_negatives(e, c))) return r;
-        list_specials(e, c, e->fws);
         if (c.train && e->cfg.bayesian && e->cfg.mfma != NTF_MFMA_F32 && mfma_np(e) == 2 && lo.in == 128 && e->pl_mu != nullptr) {
             const SignSpec so = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out), si = sign_spec(e, c, e->L - 1, T_S_IN, lo.in);
             if (so.inj == nullptr && si.inj == nullptr) {   // (injected signs: the words are transposed from the packed image k_sign_bits writes on the main stream)
@@ -995,7 +982,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         aux = true;
     }
     if (!use_head && (r = make_input(e, c))) return r;
-    if (!aux && !hp_hit) { if ((r = sample_negatives(e, c))) return r; list_specials(e, c, e->fws); }
+    if (!aux && !hp_hit) { if ((r = sample_negatives(e, c))) return r; }
     if (fused) {
         if (!use_head && (r = forward_layers(e, c, false, true))) return r;
         FusedOut f;
@@ -1046,12 +1033,6 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
-        // Round 5: in a whole train step on the wave-pair forward kernel the sparse fix-up (23 us) leaves the main stream.  The forward kernel handles the special entries
-        // itself (FusedOut.fix_in_fwd: dz, loss terms, d(hidden) terms, from the list k_special_list made beside the sampler), so the dW kernel follows it directly; what is
-        // left of the fix-up - sums of the partials - runs on the side stream in front of the loss reduction and the hidden layers' backward.  The two no-op launches
-        // of a range fallback stay on the main stream (launched on the side stream beside the dW kernel, the exact-f32 forward kernel's 132 KB workgroups would find no
-        // CU until that kernel drains, and stall everything queued behind them - measured: +0.06 ms); only the exact-f32 dW launch waits for the side stream (ev_fix).
-        early_fork = side && c.train && f.dh != nullptr && f.bf16x6 && f.np == 2 && lo.in == 128 && (e->fwd_kernel < 0 || e->fwd_kernel == 5) && e->fix_in_fwd && e->spec_step == c.step + 1;
         if (use_pre && e->lean) {
             // this step's operands came from the previous step's dW epilogue, which (lean) left no f32 copy of sigma * eps: only a step that falls back to the exact-f32 kernels
             // reads one, and makes it here - a capped grid that exits at once unless the range flag is raised (behind the head: k_head may still raise it)
@@ -1059,7 +1040,6 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, nullptr,
                                    nullptr, nullptr, nullptr, 0, 3, 1.f, nullptr, range_ptr(e));
         }
-        f.fix_in_fwd = early_fork ? 1 : 0;
 #ifdef NTF_DIAG
         if (e->cosched > 0 && c.train) {
             f.ncg_limit = e->cosched;
@@ -1095,15 +1075,6 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 8); }
         } else
         { Scope t(e, F_OUT_FUSED_FWD); launch_fused_out_fwd(e->st, f, 2); }
-        if (early_fork) {
-            if ((r = side_stream(e))) return r;
-            HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
-            HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
-            StreamRestore guard{e, e->st};
-            e->st = e->st3;
-            { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
-            HIPCHK(e, hipEventRecord(e->ev_fix, e->st3));
-        } else
         { Scope t(e, F_OUT_FUSED_AUX); launch_fused_out_fwd(e->st, f, 4); }
         nslots = fused_loss_slots(M);
     } else {
@@ -1130,10 +1101,8 @@ backward:
     StreamRestore restore{e, e->st};
     if (side) {
         if ((r = side_stream(e))) return r;
-        if (!early_fork) {      // (early_fork: the side stream left the main stream behind the forward kernel already)
-            HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
-            HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
-        }
+        HIPCHK(e, hipEventRecord(e->ev_fork, e->st));
+        HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
         if (loss_side) {
             e->st = e->st3;
             { Scope t(e, F_LOSS);
@@ -1226,14 +1195,6 @@ backward:
 #ifdef NTF_DIAG
             if (e->cosched > 0) { e->cosched_dw = f; e->cosched_have = true; goto dw_done; }      // (this step's dW rides beside the NEXT step's forward kernel: timing only)
 #endif
-            if (early_fork && f.rflag) {
-                // the exact-f32 dW launch of a range fallback reads what the side stream's exact-f32 forward + sparse fix-up leave: it alone waits for them
-                FusedDw fq = f; fq.no_fallback = 1;
-                { Scope t(e, F_OUT_FUSED_DW); if ((r = dw_launch_whole(e, fq))) return r; }
-                HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_fix, 0));
-                FusedDw fb = f; fb.fallback_only = 1;
-                launch_fused_out_dw(e->st, fb);
-            } else
             { Scope t(e, F_OUT_FUSED_DW); if ((r = dw_launch_whole(e, f))) return r; }
         dw_done:;
         } else {

@@ -30,7 +30,6 @@ struct FusedOut {
                                                     // 3 k_out_fwd_h3x - one wave per SIMD, 64-expert tiles, phases rotated across tiles (round 3's default); 0 the 32-expert-tile kernel
                                                     // k_out_fwd_b6.  NTF_FWD_KERNEL selects the A/B forms (round 3's sixteen-row-wave form, 4, was retired in round 5)
     int ncg_limit = 0;                              // > 0 (diagnostics, NTF_COSCHED): at most this many column groups, i.e. a forward grid of NRB * ncg_limit workgroups that leaves CUs free
-    int fix_in_fwd = 0;                             // np = 2 training step on k_out_fwd_h3p: the forward kernel corrects the special entries of dzT itself (phase 4 then leaves dzT alone)
     int split_fallback = 0;                         // the exact-f32 forward launch behind the split-product kernel is NOT part of phase 2 but a phase of its own (8)
     // the split-product forward over a RANGE of the experts (k_out_fwd_h3p only; data-parallel ranks launch one range per all-gathered parameter chunk): 64-expert tiles
     // [chunk_t_lo, chunk_t_hi) on chunk_ncg column groups, whose dh slabs / loss partials are chunk_cg_off .. of chunk_ncg_tot in all.  chunk_ncg_tot > 0 with chunk_ncg = 0:
@@ -97,8 +96,6 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
 // s_out != null: also the transposed s_out sign words the packed fp16x3 dW kernel reads (k_sign_words_T)
 void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 3, float h_scale = 1.f, const SignSpec* s_out = nullptr, int s_out_inj = 0, int which = 3);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
-// the special entries (positives + sampled negatives, duplicates dropped) of the batch's rows into the workspace: what FusedOut.fix_in_fwd reads (behind the sampler)
-void launch_fused_special_list(hipStream_t st, int B, int H, int M, void* ws, const int64_t* rows, const int64_t* m_indptr, const int32_t* m_indices, const int64_t* neg, int ns);
 // after a probs pass: ent_rows[i] += scale * the pass's entropy terms (nullable); transpose: P [B, M] = PT^T
 // unpack_inv_scale > 0: PT holds packed fp16 plane pairs (the fp16x3 step's dzT): P = (hi + lo) * unpack_inv_scale
 void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws, const float* PT, float* P, float* ent_rows, float scale, bool transpose,

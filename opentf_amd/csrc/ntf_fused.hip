@@ -383,9 +383,6 @@ struct OutFwd6Args {
     int plogit;                      // PROBS: store the logit leaky_relu(z) itself instead (ntf_logits: the quantity the 1e-4 parity bar is stated on)
     unsigned long long* stamps;           // diagnostics (k_out_fwd_h3x<.., ABL = 9>): per wave 8 cycle sums, see NTF_FWD_STAMP
     float h_scale, dz_scale, u_z, u_dh;   // fp16x3 (NP = 2): scales applied to h / dz before their split, and 1/(w scale * h scale), 1/(dz scale * w scale); 1 for bf16x6
-    // k_out_fwd_h3p, enable != 0: the workgroup corrects the special entries (positives, sampled negatives) of ITS rows x ITS experts in dzT itself, behind its tile loop -
-    // the dW kernel can then follow the forward kernel directly, and the sparse fix-up kernel (loss terms, d(hidden)) runs beside it on the side stream
-    struct Fix { const int64_t *rows, *m_indptr, *neg; const int32_t* m_indices; const int* spec; int ns, c_lo, enable; float tpw, wp_inv_scale; } fix;
 };
 // fp16x3 training step: dzT holds, per element, the two fp16 planes of dz * dz_scale packed in one dword (hi | lo << 16) - the split the forward
 // kernel makes anyway for its dh products - so that the dW kernel reads MFMA operands instead of splitting f32 values again
@@ -1237,107 +1234,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             __syncthreads();
         }
     };
-    // ---- the special entries (pp.fix): src/mdl/fnn.py:32-46 gives the positives and the sampled negatives of a row the weight tpw (the positives label 1).  Which they are
-    // is listed per row by k_special_list (beside the sampler, off the step's critical path); behind the tile loop every quarter-wave takes four rows, keeps the entries
-    // that fall on THIS workgroup's experts and recomputes their logits (special_z16: the sparse fix-up kernel's own function).
-    auto fix_row_info = [&](int r, int64_t& pb, int& npos, int& total) -> bool {
-        const int irow = rb * BM + r;
-        if (irow >= p.B) { pb = 0; npos = 0; total = 0; return false; }
-        const int64_t team = pp.fix.rows[irow];
-        pb = pp.fix.m_indptr[team]; npos = (int)(pp.fix.m_indptr[team + 1] - pb); total = npos + (pp.fix.neg ? pp.fix.ns : 0);
-        return true;
-    };
-    auto fix_mine = [&](int cv) -> int {          // a listed candidate (global id | label << 30, or -1) -> local id | label << 30 if it is one of this workgroup's experts, else -1
-        if (cv < 0) return -1;
-        const int c = (cv & 0x3FFFFFFF) - pp.fix.c_lo;
-        if (c < 0 || c >= p.M || c < 32 * s_beg || c >= 32 * s_end) return -1;
-        return c | (cv & (1 << 30));
-    };
-    auto fix_cand = [&](int r, int64_t pb, int npos, int total, int sidx) -> int {      // (rows with more than SPEC_W candidates: the rest straight from memory)
-        if (sidx >= total) return -1;
-        float y;
-        const int c = special_candidate(pp.fix.m_indices, pp.fix.neg, pb, npos, pp.fix.ns, rb * BM + r, sidx, y);
-        return fix_mine(c < 0 ? -1 : (c | (y != 0.f ? (1 << 30) : 0)));
-    };
-    // every wave, behind its tile loop.  For each special entry of its rows x this workgroup's experts: the logit again (special_z16), then everything the sparse fix-up
-    // kernel derives from it - the entry's dz (overwritten in dzT), its loss correction (added to this workgroup's loss partial of the row) and its d(hidden) terms (added
-    // to this workgroup's dh slab row) - so that the kernel which follows on the side stream only SUMS partials and never reads the weights the dW + Adam kernel is
-    // updating in place beside it.  A row's entries are one quarter-wave's, visited in candidate order: the sums are deterministic.
-    auto fix_dz = [&]() {
-        if (!pp.fix.enable) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's dzT / slab / loss-partial stores have completed ...
-        __syncthreads();                                          // ... and every other wave's (both roles call fix_dz exactly once)
-        const int g = wave_u * 4 + (lane >> 4), l16 = lane & 15;
-        const bool wp_planes = BAYES && pp.wp_pl != nullptr;
-        // the four rows' lists first (independent loads: one round trip instead of four), then row by row
-        int totals[4], cands[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int irow = rb * BM + g * 4 + rr;
-            totals[rr] = irow < p.B ? pp.fix.spec[(int64_t)p.Bpad * SPEC_W + irow] : 0;
-            cands[rr] = irow < p.B ? pp.fix.spec[(int64_t)irow * SPEC_W + l16] : -1;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = g * 4 + rr, irow = rb * BM + r;
-            const int total = totals[rr];
-            int cand = fix_mine(cands[rr]);
-            float hr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hsr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float lfix = 0.f;
-            uint32_t siw = 0u;          // s_in signs of this lane's 8 hidden units (bit k)
-            bool have_h = false, have_info = false;
-            int64_t pb = 0; int npos = 0, tot2 = 0;
-#pragma unroll 1
-            for (int k0 = 0; k0 < total; k0 += 16) {
-                if (k0 > 0) {        // a row with more than 16 candidates: the rest straight from memory
-                    if (!have_info) { fix_row_info(r, pb, npos, tot2); have_info = true; }
-                    cand = fix_cand(r, pb, npos, total, k0 + l16);
-                }
-                uint32_t m16 = (uint32_t)(__ballot(cand >= 0) >> (16 * (lane >> 4))) & 0xFFFFu;
-                if (m16 && !have_h) {
-                    have_h = true;
-                    const float4 a = *reinterpret_cast<const float4*>(p.h + (int64_t)irow * H + 8 * l16), b = *reinterpret_cast<const float4*>(p.h + (int64_t)irow * H + 8 * l16 + 4);
-                    hr[0] = a.x; hr[1] = a.y; hr[2] = a.z; hr[3] = a.w; hr[4] = b.x; hr[5] = b.y; hr[6] = b.z; hr[7] = b.w;
-                    if (BAYES) {
-                        const float4 c4 = *reinterpret_cast<const float4*>(p.hs + (int64_t)irow * H + 8 * l16), d4 = *reinterpret_cast<const float4*>(p.hs + (int64_t)irow * H + 8 * l16 + 4);
-                        hsr[0] = c4.x; hsr[1] = c4.y; hsr[2] = c4.z; hsr[3] = c4.w; hsr[4] = d4.x; hsr[5] = d4.y; hsr[6] = d4.z; hsr[7] = d4.w;
-                        const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + (l16 >> 2)] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)(l16 >> 2));
-                        siw = (w >> (8 * (l16 & 3))) & 0xFFu;
-                    }
-                }
-                while (m16) {
-                    const int src = __builtin_ctz(m16); m16 &= m16 - 1;
-                    const int cv = __shfl(cand, (lane & 48) + src, 64);
-                    const int c = cv & 0x3FFFFFFF; const float y = (cv >> 30) & 1 ? 1.f : 0.f;
-                    float mu_r[8], wp_r[8], so, sp, sg, dact;
-                    const float z = special_z16<BAYES>(p.mu, p.mu_b, p.wp, p.bp, pp.wp_pl, pp.fix.wp_inv_scale, wp_planes, p.sbits, p.nCB, p.so_k0, p.so_k1, p.so_inj, irow, c, l16, hr, hsr, mu_r, wp_r, so);
-                    const float dzt = special_dz(z, y, pp.fix.tpw, p.inv_B, sp, sg, dact);
-                    const float lz = z > 0.f ? z : z * kLeakySlope;
-                    lfix += pp.fix.tpw * (sp - lz * y) - p.tnw * sp;
-                    const float delta = dzt - p.tnw * sg * dact * p.inv_B;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        dv[k] += delta * mu_r[k];
-                        if (BAYES) dv[k] += delta * so * wp_r[k] * (((siw >> k) & 1u) ? -1.f : 1.f);
-                    }
-                    if (l16 == 0) reinterpret_cast<uint32_t*>(p.dzT)[dzt_index(c, irow, p.Bpad)] = special_dz_packed(dzt, pp.dz_scale);
-                }
-            }
-            if (have_h) {       // (quarter-uniform) this row had entries here: its slab row and loss partial, written by this workgroup's waves above, take the corrections
-                float* sl = p.slab + ((int64_t)(cg + p.cg_off) * p.Bpad + irow) * H + 8 * l16;
-                float cur[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) cur[k] = __hip_atomic_load(sl + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1: the row was stored by another wave)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sl[k] = cur[k] + dv[k];
-                if (l16 == 0) {
-                    float* lp = p.lossp + (int64_t)irow * p.ncg_tot + p.cg_off + cg;
-                    *lp = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + lfix;
-                }
-            }
-        }
-    };
-
     if (role == 0) {
         // ================================================================ wave A: zT, logits, DMA
         u32x4 hp[NKS][2], hs[NKS][2];               // B operand of zT: fp16 planes of h[i][16 s + 8 half ..] and of h * s_in
@@ -1514,7 +1410,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
         float lsum = lacc.sum;
         lsum += __shfl_xor(lsum, 32, 64);
         if (half == 0) p.lossp[(int64_t)i * p.ncg_tot + p.cg_off + cg] = p.tnw * lsum;
-        fix_dz();
         return;
     }
 
@@ -1663,7 +1558,6 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
             p.slab[((int64_t)(cg + p.cg_off) * p.Bpad + irow) * H + 32 * jt + il] = v;
         }
     }
-    fix_dz();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1723,9 +1617,6 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     s.so_k0 = f.s_out.k0; s.so_k1 = f.s_out.k1; s.so_inj = inj;
     s.dz_pack_scale = (f.train && f.bf16x6 && f.H == 128 && f.np == 2) ? f.dz_scale : 0.f; s.rflag = f.rflag; s.c_lo = f.c_lo;
     s.wp_pl = (f.bayes && f.bf16x6 && f.H == 128 && f.np == 2 && f.wp_pl) ? f.wp_pl : nullptr; s.wp_inv_scale = 1.f / f.w_scale;
-    // the wave-pair forward kernel corrects the special entries of dzT itself (FusedOut.fix_in_fwd): the fix-up kernel then leaves dzT alone unless the step fell back to f32
-    const bool fwd_fixes = f.fix_in_fwd && f.bf16x6 && f.H == 128 && f.np == 2 && f.train && f.dh != nullptr && f.wide == 5 && !f.probs;
-    s.dz_in_fwd = fwd_fixes ? 1 : 0;
     int grid = g.NRB * g.NCG;
     const bool range_launch = ranged && f.chunk_ncg > 0 && (phases & 2);      // THIS call launches one range
     if (range_launch) { a.t_lo = f.chunk_t_lo; a.t_hi = f.chunk_t_hi; a.cg_off = f.chunk_cg_off; a.ncg_tot = f.chunk_ncg_tot; a.NCG = f.chunk_ncg; grid = g.NRB * f.chunk_ncg; }
@@ -1738,8 +1629,6 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
         }
         if (phases & 2) {
             OutFwd6Args a6; a6.stamps = nullptr; a6.a = a; a6.mu_pl = f.mu_pl; a6.wp_pl = f.wp_pl; a6.pscale = f.pscale; a6.pacc = f.pacc; a6.plogit = f.plogit;
-            a6.fix.rows = f.rows; a6.fix.m_indptr = f.m_indptr; a6.fix.m_indices = f.m_indices; a6.fix.neg = f.neg; a6.fix.ns = f.ns; a6.fix.c_lo = f.c_lo;
-            a6.fix.enable = fwd_fixes ? 1 : 0; a6.fix.tpw = f.tpw; a6.fix.wp_inv_scale = 1.f / f.w_scale; a6.fix.spec = reinterpret_cast<const int*>(ws + w.spec);
             a6.a.rmode = (guard && np == 2) ? 1 : 0;
             a6.h_scale = np == 2 ? f.h_scale : 1.f; a6.dz_scale = np == 2 ? f.dz_scale : 1.f;
             a6.u_z = np == 2 ? 1.f / (f.w_scale * f.h_scale) : 1.f; a6.u_dh = np == 2 ? 1.f / (f.dz_scale * f.w_scale) : 1.f;
@@ -1831,7 +1720,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
             }
         }
-        if ((phases & 8) && f.split_fallback && guard && f.np == 2 && !f.probs) {   // ... as a launch of its own (the engine issues it on the side stream, in front of the sparse fix-up)
+        if ((phases & 8) && f.split_fallback && guard && f.np == 2 && !f.probs) {   // ... as a launch of its own: behind the last range of a ranged (data-parallel) step, once over the whole layer
             OutFwdArgs af = a; af.rmode = 2;
             if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
         }

@@ -15,7 +15,6 @@ namespace ntf {
 
 constexpr int BM = 128;       // batch rows per workgroup: 4 waves x 32
 constexpr int BN = 64;        // experts per tile
-constexpr int SPEC_W = 16;     // special entries (positives + sampled negatives) of a row listed by k_special_list; a row with more is finished from memory
 constexpr int NCG_MAX = 256;  // column groups (one workgroup per CU when the batch has a single row block)
 #ifndef DW_PPG
 #define DW_PPG 2      // DMA pieces of the next K block per MFMA group (1: 0.705, 2: 0.693, 4: 0.707 ms at config 2)
@@ -53,7 +52,7 @@ inline Geom geom(int B, int M) {
     g.nCB = rup((M + 31) / 32, 2);
     return g;
 }
-struct WsLayout { size_t sbits, sbitsT, sinbits, sinT, hs, hz, lossp, hb, spec, total; };
+struct WsLayout { size_t sbits, sbitsT, sinbits, sinT, hs, hz, lossp, hb, total; };
 inline WsLayout ws_layout(int Bmax, int H, int M) {
     const int Bpad = rup(Bmax, BM), nCB = rup((M + 31) / 32, 2);
     WsLayout w; size_t o = 0;
@@ -66,7 +65,6 @@ inline WsLayout ws_layout(int Bmax, int H, int M) {
     w.hz = take((size_t)Bpad * H * 4);
     w.lossp = take((size_t)Bpad * NCG_MAX * 4);
     w.hb = take((size_t)Bpad * H * 2 * 6);   // bf16 split planes of h and h*s_in, K-block tiled (k_prep_planes_T)
-    w.spec = take((size_t)Bpad * (SPEC_W + 1) * 4);   // the special entries of each row (k_special_list): [row][SPEC_W] global expert id | label << 30 (-1: dropped), then [row] candidates
     w.total = o;
     return w;
 }

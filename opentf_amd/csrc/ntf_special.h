@@ -1,5 +1,5 @@
 // The sparse fix-up of the fused output layer (src/mdl/fnn.py:32-46 - the positives and the sampled negatives of a row take the weight tpw, the positives
-// label 1): argument block, and the device functions shared by the fix-up kernel (ntf_special.hip) and the forward kernel's own fix-up (k_out_fwd_h3p, ntf_fused.hip).
+// label 1): argument block and device functions of the fix-up kernel (ntf_special.hip).
 // Internal, not part of the C ABI.
 #pragma once
 #include "ntf_fused_common.h"
@@ -21,8 +21,6 @@ struct SpecialArgs {
     const uint16_t* wp_pl; float wp_inv_scale;   // fp16x3 step: sigma * eps as the two fp16 planes the forward kernel multiplied with (k_out_fwd_h3x's tile layout); null: the f32 copy `wp`
     int fb_ncg;            // > 0: the split-product forward ran as several range launches (NCG / nslab count THEIR column groups); a step that fell back to the exact-f32 kernels
                            // has the whole-layer launch's fb_ncg column groups instead
-    int dz_in_fwd;         // the forward kernel (k_out_fwd_h3p) handled the special entries itself (dz in dzT, loss terms in its loss partials, d(hidden) terms in its slabs): this
-                           // kernel only sums the partials and reads no weight - unless *rflag is raised (then the f32 kernels ran and the entries are this kernel's)
 };
 
 // The special entries of a team - its positives (member CSR row) and its sampled negatives - as the sparse fix-up visits them: entry `sidx` of the row's
@@ -39,8 +37,8 @@ __device__ __forceinline__ int special_candidate(const int32_t* __restrict__ m_i
     return c;
 }
 // The logit z (pre-activation) of one (team i, expert cc) entry by a QUARTER-WAVE of 16 lanes, lane l holding hidden units 8 l .. 8 l + 7 of h (hr) and of h * s_in (hsr):
-// z = h . mu[cc] + mu_b[cc] + s_out(i, cc) ((h s_in) . Wp[cc] + bp[cc]).  ONE function for the sparse fix-up kernel and for the forward kernel's own fix-up of dzT, with
-// the products as explicit fmaf chains, so that both give the same bits.  mu_r / wp_r: the weights it multiplied with (the caller's dh terms); so: the entry's s_out sign.
+// z = h . mu[cc] + mu_b[cc] + s_out(i, cc) ((h s_in) . Wp[cc] + bp[cc]).  The products are explicit fmaf chains (the value does not depend on how the
+// compiler would contract them).  mu_r / wp_r: the weights it multiplied with (the caller's dh terms); so: the entry's s_out sign.
 template <bool BAYES>
 __device__ __forceinline__ float special_z16(const float* __restrict__ mu, const float* __restrict__ mu_b, const float* __restrict__ wp, const float* __restrict__ bp,
                                              const uint16_t* __restrict__ wp_pl, float wp_inv_scale, bool wp_planes, const uint32_t* __restrict__ sbits, int nCB,

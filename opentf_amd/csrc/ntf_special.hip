@@ -1,29 +1,8 @@
-// Sparse fix-up side of the fused output layer for gfx950 (split from ntf_fused.hip in round 5): k_special_list (the special entries of every row of a batch, listed
-// beside the sampler) and k_out_special (one wave per team: the entries' loss terms, dz and d(hidden) terms, and the sums of the forward kernel's partials).
+// Sparse fix-up side of the fused output layer for gfx950 (split from ntf_fused.hip in round 5): k_out_special - one wave per team: the special entries' loss terms, dz and
+// d(hidden) terms, and the sums of the forward kernel's partials.
 #include "ntf_special.h"
 
 namespace ntf {
-
-// The special entries of every row of a batch, listed once per step: spec[row][SPEC_W] = global expert id | label << 30 of candidate k (-1: a dropped duplicate, or
-// k >= the row's candidates), spec[Bpad * SPEC_W + row] = the row's candidates npos + ns.  A quarter-wave per row, a lane per candidate.  Runs right behind the sampler
-// (auxiliary stream: for a prefetched head that is beside the previous step's dW kernel); read by the fix-up at the end of k_out_fwd_h3p.
-__global__ __launch_bounds__(256) void k_special_list(const int64_t* __restrict__ rows, int B, int Bpad, const int64_t* __restrict__ m_indptr, const int32_t* __restrict__ m_indices,
-                                                      const int64_t* __restrict__ neg, int ns, int* __restrict__ spec) {
-    const int i = (int)(blockIdx.x * 16 + (threadIdx.x >> 4)), l16 = threadIdx.x & 15;
-    if (i >= B) return;
-    const int64_t team = rows[i];
-    const int64_t pb = m_indptr[team];
-    const int npos = (int)(m_indptr[team + 1] - pb), total = npos + (neg ? ns : 0);
-    float y = 0.f;
-    const int c = l16 < total ? special_candidate(m_indices, neg, pb, npos, ns, i, l16, y) : -1;
-    spec[(int64_t)i * SPEC_W + l16] = c < 0 ? -1 : (c | (y != 0.f ? (1 << 30) : 0));
-    if (l16 == 0) spec[(int64_t)Bpad * SPEC_W + i] = total;
-}
-void launch_fused_special_list(hipStream_t st, int B, int H, int M, void* ws_, const int64_t* rows, const int64_t* m_indptr, const int32_t* m_indices, const int64_t* neg, int ns) {
-    const Geom g = geom(B, M);
-    const WsLayout w = ws_layout(B, H, M);
-    hipLaunchKernelGGL(k_special_list, dim3((B + 15) / 16), dim3(256), 0, st, rows, B, g.Bpad, m_indptr, m_indices, neg, ns, reinterpret_cast<int*>(static_cast<char*>(ws_) + w.spec));
-}
 
 // One wave per team.  H = 128: the wave works as FOUR quarter-waves of 16 lanes x 8 consecutive hidden units, each quarter taking every fourth
 // special entry (and every fourth dh slab): the ~8 dependent dot-product / reduction / BCE chains of a team run four abreast, rows are read as
@@ -65,8 +44,7 @@ __global__ __launch_bounds__(64) void k_out_special(SpecialArgs p) {
     const int64_t team = p.rows[i];
     const int64_t pb = p.m_indptr[team];
     const int npos = (int)(p.m_indptr[team + 1] - pb);
-    // (dz_in_fwd: the wave-pair forward kernel has visited the entries; the dW + Adam kernel may be rewriting the weights beside this kernel by now)
-    const int total = (p.dz_in_fwd && !(p.rflag && *p.rflag)) ? 0 : npos + (p.neg ? p.ns : 0);
+    const int total = npos + (p.neg ? p.ns : 0);
     float fix = 0.f;
     for (int s0 = 0; s0 < total; s0 += NQ) {       // wave-uniform trip count: the shuffles below need every lane
         const int sidx = s0 + q;

@@ -309,9 +309,9 @@ def test_uspt_unfiltered_expert_count_step_against_the_oracle():
 @pytest.mark.parametrize("M,B", [(70_000, 1000), (3000, 333), (70_001, 129), (40, 70)])     # ragged / empty last sub-tile, ragged last row block, one tile only
 def test_wave_pair_forward_equals_the_one_wave_kernel(bayesian, M, B, monkeypatch):
     """k_out_fwd_h3p (a logit wave and a gradient wave per 32 rows, two waves per SIMD) against k_out_fwd_h3x (NTF_FWD_KERNEL=3): the same fp16x3 products and the
-    same epilogue arithmetic in the same order per accumulator - dz, hence every gradient of the OUTPUT layer, is bit-identical; the loss differs in the order its terms
-    are summed.  Round 5: the wave-pair kernel adds the special entries' d(hidden) terms to its own slabs (FusedOut.fix_in_fwd) where the one-wave kernel's step leaves
-    them to the sparse fix-up kernel - another order of the same sum: the hidden layer's gradients, and the parameters after further steps, agree to rounding"""
+    same epilogue arithmetic in the same order per accumulator - every gradient is bit-identical, and so is every parameter after three steps of the default path
+    (Adam in the dW epilogue, prefetched head); the loss differs in the order its terms are summed.  (Round 5's experiment that moved the sparse fix-up into the
+    wave-pair kernel summed d(hidden) in another order and had this test relaxed to rounding for the hidden layer; it measured slower and is gone - bit for bit again.)"""
     ds = make_dataset("dblp", d=128, seed=13, n_rows=1500, n_experts=M)
     dims = [128, 128, ds["M"]]
     order = np.random.default_rng(6).permutation(ds["N"])[:2 * B].astype(np.int64)
@@ -330,14 +330,8 @@ def test_wave_pair_forward_equals_the_one_wave_kernel(bayesian, M, B, monkeypatc
         out.append((loss, l2[0], l2[1], l3[0], l3[1], l3[2], g, sd, sd3))
     a, b = out
     for x, y in zip(a[:6], b[:6]): assert abs(x - y) <= 2e-6 * abs(x), (x, y)
-    for k in a[6]:
-        if k.startswith("layers.1."): np.testing.assert_array_equal(np.asarray(a[6][k]), np.asarray(b[6][k]), err_msg=k)
     for t in (6, 7, 8):
-        for k in a[t]:
-            x, y = np.asarray(a[t][k]), np.asarray(b[t][k])
-            # (t = 7, 8: Adam's first steps move a parameter by ~lr whatever |g| is - where |g| ~ 1e-8 a rounding difference can flip an update: a handful of elements by up to 2 lr)
-            tol = 2e-5 * float(np.abs(x).max()) + 1e-9
-            assert float((np.abs(x - y) > tol).mean()) <= (0.0 if t == 6 else 2e-4), (t, k, float(np.abs(x - y).max()), tol)
+        for k in a[t]: np.testing.assert_array_equal(np.asarray(a[t][k]), np.asarray(b[t][k]), err_msg=k)
 
 
 # ------------------------------------------------------------------------------------------ inference (Fnn.test, src/mdl/fnn.py:172-219) at BASELINE config 2's expert count
