@@ -473,10 +473,10 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
 
     const uint32_t smem_base = lds_addr(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // forward-only tiles (eval, inference) take about as long as a DMA round trip: keep TWO tiles in flight there (three LDS stages)
-    constexpr bool DEEP = !TRAIN && !INJ;
-    constexpr int NST = DEEP ? 3 : 2;
-    constexpr int NDMA = (TM / 1024 / 4) * NMAT + NMAT;   // DMA instructions per wave per tile (DEEP)
+    // Two LDS stages.  Forward-only launches (evaluation, inference) take two of these workgroups per CU (eval_ncg: twice the column groups; 66.5 KiB of LDS and
+    // <= 252 registers each): one's logit epilogue beside the other's MFMAs - 0.64 -> 0.54 ms per evaluation step at config 2, Bnn top-K inference 10.1 -> 8.6 ms
+    // (round 5; rounds 2-4 kept three stages in ONE workgroup per CU there)
+    constexpr int NST = 2;
     auto stage_tile = [&](int t, int buf) {
         const uint32_t sb = smem_base + buf * STAGE;
         constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
             if (BAYES) glds16(reinterpret_cast<const char*>(pp.wp_pl) + src, sb + TM + inst * 1024);
         }
         const int c0 = t * BN6;
-        if (DEEP || wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TM);     // DEEP: every wave, so that all issue NDMA instructions
-        if (BAYES && (DEEP || wave_u == 1)) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TM + 256);
+        if (wave_u == 0) glds4(p.mu_b + min(c0 + lane, p.M - 1), sb + NMAT * TM);
+        if (BAYES && wave_u == 1) glds4(p.bp + min(c0 + lane, p.M - 1), sb + NMAT * TM + 256);
     };
     auto sign_word_t = [&](int t) -> uint32_t {     // s_out signs of (row i, experts 32t .. 32t+31)
         if (!BAYES || !row_ok) return 0u;
@@ -500,15 +500,13 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
         return sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)t);
     };
     if (t_beg < t_end) stage_tile(t_beg, 0);
-    if (DEEP && t_beg + 1 < t_end) stage_tile(t_beg + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = t_beg; t < t_end; ++t) {
         const int buf = (t - t_beg) % NST;
         const uint32_t sw = sign_word_t(t) >> (4 * half);
-        if (DEEP) { if (t + 2 < t_end) stage_tile(t + 2, (buf + 2) % NST); }
-        else if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
+        if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
         char* sb = smem + buf * STAGE;
         const int c0 = t * BN6;
         if (c0 + BN6 > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
@@ -652,10 +650,7 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
         }
         lacc.end_tile();
         if (TRAIN) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next tile's DMA is older than this tile's 16 dzT stores
-        else if (DEEP && t + 2 < t_end) {   // tile t+1 has landed once only tile t+2's DMA (and, PROBS, this tile's 16 stores) are outstanding
-            if (PROBS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + 16) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
@@ -1584,6 +1579,7 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
 
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     Geom g = geom(f.B, f.M);
+    if (!f.train && f.H == 128) g.NCG = eval_ncg(g);      // forward-only launches: two workgroups per CU (k_out_fwd_b6)
     if (f.ncg_limit > 0) g.NCG = std::max(1, std::min(g.NCG, f.ncg_limit));
     const WsLayout w = ws_layout(f.B, f.H, f.M);
     char* ws = static_cast<char*>(f.ws);
@@ -1633,7 +1629,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
             a6.h_scale = np == 2 ? f.h_scale : 1.f; a6.dz_scale = np == 2 ? f.dz_scale : 1.f;
             a6.u_z = np == 2 ? 1.f / (f.w_scale * f.h_scale) : 1.f; a6.u_dh = np == 2 ? 1.f / (f.dz_scale * f.w_scale) : 1.f;
             const bool dh = f.dh != nullptr;
-            const size_t lds = (size_t)((!f.train && !inj) ? 3 : 2) * ((size_t)(f.bayes ? 2 : 1) * np * BN6 * 128 * 2 + 512);
+            const size_t lds = (size_t)2 * ((size_t)(f.bayes ? 2 : 1) * np * BN6 * 128 * 2 + 512);
 #define NTF_L6N(BY, TR, DHF, IJ, PR, NPV) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ, PR, NPV>;                               \
             set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);       \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
@@ -1756,7 +1752,8 @@ __global__ __launch_bounds__(256) void k_transpose_pt(const float* __restrict__ 
 }
 void launch_fused_probs_finish(hipStream_t st, int B, int H, int M, void* ws_, const float* PT, float* P, float* ent_rows /*nullable: += this pass * scale*/, float scale, bool transpose,
                                float unpack_inv_scale) {
-    const Geom g = geom(B, M);
+    Geom g = geom(B, M);
+    if (H == 128) g.NCG = eval_ncg(g);      // (the inference launches' column groups, launch_fused_out_fwd)
     const WsLayout w = ws_layout(B, H, M);
     if (ent_rows) hipLaunchKernelGGL(k_ent_slots, dim3((B + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(static_cast<char*>(ws_) + w.lossp), B, g.NCG, scale, ent_rows);
     if (transpose) hipLaunchKernelGGL(k_transpose_pt, dim3((M + 31) / 32, g.Bpad / 32), dim3(256), 0, st, PT, M, g.Bpad, B, P, unpack_inv_scale);

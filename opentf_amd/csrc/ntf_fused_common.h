@@ -52,6 +52,9 @@ inline Geom geom(int B, int M) {
     g.nCB = rup((M + 31) / 32, 2);
     return g;
 }
+// column groups of a forward-only launch (evaluation, inference) at H = 128: twice the training step's, so that two workgroups share a CU (the loss / entropy partials have
+// NCG_MAX slots a row)
+inline int eval_ncg(const Geom& g) { return std::max(1, std::min(2 * NCG_MAX / g.NRB, std::min(g.T, NCG_MAX))); }
 struct WsLayout { size_t sbits, sbitsT, sinbits, sinT, hs, hz, lossp, hb, total; };
 inline WsLayout ws_layout(int Bmax, int H, int M) {
     const int Bpad = rup(Bmax, BM), nCB = rup((M + 31) / 32, 2);
