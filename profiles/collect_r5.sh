@@ -23,7 +23,7 @@ NTF_HEAD_PREFETCH=0 python3 $B --no-gather-bench --steps 50 --warmup 10 --nsd un
 python3 $B --no-gather-bench --steps 50 --warmup 10 --nsd unigram > $O/bench_n1_nsd_unigram.json 2>> $O/bench.err
 # A/B of this round's switches, same box; the default line before and after them
 python3 $B --no-gather-bench --steps 50 --warmup 10 > $O/ab_default_a.json 2>> $O/bench.err
-# (NTF_FIX_IN_FWD=1 was an arm of the first collections: profiles/r5_ab_NTF_FIX_IN_FWD_1.json; the experiment measured slower and its code is gone)
+# (NTF_FIX_IN_FWD=1 was an arm of the first collections: profiles/r5_removed_experiment_NTF_FIX_IN_FWD_1.json; the experiment measured slower and its code is gone)
 for v in "NTF_MERGE_BIAS=0" "NTF_HEAD_PREFETCH=0" "NTF_DW_KERNEL=0" "NTF_FWD_KERNEL=3"; do
   env $v python3 $B --no-gather-bench --steps 50 --warmup 10 > $O/ab_$v.json 2>> $O/bench.err
 done
