@@ -44,8 +44,9 @@ with open(out_md, "w") as f:
     for o in out:
         if o[2] > step + 1: break
         f.write(f"| `{o[0]}` | {o[1]} | {o[2]:.1f} | {o[4]:.1f} | {o[5]:.1f} |\n")
-    ks = [o for o in out if o[2] <= step + 1 and o[1] == main_q]
-    big = sum(o[4] for o in ks if o[0].startswith(("k_out_fwd_h3", "k_out_dw_p2", "k_out_dw_q")))
+    ks = [o for o in out if o[2] < step - 1 and o[1] == main_q]        # one step: up to, not including, the next step's forward kernel (the table's closing row)
+    is_big = lambda o: o[0].startswith(("k_out_fwd_h3", "k_out_dw_p2", "k_out_dw_q"))
+    big = sum(o[4] for o in ks if is_big(o))
     small = sum(o[4] for o in ks) - big
-    f.write(f"\nMain stream: the two big kernels {big:.0f} us, every other kernel {small:.0f} us in {len(ks) - 2} launches; side streams run beside them.\n")
+    f.write(f"\nMain stream, one step: the two big kernels {big:.0f} us, every other kernel {small:.0f} us in {sum(1 for o in ks if not is_big(o))} launches; side streams run beside them.\n")
 print("wrote", out_csv, out_md)
