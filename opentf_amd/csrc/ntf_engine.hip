@@ -117,6 +117,8 @@ struct ntf_engine {
     bool adam_in_dw = false;          // this step's output-layer Adam already ran inside / beside the dW kernel
     // the dW + Adam kernel of a train step also produced the NEXT step's output-layer operands (FusedDw.produce): valid for step pre_step as long as nothing else
     // touched the output layer's parameters or the operand buffers (Wp, split planes); d_kl[2] / d_range[4] hold that step's KL and range flag until it starts
+    int f32_copy_merged = 1;          // NTF_F32_COPY_MERGED=0: the conditional f32 copy of sigma * eps as a launch of its own in front of every step, as in round 4 (A/B runs)
+    uint64_t f32_copy_step = 0;       // step + 1 whose copy job rode in the previous step's Adam launch
     int merge_bias = 1;               // NTF_MERGE_BIAS=0: the next step's output-bias operand as k_head's bias workgroups in a launch of their own behind the bias Adam, as in round 4 (A/B runs)
     int dp_side_bwd = 1;              // NTF_DP_SIDE_BWD=0: a deferred-dW (data-parallel) step runs its hidden layers' backward on the main stream in front of the dW chunks, as in round 4 (A/B runs)
     int dp_ranges = 1;                // NTF_DP_RANGES=0: a data-parallel rank waits for every parameter all-gather before its step, as in round 4 (A/B runs, tests)
@@ -248,6 +250,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
+    if (const char* fc = getenv("NTF_F32_COPY_MERGED")) e->f32_copy_merged = atoi(fc);
     if (const char* eh = getenv("NTF_EP_HEAD_PREFETCH")) e->ep_head_prefetch = atoi(eh);
     if (const char* dr = getenv("NTF_DP_RANGES")) e->dp_ranges = atoi(dr);
     if (const char* ds = getenv("NTF_DP_SIDE_BWD")) e->dp_side_bwd = atoi(ds);
@@ -1033,7 +1036,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
-        if (use_pre && e->lean) {
+        if (use_pre && e->lean && !(hp_hit && e->f32_copy_step == c.step + 1)) {      // (f32_copy_step: the previous step's Adam launch carried this job - good only if the head that
+                                                                                      // ran beside that step IS this batch's: a head redone here may raise the flag anew)
             // this step's operands came from the previous step's dW epilogue, which (lean) left no f32 copy of sigma * eps: only a step that falls back to the exact-f32 kernels
             // reads one, and makes it here - a capped grid that exits at once unless the range flag is raised (behind the head: k_head may still raise it)
             Scope t(e, F_FLIPOUT_OPERAND);
@@ -1311,8 +1315,17 @@ static int apply_adam(ntf_engine* e) {
     static const int diag_skip = getenv("NTF_SKIP") ? atoi(getenv("NTF_SKIP")) : 0;     // timing only (results garbage): 1 - no launch here; 2 - the rotation alone
     if (diag_skip == 1 && bias_nx) {} else if (diag_skip == 2 && bias_nx) launch_step_scalars(e->st, e->d_kl, 1); else
 #endif
+    // ... and, as extra workgroups of the same launch, the f32 copy of the next step's sigma * eps that only a step falling back to the exact-f32 kernels reads (lean: the dW
+    // epilogue wrote none) - round 4 issued it as a launch of its own in front of every step, a no-op in all but the rarest.  *only_if: the NEXT step's range flag, still in
+    // its slot behind the current one (this launch's last workgroup rotates it) and complete: the dW epilogue and the prefetched head are behind this launch
+    F32CopyJob f32c; const bool with_copy = bias_nx && e->lean && e->f32_copy_merged && range_ptr(e) != nullptr;
+    if (with_copy) {
+        StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B;
+        f32c.rho = e->P + lo.off[NTF_P_RHO_WEIGHT]; f32c.out = e->Wp[e->L - 1]; f32c.n = lo.nw(); f32c.eps = normal_spec(e, nx, e->L - 1, T_EPS_W); f32c.only_if = e->d_range + 4;
+        e->f32_copy_step = e->hp.step + 1;      // (+ 1: 0 = never)
+    }
     launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2), fin, &e->fin_eps, e->fin_klw,
-                       rotate ? e->d_kl : nullptr, bias_nx ? e->bp[e->L - 1] : nullptr, bias_nx ? &nx_eps : nullptr, 1.0 / (double)e->Mg);
+                       rotate ? e->d_kl : nullptr, bias_nx ? e->bp[e->L - 1] : nullptr, bias_nx ? &nx_eps : nullptr, 1.0 / (double)e->Mg, with_copy ? &f32c : nullptr);
     e->pre_rotated = rotate; e->fin_pend = false;
     if (e->hp.valid && rotate && e->hp.step == e->step && !bias_nx) {
         StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B; nx.rows_dev = e->hp.rows; nx.train = true;

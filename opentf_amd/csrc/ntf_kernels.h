@@ -99,10 +99,13 @@ void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, i
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2_sqrt);
 void launch_step_scalars(hipStream_t st, double* kl, int take_next);
+// the conditional f32 copy of the next step's sigma * eps as extra workgroups of the ticketed Adam launch (k_adam_ranges, f32c): out[0, n) = softplus(rho) * eps iff *only_if != 0
+struct F32CopyJob { const float* rho; float* out; int64_t n; NormalSpec eps; const int* only_if; };
 void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,
                         float eps, float bc1, float bc2_sqrt, const int* fin = nullptr, const NormalSpec* fin_eps = nullptr, float fin_klw = 0.f,
                         double* rotate = nullptr,    // up to four ranges per launch; fin / rotate: see k_adam_ranges
-                        float* nx_bp = nullptr, const NormalSpec* nx_eps = nullptr, double nx_klw = 0.0);   // with rotate: also the next step's output-bias operand + its KL (k_adam_ranges, nx)
+                        float* nx_bp = nullptr, const NormalSpec* nx_eps = nullptr, double nx_klw = 0.0,   // with rotate: also the next step's output-bias operand + its KL (k_adam_ranges, nx)
+                        const F32CopyJob* f32c = nullptr);
 void launch_fill(hipStream_t st, float* p, int64_t n, float v);
 // probabilities: out = (accumulate ? out : 0) + sigmoid(leaky(Z)) * scale ; ent_acc[i] += sum_c -p log(p+1e-15)
 void launch_sigmoid_acc(hipStream_t st, const float* Act, int64_t n_rows, int M, float scale, int accumulate, float* out,

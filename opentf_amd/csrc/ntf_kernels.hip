@@ -730,7 +730,11 @@ void launch_step_scalars(hipStream_t st, double* kl, int take_next) { hipLaunchK
 //                   the NEXT step's KL slot (k_head's bias workgroups did this in a launch of their own behind this one).  The rotation then cannot be thread 0's first
 //                   act - adds to the next slot are still coming: the workgroup that finishes LAST (a ticket in the int32 behind the next flag) rotates.
 struct AdamRanges { int64_t lo[4], n[4]; int blk0[5]; int cnt; int fin[4]; NormalSpec eps; float klw; double* rotate;
-                    struct { float* bp; NormalSpec eps; double klw; } nx; };
+                    struct { float* bp; NormalSpec eps; double klw; } nx;
+                    // the f32 copy of the NEXT step's sigma * eps - read only by a step that falls back to the exact-f32 kernels (launch_flipout_perturb(only_if) otherwise issues it as
+                    // a launch of its own in front of that step): workgroups [blk0, blk0 + nblk) of THIS launch, which leave at once unless *only_if (the next step's range flag,
+                    // complete by now: the dW epilogue and the prefetched head are behind this launch) is raised.  n == 0: no such job
+                    struct { const float* rho; float* out; int64_t n; NormalSpec eps; const int* only_if; int blk0, nblk; } f32c; };
 __device__ __forceinline__ void fin_mu(float& g, float p, float klw) { g += klw * p; }
 __device__ __forceinline__ void fin_rho(float& g, float r, float z, float klw) {
     const float sg = 1.f / (1.f + expf(-r));  // d softplus / d rho
@@ -745,9 +749,23 @@ __global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, floa
                               float lr_over_bc1, float b1, float b2, float eps, float bc2_sqrt) {
     const bool produce = r.nx.bp != nullptr;
     if (r.rotate && !produce && blockIdx.x == 0 && threadIdx.x == 0) rotate_scalars(r.rotate);
+    const bool f32c_wg = r.f32c.n > 0 && (int)blockIdx.x >= r.f32c.blk0;
+    if (f32c_wg && __builtin_nontemporal_load(r.f32c.only_if) != 0) {      // k_flipout_perturb's arithmetic, f32 output only
+        const int64_t quads = (r.f32c.n + 3) / 4;
+        for (int64_t q = (int64_t)((int)blockIdx.x - r.f32c.blk0) * blockDim.x + threadIdx.x; q < quads; q += (int64_t)r.f32c.nblk * blockDim.x) {
+            const int64_t e0 = q * 4;
+            float z[4];
+            normal4(r.f32c.eps, q, e0, r.f32c.n, z);
+            if (e0 + 3 < r.f32c.n) {
+                const float4 r4 = *reinterpret_cast<const float4*>(r.f32c.rho + e0);
+                float ls;
+                *reinterpret_cast<float4*>(r.f32c.out + e0) = make_float4(softplus_rho_fast(r4.x, ls) * z[0], softplus_rho_fast(r4.y, ls) * z[1], softplus_rho_fast(r4.z, ls) * z[2], softplus_rho_fast(r4.w, ls) * z[3]);
+            } else for (int j = 0; j < 4 && e0 + j < r.f32c.n; ++j) r.f32c.out[e0 + j] = softplus_rho(r.f32c.rho[e0 + j]) * z[j];
+        }
+    }
     int k = 0;
     while (k + 1 < r.cnt && (int)blockIdx.x >= r.blk0[k + 1]) ++k;
-    const int64_t lo = r.lo[k], n = r.n[k];
+    const int64_t lo = r.lo[k], n = f32c_wg ? 0 : r.n[k];
     const int fin = r.fin[k];
     const int64_t first = (int64_t)((int)blockIdx.x - r.blk0[k]) * blockDim.x + threadIdx.x, stride = (int64_t)(r.blk0[k + 1] - r.blk0[k]) * blockDim.x;
     float *p = P + lo, *m = M1 + lo, *v = V2 + lo, *g = G + lo;
@@ -826,7 +844,7 @@ __global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, floa
 // lo_hi: n pairs [lo, hi) of float offsets into the flat buffers (P, G, M1, V2 are the buffers' bases, 16-byte aligned); fin (nullable): per range 0 / 1 / 2, see above
 void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,
                         float eps, float bc1, float bc2_sqrt, const int* fin, const NormalSpec* fin_eps, float fin_klw, double* rotate,
-                        float* nx_bp, const NormalSpec* nx_eps, double nx_klw) {
+                        float* nx_bp, const NormalSpec* nx_eps, double nx_klw, const F32CopyJob* f32c) {
     int k = 0;
     bool launched = false;
     while (k < n) {
@@ -847,6 +865,11 @@ void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2
         if (r.cnt == 0) continue;
         for (int j = r.cnt; j <= 4; ++j) r.blk0[j] = blocks;
         for (int j = r.cnt; j < 4; ++j) { r.lo[j] = 0; r.n[j] = 0; r.fin[j] = 0; }
+        r.f32c.n = 0;
+        if (f32c && f32c->n > 0 && r.nx.bp && !launched) {      // (with the ticketed launch only: its last workgroup rotates the flag this job reads)
+            r.f32c.rho = f32c->rho; r.f32c.out = f32c->out; r.f32c.n = f32c->n; r.f32c.eps = f32c->eps; r.f32c.only_if = f32c->only_if;
+            r.f32c.blk0 = blocks; r.f32c.nblk = 256; blocks += 256;
+        }
         hipLaunchKernelGGL(k_adam_ranges, dim3(blocks), dim3(256), 0, st, P, G, M1, V2, r, lr / bc1, b1, b2, eps, bc2_sqrt);
         launched = true;
     }

@@ -81,6 +81,41 @@ def test_half_tile_weight_gradient_kernel_equals_the_one_workgroup_per_cu_kernel
     for k in sa: assert np.array_equal(sa[k], sb[k]), k
 
 
+# ------------------------------------------------------------------------------------------ a step of the fully prefetched path that falls back to the exact-f32 kernels
+@pytest.mark.parametrize("what", ["sigma", "hidden", "in_range"])
+def test_flagged_steps_on_the_prefetched_path_equal_the_f32_engine(what, monkeypatch):
+    """The f32 copy of sigma * eps that only a range-fallback step reads: the lean dW epilogue writes none, so a step on prefetched operands makes it when its flag is
+    raised - since round 5 as extra workgroups of the previous step's bias Adam launch (NTF_F32_COPY_MERGED=1, default: the flag of the NEXT step is complete there - dW
+    epilogue and prefetched head are both behind it), before that as a conditional launch of its own in front of the step (0).  Staged train steps with prefetched
+    operands AND prefetched head whose flag is raised by the dW epilogue's producer ('sigma': rho = 80) or by the prefetched head ('hidden': activations of 5 000): every
+    step counted as a fallback, the two forms bit for bit, and both the step an mfma = 'f32' engine takes (to rounding: that engine's hidden layer is the chain of kernels,
+    not k_head - another summation order).  In range nothing falls back."""
+    ds = make_dataset("dblp", d=128, seed=11, n_rows=2000, n_experts=3000)
+    dims = [128, 128, ds["M"]]
+    B = 256
+    order = np.random.default_rng(3).permutation(ds["N"])[:4 * B].astype(np.int64)
+    sd = init_params(dims, True, 0)
+    if what == "sigma": sd["layers.1.rho_weight"][:] = 80.0
+    if what == "hidden": sd["layers.0.mu_bias"][:] = 5000.0
+    res = {}
+    for name, mfma, merged in (("merged", None, "1"), ("own_launch", None, "0"), ("f32", "f32", "1")):
+        monkeypatch.setenv("NTF_F32_COPY_MERGED", merged)
+        e = _mk(ds, dims, True, B, "uniform", mfma=mfma)
+        e.load_state_dict(sd)
+        loss = _full_epoch(e, order, B)                 # four staged train steps: steps 2-4 on the previous epilogue's operands with the head that ran beside it
+        res[name] = (loss, e.state_dict(), e.range_fallbacks(), e.prefetched_steps(), e.head_prefetch_hits()); e.close()
+    a, a0, b = res["merged"], res["own_launch"], res["f32"]
+    assert a[3] == 3 and a[4] == 3 and a0[3] == 3 and a0[4] == 3, (a[3], a[4])
+    assert a[2] == a0[2] == (0 if what == "in_range" else 4) and b[2] == 0, (a[2], a0[2], b[2])
+    assert np.isfinite(a[0]) and a[0] == a0[0]
+    for k in a[1]: assert np.array_equal(a[1][k], a0[1][k]), k
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]), (a[0], b[0])
+    if what != "in_range":      # (a flagged step IS the f32 engine's step but for the hidden layer's summation order)
+        for k in a[1]:
+            bad = ~np.isclose(a[1][k], b[1][k], rtol=1e-4, atol=2e-5)
+            assert bad.mean() <= 2e-4, (k, float(np.abs(a[1][k] - b[1][k]).max()))
+
+
 # ------------------------------------------------------------------------------------------ head prefetch (round 4)
 @pytest.mark.parametrize("nsd,bayesian", [("uniform", True), ("unigram", True), ("uniform", False)])
 def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own_step(nsd, bayesian, monkeypatch):
