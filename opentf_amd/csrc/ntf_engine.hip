@@ -1729,8 +1729,9 @@ static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const
     if (e->cfg.bayesian) {
         e->pre_valid = false;   // this pass's operands overwrite any prefetched ones
         { Scope t(e, F_FLIPOUT_OPERAND);
+          // (the planes of mu are the first pass's: the passes of one call run back to back on unchanged parameters, and the range flag they share is read behind the last)
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, e->d_kl,
-                                 e->pl_wp, e->pl_mu, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));
+                                 e->pl_wp, pass == 0 ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], nullptr, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1], 0.0, e->d_kl); }
         f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
         f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
