@@ -44,6 +44,7 @@ struct StepCtx {
     bool fuse_adam = false;  // train step with immediate apply on one GPU: Adam of the output layer goes into the dW epilogue
     int (*chunk_cb)(int32_t, void*) = nullptr; void* chunk_user = nullptr;   // data-parallel pipelining: called in front of every forward range (ntf_step_staged_deferred_cb)
     int ub = 0;              // nsd = unigram_b: which of the two staged per-batch alias tables is THIS batch's
+    bool chain = false;      // an evaluation step inside ntf_eval_epoch's loop (ntf_engine.eval_chain)
     int part = 0;            // expert-sharded step: 1 = forward + loss (leaves the partial d(hidden)), 2 = the output layer's backward, 3 = the hidden layers' backward (0 = whole step)
 };
 
@@ -128,6 +129,9 @@ struct ntf_engine {
     int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
+    // evaluation steps of one ntf_eval_epoch call (run_epoch) run back to back on unchanged parameters: eval_chain != 0 while that loop runs; the first producer launch of
+    // the chain keeps the output layer's KL term and the range verdict on the planes of mu (d_chain: [double KL, int flag]), the later ones reuse them (PerturbChain)
+    int eval_chain = 0; bool chain_valid = false; double* d_chain = nullptr;
     bool join_pending = false;        // a deferred-dW step (data parallel) left its hidden layers' backward running on the side stream: joined (join_side) behind the last dW chunk, or by whatever reads its results first
     bool pre_rotated = false;         // ... and whose KL / range-flag scalars the previous step's last kernel already moved into place
     bool fin_pend = false; NormalSpec fin_eps; float fin_klw = 0.f;   // the output layer's bias-gradient finalisation rides in the Adam launch that follows (fused-Adam steps)
@@ -291,7 +295,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->Wp.assign(e->L, nullptr); e->bp.assign(e->L, nullptr);
     if (cfg->bayesian) for (int l = 0; l < e->L; ++l) { A(dmalloc(e, &e->Wp[l], e->layers[l].nw())); A(dmalloc(e, &e->bp[l], e->layers[l].out)); }
     A(dmalloc(e, &e->partial, (int64_t)B * std::max(loss_dense_nchunk(M), fused_loss_slots(M)))); A(dmalloc(e, &e->row_fix, B));
-    A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 4)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
+    A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 4)); A(dmalloc(e, &e->d_chain, 2)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
     A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B)); A(dmalloc(e, &e->gemm_slab, kGemmSlabFloats));
     if (rc == NTF_OK && fused_ok(e)) {
         A(dmalloc(e, &e->dh_slab, fused_dh_slab_floats(B, e->layers[e->L - 1].in, M)));
@@ -331,7 +335,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     dfree(e->Zout); dfree(e->dZout); dfree(e->Pbuf); dfree(e->Zh); dfree(e->dAct[0]); dfree(e->dAct[1]);
     for (auto& p : e->Wp) dfree(p);
     for (auto& p : e->bp) dfree(p);
-    dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_acc); dfree(e->d_acc_steps);
+    dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_chain); dfree(e->d_acc); dfree(e->d_acc_steps);
     dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws_set[0]); dfree(e->fws_set[1]); dfree(e->pl_mu); dfree(e->pl_wp); dfree(e->gemm_slab); dfree(e->tk_vals); dfree(e->tk_idx);
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
     for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -924,6 +928,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     // (round 5: also of a deferred-dW step - a data-parallel rank's - whose dW chunks the host launches right behind this call: the join then waits behind the last chunk, join_side)
     const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && (!c.defer_dw || e->dp_side_bwd) && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
     bool hp_hit = false, hp_stale = false;
+    bool chain_ok = false, chain_lean = false, chain_fill = false; PerturbChain pch;
     FwdRange fr[4]; int fr_tot = 0;
     const int nfr = (c.chunk_cb && c.defer_dw && c.train && c.part == 0 && !c.inj && e->dp_ranges) ? fwd_ranges(e, B, fr, &fr_tot) : 0;      // > 0: producer + forward kernel range by range
     if (fused) e->fws = e->fws_set[c.step & 1];     // (every kernel of a step works in ONE of the two workspace sets: a prefetched head of step t + 1 fills the other beside step t's dW kernel)
@@ -946,7 +951,13 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     }
     // the step's KL sum and fp16x3 range flag: zero, or the values the previous step's dW epilogue produced for this one (moved into place by that step's Adam launch
     // if pre_rotated, else here)
-    if (e->cfg.bayesian) { if (!(use_pre && e->pre_rotated)) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0); }
+    // (an evaluation step of a chain that has the output layer's KL term kept: the sum starts from it, the lean producer below adds none)
+    chain_ok = c.chain && !c.train && fused && e->cfg.bayesian && !use_pre && !nfr && !c.inj && e->pl_wp && e->pl_mu && mfma_np(e) == 2 && range_ptr(e) && e->d_chain;
+    chain_lean = chain_ok && e->chain_valid; chain_fill = chain_ok && !e->chain_valid;
+    if (chain_fill) HIPCHK(e, hipMemsetAsync(e->d_chain, 0, 16, e->st));
+    if (chain_fill) { pch.kl_out2 = e->d_chain; pch.mu_flag_out = reinterpret_cast<int*>(e->d_chain + 1); e->chain_valid = true; }
+    if (chain_lean) pch.raise_if = reinterpret_cast<const int*>(e->d_chain + 1);
+    if (e->cfg.bayesian) { if (!(use_pre && e->pre_rotated)) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0, chain_lean ? e->d_chain : nullptr); }
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
     e->pre_rotated = false;
     if (fused && e->side_bwd && !hp_hit) {
@@ -962,8 +973,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
             e->st = e->st3;
             { Scope t(e, F_FLIPOUT_OPERAND);
-              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], e->P + lo.off[NTF_P_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                     1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, e->P + lo.off[NTF_P_WEIGHT], lo.in, mfma_np(e), kW16Scale, range_ptr(e)); }
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], chain_lean ? nullptr : e->P + lo.off[NTF_P_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
+                                     1.0 / out_nw, e->d_kl, e->pl_wp, (e->pl_wp && !chain_lean) ? e->pl_mu : nullptr, e->P + lo.off[NTF_P_WEIGHT], lo.in, mfma_np(e), kW16Scale, range_ptr(e), nullptr, pch); }
             HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
             prod_side = true;
         }
@@ -998,8 +1009,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
         if (e->cfg.bayesian) {
             if (!prod_side && !use_pre && !nfr) { Scope t(e, F_FLIPOUT_OPERAND);
-              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
-                                     1.0 / out_nw, e->d_kl, e->pl_wp, e->pl_wp ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e)); }   // + the split planes of Wp and mu
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], chain_lean ? nullptr : f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
+                                     1.0 / out_nw, e->d_kl, e->pl_wp, (e->pl_wp && !chain_lean) ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e), nullptr, pch); }   // + the split planes of Wp and mu
             if (!aux && !use_head) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
                                      1.0 / out_nb, e->d_kl); }
@@ -1374,6 +1385,7 @@ static int step_common(ntf_engine* e, const int64_t* rows, int32_t B, int32_t gl
     if ((r = join_side(e))) return r;       // (an abandoned deferred step's side-stream chain still orders before this one)
     StepCtx c; c.B = B; c.global_B = global_B; c.inj = inj; c.train = train; c.step = e->step++;
     c.fuse_adam = train && apply && e->cfg.fuse_adam && global_B == B && fused_ok(e);
+    c.chain = !train && e->eval_chain != 0 && !inj;
     c.defer_dw = defer_dw && train && !apply && fused_ok(e);
     c.row0 = row0;
     if (c.defer_dw) { c.chunk_cb = e->cb_fn; c.chunk_user = e->cb_user; }
@@ -1599,10 +1611,12 @@ static int run_epoch(ntf_engine* e, const int64_t* order, int64_t n, int32_t B, 
     if (r) return r;
     HIPCHK(e, hipMemsetAsync(e->d_acc, 0, 8, e->st));
     HIPCHK(e, hipMemsetAsync(e->d_acc_steps, 0, 8, e->st));
+    e->eval_chain = train ? 0 : 1; e->chain_valid = false;      // (evaluation: nothing but these steps touches the engine until the loop ends)
     for (int64_t o = 0; o < n; o += B) {
         const int b = (int)std::min<int64_t>(B, n - o);
-        if ((r = ntf_step_staged(e, o, b, o, b, train, train, nullptr))) return r;
+        if ((r = ntf_step_staged(e, o, b, o, b, train, train, nullptr))) { e->eval_chain = 0; return r; }
     }
+    e->eval_chain = 0; e->chain_valid = false;
     double sum = 0; int64_t steps = 0;
     if ((r = ntf_epoch_loss(e, &sum, &steps))) return r;
     if (mean_loss) *mean_loss = steps ? (float)(sum / (double)steps) : 0.f;

@@ -54,11 +54,16 @@ void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 // Wp = softplus(rho) * eps  (eps generated or injected)
 // also accumulates w * KL(N(mu, softplus(rho)^2) || N(0,1)) summed over the tensor into kl_out when mu != nullptr
 // planes_w / planes_mu != null (H % 4 == 0, n = rows * H): also writes the bf16 split planes of out / of pmu (fused_planes_elems layout, rows past n/H untouched)
+// evaluation steps of ONE ntf_eval_epoch call run back to back on unchanged parameters: the first producer launch of the chain also leaves the output layer's KL term
+// (kl_out2) and whether the planes of mu left the fp16 window (mu_flag_out); the later ones skip both (mu = planes_mu = null), start the step's KL sum from the kept value
+// (launch_step_scalars, start_from) and raise the step's range flag if raise_if says so
+struct PerturbChain { double* kl_out2 = nullptr; int* mu_flag_out = nullptr; const int* raise_if = nullptr; };
 void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out,
                             uint16_t* planes_w = nullptr, uint16_t* planes_mu = nullptr, const float* pmu = nullptr, int H = 0,
                             int np = 3 /*3: bf16 three-way planes, 2: fp16 two-way planes of value * pscale*/, float pscale = 1.f,
                             int* rflag = nullptr /*np = 2: raised when a plane operand leaves the fp16 window*/,
-                            const int* only_if = nullptr /*device flag: the launch does nothing unless it is non-zero (the f32 sigma * eps of a step on prefetched operands that falls back to the exact-f32 kernels)*/);
+                            const int* only_if = nullptr /*device flag: the launch does nothing unless it is non-zero (the f32 sigma * eps of a step on prefetched operands that falls back to the exact-f32 kernels)*/,
+                            PerturbChain ch = PerturbChain());
 // g_rho = gWp * eps * sigmoid(rho) + kl' ; g_mu += kl'   (KL of N(mu, sigma^2) against N(0,1), mean over n, times klw)
 void launch_flipout_grad_finalize(hipStream_t st, const float* mu, const float* rho, float* g_mu, float* g_rho /*in: gWp*/,
                                   int64_t n, NormalSpec eps, float klw);
@@ -98,7 +103,7 @@ void launch_ns_alias_sparse(hipStream_t st, const int64_t* rows, int B, int M, i
 
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2_sqrt);
-void launch_step_scalars(hipStream_t st, double* kl, int take_next);
+void launch_step_scalars(hipStream_t st, double* kl, int take_next, const double* start_from = nullptr);
 // the conditional f32 copy of the next step's sigma * eps as extra workgroups of the ticketed Adam launch (k_adam_ranges, f32c): out[0, n) = softplus(rho) * eps iff *only_if != 0
 struct F32CopyJob { const float* rho; float* out; int64_t n; NormalSpec eps; const int* only_if; };
 void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2, const int64_t* lo_hi, int n, float lr, float b1, float b2,

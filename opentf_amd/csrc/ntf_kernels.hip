@@ -254,10 +254,11 @@ void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict__ rho, const float* __restrict__ mu, int64_t n, NormalSpec eps,
                                                          float* __restrict__ out, double w, double* kl_out, uint16_t* __restrict__ planes_w,
                                                          uint16_t* __restrict__ planes_mu, const float* __restrict__ pmu, int H, int np, float pscale,
-                                                         int* __restrict__ rflag, const int* __restrict__ only_if) {
+                                                         int* __restrict__ rflag, const int* __restrict__ only_if, PerturbChain ch) {
     if (only_if && __builtin_nontemporal_load(only_if) == 0) return;   // (the f32 copy of sigma * eps for a step that fell back to the exact-f32 kernels, see launch_flipout_perturb)
     const int64_t quads = (n + 3) / 4;
-    float kl = 0.f, amax = 0.f;
+    float kl = 0.f, amax = 0.f, amax_mu = 0.f;
+    if (rflag && ch.raise_if && blockIdx.x == 0 && threadIdx.x == 0 && *ch.raise_if) *rflag = 1;      // (the planes of mu - not rewritten by this launch - left the fp16 window when they were made)
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e0 = q * 4;
         float z[4];
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
                     if (planes_mu) planes_store_quad<3>(planes_mu, row, j, H, m4.x, m4.y, m4.z, m4.w, 1.f);
                 } else {
                     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3]))));
-                    if (planes_mu) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(m4.x), fabsf(m4.y)), fmaxf(fabsf(m4.z), fabsf(m4.w))));
+                    if (planes_mu) amax_mu = fmaxf(amax_mu, fmaxf(fmaxf(fabsf(m4.x), fabsf(m4.y)), fmaxf(fabsf(m4.z), fabsf(m4.w))));
                     planes_store_quad<2>(planes_w, row, j, H, ov[0], ov[1], ov[2], ov[3], pscale);
                     if (planes_mu) planes_store_quad<2>(planes_mu, row, j, H, m4.x, m4.y, m4.z, m4.w, pscale);
                 }
@@ -296,18 +297,19 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
             }
         }
     }
-    if (rflag && !(amax * pscale <= 65504.f)) *rflag = 1;   // an operand of the fp16x3 products leaves the fp16 window (or is NaN)
+    if (rflag && !(fmaxf(amax, amax_mu) * pscale <= 65504.f)) *rflag = 1;   // an operand of the fp16x3 products leaves the fp16 window (or is NaN)
+    if (ch.mu_flag_out && !(amax_mu * pscale <= 65504.f)) *ch.mu_flag_out = 1;
     if (mu) {
         const double s = block_reduce_sum_d((double)kl);
-        if (threadIdx.x == 0) atomicAdd(kl_out, s * w);
+        if (threadIdx.x == 0) { atomicAdd(kl_out, s * w); if (ch.kl_out2) atomicAdd(ch.kl_out2, s * w); }
     }
 }
 void launch_flipout_perturb(hipStream_t st, const float* rho, const float* mu, int64_t n, NormalSpec eps, float* out, double w, double* kl_out,
-                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale, int* rflag, const int* only_if) {
+                            uint16_t* planes_w, uint16_t* planes_mu, const float* pmu, int H, int np, float pscale, int* rflag, const int* only_if, PerturbChain ch) {
     if (n <= 0) return;
     const int64_t quads = (n + 3) / 4;
     const int blocks = (int)std::min<int64_t>((quads + 255) / 256, only_if ? 256 : 2048);   // (only_if: a no-op in all but the rarest step - one short round of workgroups)
-    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale, (planes_w && np == 2) ? rflag : nullptr, only_if);
+    hipLaunchKernelGGL(k_flipout_perturb, dim3(blocks), dim3(256), 0, st, rho, mu, n, eps, out, w, kl_out, planes_w, planes_mu, pmu, H, np, pscale, (planes_w && np == 2) ? rflag : nullptr, only_if, ch);
 }
 
 __global__ void k_flipout_grad_finalize(const float* __restrict__ mu, const float* __restrict__ rho, float* __restrict__ g_mu,
@@ -712,13 +714,13 @@ void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, i
 
 // per-step scalars behind d_kl (ntf_engine.hip): [0] the step's KL sum (double), int32 view [2] its fp16x3 range flag, [3] the fallback counter (kept);
 // [2] (double) and int32 [6]: the same two for the NEXT step, written by the dW + Adam epilogue when it also produced that step's operands (FusedDw.produce)
-__global__ void k_step_scalars(double* kl, int take_next) {
+__global__ void k_step_scalars(double* kl, int take_next, const double* start_from) {
     int32_t* w = reinterpret_cast<int32_t*>(kl);
-    kl[0] = take_next ? kl[2] : 0.0;
+    kl[0] = take_next ? kl[2] : (start_from ? *start_from : 0.0);
     w[2] = take_next ? w[6] : 0;
     kl[2] = 0.0; w[6] = 0;
 }
-void launch_step_scalars(hipStream_t st, double* kl, int take_next) { hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(1), 0, st, kl, take_next); }
+void launch_step_scalars(hipStream_t st, double* kl, int take_next, const double* start_from) { hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(1), 0, st, kl, take_next, start_from); }
 
 // the same update over up to four [lo, lo + n) ranges of the flat buffers in ONE launch (the rest of the model beside the dW kernel's in-epilogue
 // Adam: hidden layers, biases, rho biases - three short ranges, three dependent launches before).  Two more small launches ride here:

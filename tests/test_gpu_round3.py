@@ -116,6 +116,32 @@ def test_flagged_steps_on_the_prefetched_path_equal_the_f32_engine(what, monkeyp
             assert bad.mean() <= 2e-4, (k, float(np.abs(a[1][k] - b[1][k]).max()))
 
 
+# ------------------------------------------------------------------------------------------ the evaluation steps of one ntf_eval_epoch call
+@pytest.mark.parametrize("what", ["in_range", "mu", "sigma"])
+def test_evaluation_steps_of_one_epoch_call_share_the_output_layers_kl_and_mu_planes(what):
+    """Round 5: inside ntf_eval_epoch the steps run back to back on unchanged parameters - the first producer launch keeps the output layer's KL term and the range verdict
+    on the planes of mu, the later ones draw fresh eps only (no planes of mu, no KL pass; src/mdl/fnn.py:118-140's validation loop draws eps per batch and adds the same
+    kl / b to every batch loss).  The epoch loss equals the mean of the same steps made one by one (which take no such shortcut) and an mfma = 'f32' engine's; a mu outside
+    the fp16 window ('mu': the verdict is the first step's) or a sigma * eps outside it ('sigma': every step's own) sends EVERY step to the exact-f32 kernels."""
+    ds = make_dataset("dblp", d=128, seed=12, n_rows=2000, n_experts=3000)
+    dims = [128, 128, ds["M"]]
+    B = 256
+    order = np.random.default_rng(5).permutation(ds["N"])[:3 * B + 100].astype(np.int64)
+    sd = init_params(dims, True, 0)
+    if what == "mu": sd["layers.1.mu_weight"][17, 5] = 300.0
+    if what == "sigma": sd["layers.1.rho_weight"][:] = 80.0
+    e = _mk(ds, dims, True, B, "uniform"); e.load_state_dict(sd)
+    l_epoch = e.eval_epoch(order, B); fb_epoch = e.range_fallbacks()
+    e.set_seed(5, 0); e.stage_order(order)
+    one_by_one = [e.step_staged(o, min(B, len(order) - o), train=False, apply=False, want_loss=True) for o in range(0, len(order), B)]
+    fb_steps = e.range_fallbacks() - fb_epoch; e.close()
+    f = _mk(ds, dims, True, B, "uniform", mfma="f32"); f.load_state_dict(sd)
+    l_f32 = f.eval_epoch(order, B); f.close()
+    assert fb_epoch == fb_steps == (0 if what == "in_range" else 4), (fb_epoch, fb_steps)
+    assert np.isfinite(l_epoch) and abs(l_epoch - float(np.mean(one_by_one))) <= 2e-7 * abs(l_epoch), (l_epoch, float(np.mean(one_by_one)))
+    assert abs(l_epoch - l_f32) <= 2e-5 * abs(l_f32), (l_epoch, l_f32)
+
+
 # ------------------------------------------------------------------------------------------ head prefetch (round 4)
 @pytest.mark.parametrize("nsd,bayesian", [("uniform", True), ("unigram", True), ("uniform", False)])
 def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own_step(nsd, bayesian, monkeypatch):
