@@ -830,7 +830,7 @@ __global__ void k_adam_ranges(float* __restrict__ P, float* __restrict__ G, floa
         __syncthreads();
         if (threadIdx.x == 0) {
             int32_t* w = reinterpret_cast<int32_t*>(r.rotate);
-            if (fin) atomicAdd(r.rotate + 2, (red[0] + red[1] + red[2] + red[3]) * r.nx.klw);
+            if (fin && !f32c_wg) atomicAdd(r.rotate + 2, (red[0] + red[1] + red[2] + red[3]) * r.nx.klw);
             __threadfence();                                        // the add (a device-scope atomic) has been performed before the ticket is taken
             last = atomicAdd(w + 7, 1) == (int)gridDim.x - 1;
             if (last) {
@@ -870,7 +870,7 @@ void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2
         r.f32c.n = 0;
         if (f32c && f32c->n > 0 && r.nx.bp && !launched) {      // (with the ticketed launch only: its last workgroup rotates the flag this job reads)
             r.f32c.rho = f32c->rho; r.f32c.out = f32c->out; r.f32c.n = f32c->n; r.f32c.eps = f32c->eps; r.f32c.only_if = f32c->only_if;
-            r.f32c.blk0 = blocks; r.f32c.nblk = 256; blocks += 256;
+            r.f32c.blk0 = blocks; r.f32c.nblk = 64; blocks += 64;      // (few: each takes a ticket; the copy itself is made in all but never)
         }
         hipLaunchKernelGGL(k_adam_ranges, dim3(blocks), dim3(256), 0, st, P, G, M1, V2, r, lr / bc1, b1, b2, eps, bc2_sqrt);
         launched = true;
