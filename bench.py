@@ -79,7 +79,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
+def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=10):
     """The oracle's reference-shaped step (dense [B, M] labels, rand_like+topk negatives, autograd, Adam) on the host."""
     import scipy.sparse
     import torch
@@ -127,21 +127,31 @@ def cpu_baseline(ds, dims, bayesian, cfg, sample_rows=1000, steps=3):
                     "of src/mdl/ntf.py:22-24; BASELINE.md section 3"}
 
 
+def launched_kernel(family, a):
+    """name (prefix) of the output-layer kernel a default-shaped run launches for a timed family - what a committed PMC file must be about before its bytes are quoted"""
+    if a.no_fused or a.hidden != 128: return None
+    if a.mfma == "f32": return {"out_fused_fwd_loss_dh": "k_out_fwd<", "out_fused_dw_adam": "k_out_dw<"}.get(family)
+    fwd = {None: "k_out_fwd_h3p", "5": "k_out_fwd_h3p", "3": "k_out_fwd_h3x", "0": "k_out_fwd_b6"}.get(os.environ.get("NTF_FWD_KERNEL"))
+    dw = {None: "k_out_dw_q", "1": "k_out_dw_q"}.get(os.environ.get("NTF_DW_KERNEL"))
+    return {"out_fused_fwd_loss_dh": fwd, "out_fused_dw_adam": dw}.get(family)
+
+
 def pmc_traffic(family, a, ds):
     """HBM bytes per launch of an output-layer kernel from the committed rocprofv3 PMC passes (profiles/, collected and corrected
-    as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration."""
-    names = {"f32": ["r1_c_pmc_traffic_and_sq.json"], "bf16x6": ["r1_d_pmc_traffic_and_sq.json"]}.get(a.mfma, ["r5_pmc_traffic_and_sq.json", "r4_pmc_traffic_and_sq.json", "r3_pmc_traffic_and_sq.json", "r2_pmc_traffic_and_sq.json"])
+    as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled, separate passes); only when the run is the profiled configuration AND the
+    file's kernel is the one this run launches (a PMC file goes stale silently when a kernel is replaced: then traffic is null)."""
+    names = {"f32": ["r1_c_pmc_traffic_and_sq.json"]}.get(a.mfma, ["r6_pmc_traffic_and_sq.json", "r5_pmc_traffic_and_sq.json"])
     path = next((os.path.join(ROOT, "profiles", n) for n in names if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if not (path and a.dataset == "dblp" and a.model == "bnn" and a.batch == 1000 and a.d == 128 and a.hidden == 128
             and a.input == "meanpool" and not a.rows and not a.experts):
         return None, None
-    key = {"out_fused_fwd_loss_dh": "k_out_fwd", "out_fused_dw_adam": "k_out_dw_"}.get(family)
+    key = launched_kernel(family, a)
     if not key:
         return None, None
     best = None
     for name, v in json.load(open(path))["kernels"].items():
         if key in name and "hbm_bytes" in v and (best is None or v["hbm_bytes"] > best): best = v["hbm_bytes"]   # (the no-op range-fallback kernels share the prefix)
-    return best, os.path.basename(path)
+    return (best, os.path.basename(path)) if best is not None else (None, None)
 
 
 def workload_label(a, ds, bayesian, multihot):
@@ -269,6 +279,26 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep, evt_steps=None, adam_in_d
     return (out[0] if out else None), (out[1] if len(out) > 1 else None)
 
 
+def step_roofline(a, bayesian, head, ds, multihot, step_s):
+    """The WHOLE step against both roofs (the per-kernel `roofline` objects leave out what sits between the kernels): SURVEY 8d's algorithmic FLOPs per team
+    (Bnn 12 H M + 8 D H, Fnn 6 (D H + H M); D = the dense input width, the multi-hot first layer counted as its gather: 2 nnz H per product) x the rows one
+    engine steps, and the step's compulsory HBM bytes (split planes read + packed dz written and read + Adam in place + next-step operands), each over the
+    measured ms_per_step."""
+    eB, H, M = head["eB"], a.hidden, head["Mloc"]
+    D = (ds["skill"][0][-1] / ds["N"]) if multihot else a.d
+    flop = eB * ((12.0 * H * M + 8.0 * D * H) if bayesian else 6.0 * (D * H + H * M))
+    split = a.mfma != "f32" and not a.no_fused and a.hidden == 128
+    peak = BF16_MFMA_PEAK_TFLOPS / (6 if a.mfma == "bf16x6" else 3) if split else F32_MFMA_PEAK_TFLOPS
+    Bpad = (eB + 127) // 128 * 128; Mpad = (M + 255) // 256 * 256
+    k = 2 if bayesian else 1
+    fwd_b = 4.0 * k * H * M + 4.0 * Bpad * Mpad                        # two fp16 planes of mu (and of sigma * eps) read once; the packed dz written
+    dw_b = 4.0 * Bpad * Mpad + ((56 if os.environ.get("NTF_LEAN", "1") != "0" else 64) if bayesian else 24) * H * M
+    nbytes = fwd_b + dw_b
+    return {"flop_per_step": flop, "tflops": flop / step_s / 1e12, "mfma_peak": peak, "mfma_frac": flop / step_s / 1e12 / peak,
+            "bytes_per_step": nbytes, "gbs": nbytes / step_s / 1e9, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": nbytes / step_s / 1e9 / HBM_PEAK_GBS,
+            "note": "whole step: algorithmic FLOPs (SURVEY 8d) and the output layer's compulsory HBM bytes over ms_per_step; the hidden layer's and the head's bytes (< 1 %) are left out"}
+
+
 def main():
     a = parse()
     import torch
@@ -379,7 +409,7 @@ def main():
                         times[fam] = (times.get(fam, (0.0, 0))[0] + ms, times.get(fam, (0.0, 0))[1] + calls)
                         evt_steps[fam] = evt_steps.get(fam, 0) + nsteps
             e.kernel_times(enable=0 if no_events else 3)
-            regions, mean_loss, off = [], None, warmup * gB
+            regions, mean_loss, off, losses = [], None, warmup * gB, []
             while len(regions) < reps_max:
                 e.synchronize(); torch.cuda.synchronize()
                 if world > 1: dist.barrier()
@@ -389,7 +419,7 @@ def main():
                 if world > 1: dist.barrier()
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
                 if world > 1: dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank sees the same region time, hence takes the same decision below
-                regions.append(float(t.item())); off += steps * gB
+                regions.append(float(t.item())); off += steps * gB; losses.append(float(mean_loss))
                 collect(0 if no_events else (4 if len(regions) % 2 else 3), steps)      # (a single region: the forward kernel only - its partner comes from the breakdown pass below)
                 if sum(regions) >= float(os.environ.get("NTF_BENCH_MIN_TIMED_S", "2.0")): break                                # every rank sees the same (max-reduced) times, hence takes the same decision
             collect(0)
@@ -403,7 +433,7 @@ def main():
                 for fam in ("out_fused_fwd_loss_dh", "out_fused_dw_adam", "out_fwd_gemm", "out_bwd_dw_gemm"):      # a run of ONE timed region saw one of the two kernels only
                     if fam not in times and fam in full and full[fam][1] > 0: times[fam] = full[fam]; evt_steps[fam] = k3
             dt = float(np.median(regions))
-            res = {"par": par, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
+            res = {"par": par, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "region_losses": losses, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
                    "Mloc": (shard[1] - shard[0]) if ep else model_dims[-1], "engine": e,
                    "rccl_payload_bytes_per_step": (4 * gB * a.hidden) if ep else (8 * n_params if world > 1 else 0),
                    "emulated_bytes": getattr(dp, "emulated_bytes", None)}
@@ -455,7 +485,7 @@ def main():
 
     # ---- the JSON line (rank 0), assembled from the headline BEFORE anything else runs: whatever happens in a later leg, this much is printed
     extra_modes = {}
-    state = {"exact_f32": None, "extra_configs": None, "cpu_baseline": None, "printed": False}
+    state = {"exact_f32": None, "extra_configs": None, "cpu_baseline": None, "printed": False, "loss_finite": True}
     import threading
     emit_lock = threading.Lock()      # the watchdog thread and the main thread may both reach emit(): exactly one line is printed
 
@@ -471,6 +501,8 @@ def main():
         ep = head["ep"]; dt = head["dt"]
         roof, roof_other = rooflines(head["times"], a, bayesian, head["eB"], H, head["Mloc"], ds, ep, head.get("evt_steps"), head.get("adam_in_dw", True))
         spread = (max(head["regions"]) - min(head["regions"])) / dt if len(head["regions"]) > 1 else None
+        state["loss_finite"] = bool(np.all(np.isfinite(head["region_losses"]))) and all(
+            np.isfinite(v.get("mean_loss", 0.0) or 0.0) for v in list((state["extra_configs"] or {}).values()) + list(extra_modes.values()) if isinstance(v, dict))
         devices = [torch.cuda.get_device_name(local)]
         out = {
             "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
@@ -480,7 +512,8 @@ def main():
             "config": {"workload": workload_label(a, ds, bayesian, multihot), "global_batch": gB,
                        "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else
                                        f"dp{world}" + (": rows split over the GPUs, gradients reduce-scattered / parameters all-gathered over RCCL, Adam on the owned 1/N shard" if world > 1 else ""))},
-            "roofline": roof, "roofline_other": roof_other, "cpu_baseline": state["cpu_baseline"], "exact_f32_mfma": state["exact_f32"], "mean_loss": head["mean_loss"],
+            "roofline": roof, "roofline_other": roof_other, "step_roofline": step_roofline(a, bayesian, head, ds, multihot, dt / a.steps), "cpu_baseline": state["cpu_baseline"], "exact_f32_mfma": state["exact_f32"], "mean_loss": head["mean_loss"],
+            "mean_loss_finite_in_every_timed_region": state["loss_finite"],
             "kernel_ms_per_step": head["breakdown"], "kernel_ms_note": "separate pass of %d steps with events around every kernel family (side-stream families overlap the big kernels: the column does not sum to the step); the timed region carries events around the two output-layer kernels only" % head["k3"],
             "rccl_ranks": world if world > 1 else 1, "rank0_device": f"cuda:{local} {devices[0]}",
             "rccl_payload_bytes_per_step": head["rccl_payload_bytes_per_step"],
@@ -629,6 +662,10 @@ def main():
     clean = not any("error" in v for v in extra_modes.values() if isinstance(v, dict))
     if world > 1 and clean: dist.destroy_process_group()   # before the JSON line: RCCL prints its version banner when the group goes away
     emit(final=True)
+    if not state["loss_finite"]:      # the line is printed (it says which); a benchmark whose loss is not a number has measured nothing
+        print("bench.py: a timed region's mean loss is not finite", file=sys.stderr, flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(5)
     if world > 1:
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(4 if leg_failed else 0)      # the line (with the leg's {"error": ...}) is printed; the exit code says a leg failed while running

@@ -92,7 +92,7 @@ def _wait_group():
     import datetime
     import torch.distributed as dist
     if _WAIT_GROUP is None:
-        _WAIT_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=7))       # (a collective itself: every rank reaches the first use together)
+        _WAIT_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=7))       # a collective itself: learn() creates it up front, where the ranks are together
     return _WAIT_GROUP
 
 
@@ -150,6 +150,10 @@ class Gnn(T2v):
         member = teamsvecs["member"]
         d = int(cfg_get(m, "d"))
         w = None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            _barrier(); _wait_group()      # the long-timeout group is made HERE, all ranks arriving together: made lazily inside _sync_torch_rng, rank 0 would reach new_group only
+                                           # after training the whole first fold, and the others' wait inside gloo's connect would be cut by the store's own (short) timeout
         for foldidx in splits["folds"].keys():
             drop = np.concatenate([np.asarray(splits["test"]), np.asarray(splits["folds"][foldidx]["valid"])])
             rowptr, col, off, n = stm_graph(skill, member, drop)
@@ -203,11 +207,13 @@ class Gnn(T2v):
         which its pickled HeteroData holds the node stores (src/mdl/emb/gnn.py:29-47: the iteration order of a Python set, recorded only in `*.graph.pkl`): that file is
         read and the row blocks are re-stacked; a foreign table without its graph file is refused - sliced by the wrong order it would train silently on the wrong rows."""
         from . import pyg_reader
-        ref = pyg_reader.reference_table(path)      # restricted unpickler: the omegaconf cfg inside a reference checkpoint resolves to inert holders
-        import torch
-        try: ck = torch.load(path, map_location="cpu", weights_only=False)
-        except Exception: ck = {}                   # (a reference checkpoint: its cfg needs omegaconf)
-        if isinstance(ck, dict) and ck.get("node_order") == NODE_ORDER and tuple(ck.get("node_offsets", ())) == (off["skill"], off["member"], off["team"], n):
+        ref = pyg_reader.reference_table(path)      # restricted unpickler, the ONLY load of the file: the pickled cfg (omegaconf or not) resolves to inert holders, this plugin's
+                                                    # node_order / node_offsets markers are plain builtins and come through it - plugin or reference is decided from those alone
+        if ref["node_order"] is not None and ref["node_order"] != NODE_ORDER:
+            raise RuntimeError(f"{path}: node order {ref['node_order']!r}, this build writes and reads {NODE_ORDER!r}")
+        if ref["node_order"] == NODE_ORDER:
+            if ref["node_offsets"] != (off["skill"], off["member"], off["team"], n):
+                raise RuntimeError(f"{path}: written for node offsets {ref['node_offsets']}, teamsvecs gives {(off['skill'], off['member'], off['team'], n)}")
             log.info(f"Loading the model {path} ...")
             return ref["weight"]
         graph = getattr(self, "graph_file", None)

@@ -80,10 +80,18 @@ def node_blocks(graph_pkl):
 _TORCH_OK = ("torch._utils", "torch", "torch.storage", "torch._tensor", "torch.serialization", "torch.nn.parameter")
 
 
+def _load_from_bytes_weights_only(b):
+    """torch.storage._load_from_bytes is a nested, unrestricted torch.load of a storage's bytes: here the nested load admits tensors and storages only"""
+    import io
+    import torch
+    return torch.load(io.BytesIO(b), map_location="cpu", weights_only=True)
+
+
 class _CkptUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if (module, name) in _SAFE_BUILTINS: return super().find_class(module, name)
-        if module in _TORCH_OK and (name.startswith("_rebuild") or name.endswith("Storage") or name in ("Tensor", "Size", "device", "dtype", "Parameter", "_load_from_bytes")):
+        if (module, name) == ("torch.storage", "_load_from_bytes"): return _load_from_bytes_weights_only
+        if module in _TORCH_OK and (name.startswith("_rebuild") or name.endswith("Storage") or name in ("Tensor", "Size", "device", "dtype", "Parameter")):
             return super().find_class(module, name)
         return _holder(module, name)
 
@@ -96,14 +104,19 @@ class _PickleModule:
 
 
 def reference_table(path):
-    """{'weight': float32 [n, d] = model_state_dict['embedding.weight'], 'e', 't_loss', 'v_loss'} of a checkpoint gnn.py:445,453 wrote"""
+    """{'weight': float32 [n, d] = model_state_dict['embedding.weight'], 'e', 't_loss', 'v_loss'} of a checkpoint gnn.py:445,453 wrote, + 'node_order' (str or None) and
+    'node_offsets' (tuple of ints or None): the markers opentf_amd.mdl.emb.gnn._save adds - plain builtins, so they survive the restricted load whatever the pickled cfg is"""
     import torch
     ck = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
     sd = ck.get("model_state_dict") if isinstance(ck, dict) else None
     if not isinstance(sd, dict) or "embedding.weight" not in sd:
         raise RuntimeError(f"{path}: no model_state_dict['embedding.weight'] inside (not a node2vec checkpoint of src/mdl/emb/gnn.py)")
     w = sd["embedding.weight"]
-    return {"weight": np.ascontiguousarray(w.detach().cpu().numpy(), dtype=np.float32), "e": ck.get("e"), "t_loss": ck.get("t_loss"), "v_loss": ck.get("v_loss")}
+    order, offs = ck.get("node_order"), ck.get("node_offsets")
+    order = order if isinstance(order, str) else None
+    offs = tuple(int(o) for o in offs) if isinstance(offs, (tuple, list)) and all(isinstance(o, int) for o in offs) else None
+    return {"weight": np.ascontiguousarray(w.detach().cpu().numpy(), dtype=np.float32), "e": ck.get("e"), "t_loss": ck.get("t_loss"), "v_loss": ck.get("v_loss"),
+            "node_order": order, "node_offsets": offs}
 
 
 def blocks_to_order(weight, blocks, want):

@@ -100,3 +100,35 @@ def test_the_references_graph_file_and_table_are_read_without_torch_geometric(tm
     evil.write_bytes(pickle.dumps(Evil(), protocol=4))
     with pytest.raises(RuntimeError, match="_node_store_dict"): R.node_blocks(str(evil))
     assert not (tmp_path / "pwned").exists()
+
+
+def test_a_plugin_table_is_recognised_under_the_restricted_load_whatever_its_cfg_is(tmp_path):
+    """ADVICE r5 (medium).  `_load_fold` decides "this plugin's table" from the node_order / node_offsets markers, which are plain builtins and come through the restricted
+    unpickler - it no longer re-opens the file with an unrestricted torch.load (whose failure on an un-unpicklable cfg used to demote the table to "the reference's" and
+    re-stack its rows by a graph file lying beside it).  Here the cfg is an instance of a class that no longer exists at load time, and a payload that would run code on
+    an unrestricted load sits in the file: the table is taken as the plugin's, rows untouched, nothing runs."""
+    import os, sys, types
+    from opentf_amd.mdl.emb import pyg_reader as R
+    from opentf_amd.mdl.emb.gnn import Gnn, NODE_ORDER
+    mod = types.ModuleType("gone_cfg_module")
+    class GoneCfg(dict): pass
+    GoneCfg.__module__ = "gone_cfg_module"; GoneCfg.__qualname__ = "GoneCfg"; mod.GoneCfg = GoneCfg
+    class Evil:
+        def __reduce__(self): return (os.system, (f"touch {tmp_path}/pwned",))
+    W = np.arange(12 * 4, dtype=np.float32).reshape(12, 4)
+    off = {"skill": 0, "member": 3, "team": 7}
+    sys.modules["gone_cfg_module"] = mod
+    try:
+        torch.save({"model_state_dict": {"embedding.weight": torch.from_numpy(W)}, "cfg": GoneCfg(a=1), "f": 0, "e": 2, "t_loss": 1.0, "v_loss": 2.0, "evil": Evil(),
+                    "node_order": NODE_ORDER, "node_offsets": (0, 3, 7, 12)}, tmp_path / "f0.pt")
+    finally:
+        del sys.modules["gone_cfg_module"]
+    t = R.reference_table(str(tmp_path / "f0.pt"))
+    assert t["node_order"] == NODE_ORDER and t["node_offsets"] == (0, 3, 7, 12) and not (tmp_path / "pwned").exists()
+    g = Gnn.__new__(Gnn); g.graph_file = str(tmp_path / "stm.add.graph.pkl")       # (absent: a table taken for the reference's would be refused)
+    np.testing.assert_array_equal(g._load_fold(str(tmp_path / "f0.pt"), off, 12), W)
+    assert not (tmp_path / "pwned").exists()
+    with pytest.raises(RuntimeError, match="node offsets"): g._load_fold(str(tmp_path / "f0.pt"), {"skill": 0, "member": 4, "team": 7}, 12)
+    # a table without the markers and without its graph file stays refused
+    torch.save({"model_state_dict": {"embedding.weight": torch.from_numpy(W)}, "cfg": None, "e": 0, "t_loss": 0.0, "v_loss": 0.0}, tmp_path / "f1.pt")
+    with pytest.raises(RuntimeError, match="graph file"): g._load_fold(str(tmp_path / "f1.pt"), off, 12)
