@@ -292,6 +292,8 @@ int  ntf_n2v_edge_bce(ntf_n2v* h, const int64_t* src, const int64_t* dst, int64_
  * the pass at which the document's job was cut.  Random draws are Philox words keyed by (seed, epoch) and counted by (document, position, unit, slot).  serial != 0: one wave walks
  * all documents in order - the oracle's sequential pass (parity tests); otherwise one wave per document, Hogwild through f32 atomic adds as gensim's worker threads
  * are through plain stores.  mean_loss (nullable): mean -log sigmoid(+-f) over the pairs trained; device_ms (nullable): device time of the pass.
+ * d: any vector size 1..256 (data.embedding.d is free in the reference, its CI trains d = 9): on the device a row is padded to a multiple of 64 floats, the pad
+ * stays zero; the host side sees [rows, d] arrays only.
  * ntf_d2v_get / ntf_d2v_set: what = 0 doc vectors [n_docs, d] (= Doc2Vec.dv.vectors, row i = team i), 1 word vectors [n_vocab, d], 2 syn1neg [n_vocab, d]. */
 typedef struct ntf_d2v ntf_d2v;
 int  ntf_d2v_create(int device, int64_t n_docs, int64_t n_vocab, int32_t d, const int64_t* doc_ptr, const int32_t* words, const uint32_t* sample_int,

@@ -23,7 +23,7 @@ using namespace ntf;
 
 struct ntf_d2v {
     int device = 0; hipStream_t st = nullptr;
-    int64_t n_docs = 0, n_vocab = 0, n_words = 0; int d = 0;
+    int64_t n_docs = 0, n_vocab = 0, n_words = 0; int d = 0, dp = 0;   // dp: the device row stride, d rounded up to a multiple of 64 (a wave holds dp / 64 values per lane; the columns past d are zero and stay zero)
     int64_t* doc_ptr = nullptr; int32_t* words = nullptr;
     uint32_t *sample_int = nullptr, *cum_table = nullptr;
     float *dv = nullptr, *wv = nullptr, *syn1neg = nullptr;
@@ -307,8 +307,8 @@ extern "C" int ntf_d2v_create(int device, int64_t n_docs, int64_t n_vocab, int32
                               const uint32_t* cum_table, const float* init_wv, const float* init_dv, uint64_t seed, ntf_d2v** out) {
     if (!out) { g_d2v_create_error = "out is NULL"; return NTF_EINVAL; }
     *out = nullptr;
-    if (n_docs < 1 || n_vocab < 1 || d < 64 || d > 256 || (d & 63) || !doc_ptr || !words || !sample_int || !cum_table || !init_wv || !init_dv) {
-        g_d2v_create_error = "d2v: need n_docs >= 1, n_vocab >= 1, d in {64, 128, 192, 256}, the documents, the vocabulary tables and the initial vectors"; return NTF_EINVAL; }
+    if (n_docs < 1 || n_vocab < 1 || d < 1 || d > 256 || !doc_ptr || !words || !sample_int || !cum_table || !init_wv || !init_dv) {
+        g_d2v_create_error = "d2v: need n_docs >= 1, n_vocab >= 1, 1 <= d <= 256, the documents, the vocabulary tables and the initial vectors"; return NTF_EINVAL; }
     if (doc_ptr[0] != 0) { g_d2v_create_error = "d2v: doc_ptr[0] != 0"; return NTF_EINVAL; }
     for (int64_t i = 0; i < n_docs; ++i) if (doc_ptr[i + 1] < doc_ptr[i]) { g_d2v_create_error = "d2v: doc_ptr not monotone"; return NTF_EINVAL; }
     const int64_t nw = doc_ptr[n_docs];
@@ -319,20 +319,24 @@ extern "C" int ntf_d2v_create(int device, int64_t n_docs, int64_t n_vocab, int32
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_d2v_create_error = "no such HIP device (there is no CPU fallback)"; return NTF_EHIP; }
     hipSetDevice(device);
     ntf_d2v* h = new ntf_d2v();
-    h->device = device; h->n_docs = n_docs; h->n_vocab = n_vocab; h->n_words = nw; h->d = d; h->seed = seed;
+    h->device = device; h->n_docs = n_docs; h->n_vocab = n_vocab; h->n_words = nw; h->d = d; h->dp = (d + 63) / 64 * 64; h->seed = seed;
+    const int64_t dp = h->dp;
     int rc = NTF_OK;
     auto A = [&](int r) { if (rc == NTF_OK) rc = r; };
     if (hipStreamCreate(&h->st) != hipSuccess) { g_d2v_create_error = "hipStreamCreate failed"; delete h; return NTF_EHIP; }
     A(dalloc(h, &h->doc_ptr, n_docs + 1)); A(dalloc(h, &h->words, std::max<int64_t>(nw, 1))); A(dalloc(h, &h->sample_int, n_vocab)); A(dalloc(h, &h->cum_table, n_vocab));
-    A(dalloc(h, &h->dv, n_docs * d)); A(dalloc(h, &h->wv, n_vocab * d)); A(dalloc(h, &h->syn1neg, n_vocab * d)); A(dalloc(h, &h->order, n_docs)); A(dalloc(h, &h->progress, n_docs)); A(dalloc(h, &h->d_loss, 2));
+    A(dalloc(h, &h->dv, n_docs * dp)); A(dalloc(h, &h->wv, n_vocab * dp)); A(dalloc(h, &h->syn1neg, n_vocab * dp)); A(dalloc(h, &h->order, n_docs)); A(dalloc(h, &h->progress, n_docs)); A(dalloc(h, &h->d_loss, 2));
     if (rc != NTF_OK) { g_d2v_create_error = h->err; ntf_d2v_destroy(h); return rc; }
     hipMemcpy(h->doc_ptr, doc_ptr, (n_docs + 1) * 8, hipMemcpyHostToDevice);
     if (nw) hipMemcpy(h->words, words, nw * 4, hipMemcpyHostToDevice);
     hipMemcpy(h->sample_int, sample_int, n_vocab * 4, hipMemcpyHostToDevice);
     hipMemcpy(h->cum_table, cum_table, n_vocab * 4, hipMemcpyHostToDevice);
-    hipMemcpy(h->dv, init_dv, (size_t)n_docs * d * 4, hipMemcpyHostToDevice);
-    hipMemcpy(h->wv, init_wv, (size_t)n_vocab * d * 4, hipMemcpyHostToDevice);
-    hipMemsetAsync(h->syn1neg, 0, (size_t)n_vocab * d * 4, h->st);
+    // any vector size (the reference's CI trains d9 tables, data.embedding.d is free): rows of d floats at a stride of dp, the pad columns zero.  A zero column of
+    // every table stays zero through every update (each update is a multiple of another table's same column), and adds nothing to a dot product
+    if (dp != d) { hipMemset(h->dv, 0, (size_t)n_docs * dp * 4); hipMemset(h->wv, 0, (size_t)n_vocab * dp * 4); }
+    hipMemcpy2D(h->dv, (size_t)dp * 4, init_dv, (size_t)d * 4, (size_t)d * 4, (size_t)n_docs, hipMemcpyHostToDevice);
+    hipMemcpy2D(h->wv, (size_t)dp * 4, init_wv, (size_t)d * 4, (size_t)d * 4, (size_t)n_vocab, hipMemcpyHostToDevice);
+    hipMemsetAsync(h->syn1neg, 0, (size_t)n_vocab * dp * 4, h->st);
     if (hipStreamSynchronize(h->st) != hipSuccess) { g_d2v_create_error = "device initialisation failed"; ntf_d2v_destroy(h); return NTF_EHIP; }
     *out = h;
     return NTF_OK;
@@ -356,7 +360,7 @@ extern "C" int ntf_d2v_train_epoch(ntf_d2v* h, int32_t dm, int32_t window, int32
     }
     DCHK(h, hipMemsetAsync(h->d_loss, 0, 16, h->st));
     D2vArgs a;
-    a.n_docs = h->n_docs; a.n_vocab = h->n_vocab; a.d = h->d; a.window = window; a.negative = negative; a.serial = serial ? 1 : 0;
+    a.n_docs = h->n_docs; a.n_vocab = h->n_vocab; a.d = h->dp; a.window = window; a.negative = negative; a.serial = serial ? 1 : 0;
     a.doc_ptr = h->doc_ptr; a.words = h->words; a.sample_int = h->sample_int; a.cum_table = h->cum_table; a.order = order ? h->order : nullptr; a.progress = progress ? h->progress : nullptr;
     a.dv = h->dv; a.wv = h->wv; a.syn1neg = h->syn1neg; a.alpha_start = alpha_start; a.alpha_end = alpha_end; a.loss = mean_loss ? h->d_loss : nullptr;
     d2v_key(h->seed, epoch, a.k0, a.k1);
@@ -366,14 +370,14 @@ extern "C" int ntf_d2v_train_epoch(ntf_d2v* h, int32_t dm, int32_t window, int32
     if (device_ms) { if (!h->ev0) { DCHK(h, hipEventCreate(&h->ev0)); DCHK(h, hipEventCreate(&h->ev1)); } DCHK(h, hipEventRecord(h->ev0, h->st)); }
     // PV-DM at the reference's window (src/mdl/emb/__config__.yaml: w = 5): word-vector additions deferred to one per kept position (k_d2v_epoch<.., 5>); NTF_D2V_DEFER=0: the plain kernel
     static const bool defer_ok = !(getenv("NTF_D2V_DEFER") && atoi(getenv("NTF_D2V_DEFER")) == 0);
-    if (dm && window == 5 && defer_ok && h->d >= 128) {     // (d = 64: the rows are 256 B and the plain kernel's shorter chain wins - 45.7 against 49.4 ms; d = 128 / 192 / 256: 55 / 78 / 98 against 66 / 102 / 133)
-        switch (h->d / 64) {
+    if (dm && window == 5 && defer_ok && h->dp >= 128) {     // (d = 64: the rows are 256 B and the plain kernel's shorter chain wins - 45.7 against 49.4 ms; d = 128 / 192 / 256: 55 / 78 / 98 against 66 / 102 / 133)
+        switch (h->dp / 64) {
             case 2: hipLaunchKernelGGL((k_d2v_epoch<2, 5>), grid, block, 0, h->st, a, dm); break;
             case 3: hipLaunchKernelGGL((k_d2v_epoch<3, 5>), grid, block, 0, h->st, a, dm); break;
             default: hipLaunchKernelGGL((k_d2v_epoch<4, 5>), grid, block, 0, h->st, a, dm); break;
         }
     } else
-    switch (h->d / 64) {
+    switch (h->dp / 64) {
         case 1: hipLaunchKernelGGL(k_d2v_epoch<1>, grid, block, 0, h->st, a, dm); break;
         case 2: hipLaunchKernelGGL(k_d2v_epoch<2>, grid, block, 0, h->st, a, dm); break;
         case 3: hipLaunchKernelGGL(k_d2v_epoch<3>, grid, block, 0, h->st, a, dm); break;
@@ -398,7 +402,7 @@ extern "C" int ntf_d2v_get(ntf_d2v* h, int what, float* host) {   // what: 0 = d
     DCHK(h, hipStreamSynchronize(h->st));
     const float* src = what == 0 ? h->dv : what == 1 ? h->wv : h->syn1neg;
     const int64_t rows = what == 0 ? h->n_docs : h->n_vocab;
-    DCHK(h, hipMemcpy(host, src, (size_t)rows * h->d * 4, hipMemcpyDeviceToHost));
+    DCHK(h, hipMemcpy2D(host, (size_t)h->d * 4, src, (size_t)h->dp * 4, (size_t)h->d * 4, (size_t)rows, hipMemcpyDeviceToHost));
     return NTF_OK;
 }
 
@@ -408,6 +412,6 @@ extern "C" int ntf_d2v_set(ntf_d2v* h, int what, const float* host) {   // resum
     DCHK(h, hipStreamSynchronize(h->st));
     float* dst = what == 0 ? h->dv : what == 1 ? h->wv : h->syn1neg;
     const int64_t rows = what == 0 ? h->n_docs : h->n_vocab;
-    DCHK(h, hipMemcpy(dst, host, (size_t)rows * h->d * 4, hipMemcpyHostToDevice));
+    DCHK(h, hipMemcpy2D(dst, (size_t)h->dp * 4, host, (size_t)h->d * 4, (size_t)h->d * 4, (size_t)rows, hipMemcpyHostToDevice));
     return NTF_OK;
 }

@@ -737,8 +737,9 @@ static int set_batch_unigram(ntf_engine* e, const int64_t* global_rows_host, int
     // staging: [cols | alias | prob | weight] per slot
     const size_t need = (size_t)std::max(nsup, 1) * 16;
     if (e->ub_cap < need) {
-        HIPCHK(e, hipStreamSynchronize(e->st));
-        if (e->st4) HIPCHK(e, hipStreamSynchronize(e->st4));      // (a prefetched sampler may still read the old buffers)
+        // every stream, not the two named here: called from prefetch_next_head e->st IS e->st4 (the main stream, whose in-flight step may still read its own slot's
+        // table, would not be waited for).  Growing is rare (the capacity doubles): a device-wide wait costs nothing that matters
+        HIPCHK(e, hipDeviceSynchronize());
         e->hp.ub = -1;
         for (int k = 0; k < 2; ++k) { if (e->ub_host[k]) hipHostFree(e->ub_host[k]); if (e->ub_dev[k]) hipFree(e->ub_dev[k]); e->ub_host[k] = nullptr; e->ub_dev[k] = nullptr; }
         e->ub_cap = need * 2;

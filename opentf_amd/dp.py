@@ -90,7 +90,10 @@ class CollectiveTrace:
 
     def wait(self, work):
         if self.stream_ordered:
-            work.wait()          # orders the current stream behind the collective; the host does not block (a hang surfaces in `sync`, bounded)
+            try:
+                work.wait()      # orders the current stream behind the collective; the host does not block (a hang surfaces in `sync`, bounded)
+            except RuntimeError as ex:      # an RCCL error raised at the wait (communicator aborted, a peer gone) keeps the contract: a naming message, a non-zero exit
+                raise CollectiveTimeout(f"{self.who}: {type(ex).__name__}: {ex} [{self.describe()}]") from ex
             return
         try:
             work.wait(timeout=datetime.timedelta(seconds=collective_timeout_s()))
@@ -131,6 +134,7 @@ class DataParallel:
         self.world = self.emulate or (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = 0 if self.emulate else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.emulated_bytes = {"reduce_scatter_in": 0, "all_reduce": 0, "all_gather_out": 0, "steps": 0}
+        self.sync_every = max(1, int(os.environ.get("NTF_DP_SYNC_EVERY", "64")))
         self._grad = engine.grad_tensor()  # flat view of the engine's gradient buffer (HBM; aliases, no copy)
         # NTF_DP_FORCE_ALLREDUCE=1: run the collectives even at world_size 1 (exercises RCCL on the aliased buffers on a 1-GPU box)
         self.force_allreduce = (dist.is_initialized() and os.environ.get("NTF_DP_FORCE_ALLREDUCE", "0") == "1") or bool(self.emulate)
@@ -225,7 +229,10 @@ class DataParallel:
         self._finish_gathers(keep_chunks=bool(spans))
         works, owned, gathered = [], [], []
 
+        ranges_seen = []
+
         def before_range(j):
+            ranges_seen.append(j)
             for k in range(spans[j][0], spans[j][1]):
                 for w in self._pending_chunk.pop(k, ()):
                     self.trace.wait(w)
@@ -233,6 +240,10 @@ class DataParallel:
         if self.n_chunks:
             if have_rows and spans:
                 e.step_staged_deferred(goff + lo, hi - lo, goff, gB, before_range=before_range)
+                if ranges_seen != list(range(len(spans))):
+                    # Python's fwd_ranges() and the engine's in-step decision disagreed (the engine ran the whole-layer head): its producer and forward kernel were queued
+                    # in front of the all-gathers still pending here, i.e. read parameters that had not arrived.  Never silently: this is a bug, not a slow path.
+                    raise RuntimeError(f"data-parallel head: the engine called back for ranges {ranges_seen}, {len(spans)} were planned; the step read parameters whose all-gathers were still pending")
                 self._finish_gathers()            # (every chunk belongs to a range: nothing is left; kept as the invariant)
             elif have_rows:
                 e.step_staged_deferred(goff + lo, hi - lo, goff, gB)
@@ -280,6 +291,10 @@ class DataParallel:
                 self.engine.step_staged(goff, gB, global_offset=goff, global_B=gB, train=train, apply=train)
                 continue
             lo, hi = shard_bounds(gB, self.world, self.rank)
+            if self.trace.stream_ordered and self._grad.is_cuda and steps % self.sync_every == 0:
+                # RCCL waits are stream-ordered and unbounded: without this the host queues the whole epoch behind a hung collective and blocks inside a full launch
+                # queue, never reaching the bounded sync at the end of the phase.  One event poll every `sync_every` steps (NTF_DP_SYNC_EVERY, default 64).
+                self.trace.sync(f"steps up to {steps} of the phase")
             if train:
                 self._train_step(goff, gB, lo, hi)
             elif hi > lo:

@@ -149,3 +149,42 @@ def calculate_skill_coverage(X, Y_, expertskillvecs, per_instance=False, topks="
         raise libntf.NtfError(f"ntf_skill_coverage failed ({rc})")
     df = pd.DataFrame(out.astype(np.float64), columns=[f"skill_coverage_{k}" for k in cuts])
     return df, df.mean().to_frame("mean").rename_axis("metrics")
+
+
+class EvalSpec:
+    """what an eval config asks for (src/__config__.yaml eval section), parsed once"""
+    def __init__(self, topK, per_instance, trec, other):
+        self.topK, self.per_instance, self.trec = topK, bool(per_instance), list(trec or [])
+        other = list(other or [])
+        self.auc = next((m for m in other if "aucroc" in m), None)               # 'aucroc' or 'aucroc+' (+ = keep the curve)
+        self.skc = next((m for m in other if "skill_coverage" in m), None)       # 'skill_coverage_2,5,10'
+
+    @classmethod
+    def from_cfg(cls, evalcfg):
+        from ..mdl.ntf import cfg_get
+        m = cfg_get(evalcfg, "metrics")
+        return cls(cfg_get(evalcfg, "topK"), cfg_get(evalcfg, "per_instance"), cfg_get(m, "trec"), cfg_get(m, "other"))
+
+
+def score_predictions(teamsvecs, rows, Y_, spec, device=0):
+    """One prediction matrix against the truth rows `rows` of teamsvecs: (per-instance table, mean table, roc curve or None).  Row order of the mean table as the
+    reference writes it: trec metrics, aucroc, skill coverage (src/mdl/ntf.py:57-84)."""
+    import pandas as pd
+    Y = teamsvecs["member"][rows]
+    assert Y.shape == Y_.shape, f"Shape mismatch between truth Y {Y.shape} vs preds Y_ {Y_.shape}!"
+    inst_parts, mean_parts, roc = [], [], None
+    if spec.trec:
+        df, df_mean = calculate_metrics(Y, Y_, spec.topK, spec.per_instance, spec.trec, device=device)
+        inst_parts.append(df); mean_parts.append(df_mean)
+    if spec.auc:
+        auc, roc = calculate_auc_roc(Y, Y_, curve=(spec.auc == "aucroc+"))
+        mean_parts.append(pd.DataFrame({"mean": [auc]}, index=pd.Index(["aucroc"], name="metrics")))
+    if spec.skc:
+        X = teamsvecs["skill"] if sp.issparse(teamsvecs["skill"]) else teamsvecs["original_skill"]
+        df, df_mean = calculate_skill_coverage(X[rows], Y_, teamsvecs["skillcoverage"], spec.per_instance, topks=spec.skc.replace("skill_coverage_", ""), device=device)
+        inst_parts.append(df); mean_parts.append(df_mean)
+    inst_parts = [d.reset_index(drop=True) for d in inst_parts if d is not None and not d.empty]
+    inst = pd.concat(inst_parts, axis=1) if inst_parts else pd.DataFrame()
+    mean = pd.concat(mean_parts, axis=0) if mean_parts else pd.DataFrame(columns=["mean"])
+    mean.index.name = "metrics"
+    return inst, mean, roc

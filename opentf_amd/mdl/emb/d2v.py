@@ -212,8 +212,8 @@ class D2v(T2v):
         os.makedirs(self.output, exist_ok=True)
         doc_ptr, words, key = self.data
         d, e, w, dm, min_alpha = int(cfg_get(c, "d")), int(cfg_get(c, "e")), int(cfg_get(c, "w")), int(cfg_get(c, "dm")), float(cfg_get(c, "lr"))
-        if d not in (64, 128, 192, 256):
-            raise ValueError(f"d2v on the device trains vector sizes 64, 128, 192 and 256 (a wave holds d / 64 values per lane); data.embedding.d = {d} is not one of them")
+        if not 1 <= d <= 256:
+            raise ValueError(f"d2v on the device trains vector sizes 1..256 (a wave holds ceil(d / 64) values per lane, at most four); data.embedding.d = {d}")
         longest = int(np.diff(np.asarray(doc_ptr)).max()) if len(doc_ptr) > 1 else 0
         if longest > 10000:
             log.info(f"The longest document has {longest} words: as in gensim, at most 10 000 of a document's words that survive the subsampling are trained on")

@@ -79,6 +79,49 @@ def summary_writer():
         return _NullWriter
 
 
+class _PredJob:
+    __slots__ = ("pred_set", "fold", "path", "final")
+    def __init__(self, pred_set, fold, path, final): self.pred_set, self.fold, self.path, self.final = pred_set, fold, path, final
+
+
+def _pred_jobs(output, splits, on_train, per_epoch):
+    """the prediction files of a run directory, set by set and fold by fold; `final` marks a fold's end-of-training file `f{k}.{set}.pred` (the one the set-level
+    tables aggregate), the per-epoch files `f{k}.{set}.e{e}.pred` follow it in epoch order"""
+    import re
+    names = os.listdir(output) if per_epoch else []
+    for pred_set in (("test", "train", "valid") if on_train else ("test",)):
+        for k in splits["folds"].keys():
+            yield _PredJob(pred_set, k, f"{output}/f{k}.{pred_set}.pred", True)
+            epoch_files = [(int(m.group(1)), n) for n in names for m in [re.match(rf"f{k}\.{pred_set}\.e(\d+)\.pred$", n)] if m]
+            for _, n in sorted(epoch_files):
+                yield _PredJob(pred_set, k, f"{output}/{n}", False)
+
+
+def _read_pred(path):
+    """`y_pred` of a prediction file (src/mdl/fnn.py:218) as a numpy array (dense files) or a scipy CSR (the top-K files, sparse COO inside)"""
+    import scipy.sparse
+    import torch
+    y = torch.load(path, map_location="cpu", weights_only=False)["y_pred"]
+    if not y.is_sparse: return y.numpy()
+    y = y.coalesce(); ij = y.indices().numpy()
+    return scipy.sparse.csr_matrix((y.values().numpy(), (ij[0], ij[1])), shape=tuple(y.size()))
+
+
+class _FoldTable:
+    """what the set-level files need of the folds' final files: one column of means per fold, and the running sum of the per-instance tables"""
+    def __init__(self): self.means, self.inst_sum = [], None
+
+    def add(self, mean, inst):
+        self.means.append(mean["mean"])
+        if inst is not None: self.inst_sum = inst.copy() if self.inst_sum is None else self.inst_sum.add(inst, fill_value=0)
+
+    def write(self, stem, n_folds):
+        import pandas as pd
+        per_fold = pd.concat(self.means, axis=1)
+        pd.DataFrame({"mean": per_fold.mean(axis=1), "std": per_fold.std(axis=1)}).to_csv(f"{stem}.mean.csv")
+        if self.inst_sum is not None: (self.inst_sum / n_folds).to_csv(f"{stem}.instance_mean.csv", index=False)
+
+
 class Ntf:
     def __init__(self, output, device, seed, cfg):
         self.cfg = cfg
@@ -99,68 +142,28 @@ class Ntf:
     def test(self, teamsvecs, splits, testcfg): pass
 
     def evaluate(self, teamsvecs, splits, evalcfg):
-        """The reference's eval stage (src/mdl/ntf.py:32-92) with the per-instance metrics on the device (opentf_amd.evl.metric):
-        same inputs (the `.pred` files test() wrote), same outputs (`*.pred.eval.mean.csv`, `*.pred.eval.instance.csv`,
-        `{set}.pred.eval.mean.csv` with mean/std over folds).  Mounted in the reference tree the plugin inherits the reference's
-        own evaluate() instead."""
-        import re
-        import pandas as pd
-        import scipy.sparse
-        import torch
+        """Eval stage: scores the `.pred` files test() wrote and leaves the files the reference's stage leaves (src/mdl/ntf.py:32-92): per prediction file
+        `<file>.eval.mean.csv` (+ `.eval.instance.csv`, `.eval.roc.pkl`), per prediction set `{set}.pred.eval.mean.csv` (mean / std over the folds' final files) and
+        `{set}.pred.eval.instance_mean.csv`.  A thin driver: `_pred_jobs` lists the files, `evl.metric.score_predictions` does the arithmetic (rank metrics and skill
+        coverage on the device), `_FoldTable` keeps what the set-level files need.  Mounted in the reference tree the plugin inherits the reference's own evaluate()
+        instead."""
         from ..evl import metric
         assert os.path.isdir(self.output), f"No folder for {self.output} exist!"
         if dist_rank() != 0:        # torchrun: ONE writer of the csv / pkl files (as in test()); the others wait for it
             _dist_barrier(); return
-        y_test = teamsvecs["member"][splits["test"]]
-        trec = list(cfg_get(cfg_get(evalcfg, "metrics"), "trec") or [])
-        other = list(cfg_get(cfg_get(evalcfg, "metrics"), "other") or [])
-        per_instance = bool(cfg_get(evalcfg, "per_instance"))
-        for pred_set in (["test", "train", "valid"] if cfg_get(evalcfg, "on_train") else ["test"]):
-            fold_mean, mean_std = pd.DataFrame(), pd.DataFrame()
-            fold_inst = pd.DataFrame()
-            for foldidx in splits["folds"].keys():
-                Y = y_test if pred_set == "test" else teamsvecs["member"][splits["folds"][foldidx][pred_set]]
-                predfiles = [f"{self.output}/f{foldidx}.{pred_set}.pred"]
-                if cfg_get(evalcfg, "per_epoch"):
-                    predfiles += [f"{self.output}/{_}" for _ in os.listdir(self.output) if re.match(rf"f{foldidx}.{pred_set}.e\d+.pred$", _)]
-                for i, predfile in enumerate(sorted(sorted(predfiles), key=len)):
-                    Y_ = torch.load(predfile, map_location="cpu", weights_only=False)["y_pred"]
-                    if Y_.is_sparse:
-                        Y_ = Y_.coalesce()
-                        ind = Y_.indices().numpy()
-                        Y_ = scipy.sparse.csr_matrix((Y_.values().numpy(), (ind[0], ind[1])), shape=tuple(Y_.size()))
-                    else:
-                        Y_ = Y_.numpy()
-                    assert Y.shape == Y_.shape, f"Shape mismatch between truth Y {Y.shape} vs preds Y_ {Y_.shape}!"
-                    df, df_mean = pd.DataFrame(), pd.DataFrame()
-                    if trec:
-                        df, df_mean = metric.calculate_metrics(Y, Y_, cfg_get(evalcfg, "topK"), per_instance, trec)
-                    auc = [m for m in other if "aucroc" in m]
-                    if auc:
-                        aucroc, fpr_tpr = metric.calculate_auc_roc(Y, Y_, curve=(auc[0] == "aucroc+"))
-                        if df_mean.empty: df_mean = pd.DataFrame(columns=["mean"])
-                        df_mean.loc["aucroc"] = aucroc
-                        if fpr_tpr:   # the (fpr, tpr) pair plot_roc consumes (src/mdl/ntf.py:67-69)
-                            import pickle
-                            with open(f"{predfile}.eval.roc.pkl", "wb") as outfile: pickle.dump(fpr_tpr, outfile)
-                    skc = [m for m in other if "skill_coverage" in m]
-                    if skc:
-                        X = teamsvecs["skill"] if scipy.sparse.issparse(teamsvecs["skill"]) else teamsvecs["original_skill"]
-                        X = X[splits["test"]] if pred_set == "test" else X[splits["folds"][foldidx][pred_set]]
-                        df_skc, df_mean_skc = metric.calculate_skill_coverage(X, Y_, teamsvecs["skillcoverage"], per_instance,
-                                                                               topks=skc[0].replace("skill_coverage_", ""))
-                        df = df_skc if (df is None or df.empty) else pd.concat([df.reset_index(drop=True), df_skc.reset_index(drop=True)], axis=1)
-                        df_mean = df_mean_skc if df_mean.empty else pd.concat([df_mean, df_mean_skc], axis=0)
-                    if per_instance: df.to_csv(f"{predfile}.eval.instance.csv", float_format="%.5f", index=False)
-                    df_mean.to_csv(f"{predfile}.eval.mean.csv")
-                    if i == 0:
-                        fold_mean = pd.concat([fold_mean, df_mean], axis=1)
-                        if per_instance: fold_inst = fold_inst.add(df, fill_value=0)
-            mean_std["mean"] = fold_mean.mean(axis=1)
-            mean_std["std"] = fold_mean.std(axis=1)
-            mean_std.to_csv(f"{self.output}/{pred_set}.pred.eval.mean.csv")
-            if per_instance:
-                fold_inst.truediv(len(splits["folds"].keys())).to_csv(f"{self.output}/{pred_set}.pred.eval.instance_mean.csv", index=False)
+        spec = metric.EvalSpec.from_cfg(evalcfg)
+        tables = {}
+        for job in _pred_jobs(self.output, splits, bool(cfg_get(evalcfg, "on_train")), bool(cfg_get(evalcfg, "per_epoch"))):
+            rows = splits["test"] if job.pred_set == "test" else splits["folds"][job.fold][job.pred_set]
+            inst, mean, roc = metric.score_predictions(teamsvecs, rows, _read_pred(job.path), spec)
+            if roc is not None:   # the (fpr, tpr) pair plot_roc consumes (src/mdl/ntf.py:67-69)
+                import pickle
+                with open(f"{job.path}.eval.roc.pkl", "wb") as f: pickle.dump(roc, f)
+            if spec.per_instance: inst.to_csv(f"{job.path}.eval.instance.csv", float_format="%.5f", index=False)
+            mean.to_csv(f"{job.path}.eval.mean.csv")
+            if job.final: tables.setdefault(job.pred_set, _FoldTable()).add(mean, inst if spec.per_instance else None)
+        for pred_set, t in tables.items():
+            t.write(f"{self.output}/{pred_set}.pred.eval", len(splits["folds"]))
         _dist_barrier()   # rank 0 wrote: the other ranks (waiting at the top) may go on
 
     def adila(self, teamsvecs, splits, faircfg):
