@@ -143,6 +143,10 @@ int ntf_prefetched_steps(ntf_engine* e, int64_t* steps);
  * fnn.py:25) - beside the dW kernel instead of between two steps' big kernels.  Reports how many steps found their head done that way (same results either way;
  * NTF_HEAD_PREFETCH=0 turns it off; per-batch unigram_b tables, injected tensors, expert shards and data-parallel shards always run their head in their own step). */
 int ntf_head_prefetch_hits(ntf_engine* e, int64_t* steps);
+/* Multi-hot input with a Flipout first layer (BASELINE config 3: 90 671 x 128 mu / rho pairs, src/mdl/ntf.py:23 + src/mdl/fnn.py:25,136-139): in a fused train step the
+ * layer's gradient finalisation (Flipout chain rule + KL), its Adam update and the NEXT step's sigma * eps + KL term are ONE pass over the layer beside the dW kernel
+ * (launch_flipout_sweep) instead of three.  Reports how many steps started on a first-layer operand produced that way (same results either way; NTF_L0_SWEEP=0 turns it off). */
+int ntf_first_layer_sweeps(ntf_engine* e, int64_t* steps);
 
 /* ---- the step:  body of the hot loop                              src/mdl/fnn.py:118-151
  * rows = B global team ids (host).  loss_out may be NULL: then nothing is synchronised and the loss is

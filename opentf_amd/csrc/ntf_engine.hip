@@ -128,6 +128,12 @@ struct ntf_engine {
                                       // 0 never; 2 always; 1 always, with the sampler / sign words on the auxiliary stream from the end of phase 1 (beside the whole dW kernel: slower, 1.34 against 1.30 at 8)
     int head = 1;                     // NTF_HEAD=0: the step's head as its chain of small kernels (A/B runs)
     bool pre_valid = false; uint64_t pre_step = 0; int prefetch = 1;   // NTF_PREFETCH=0: always the stand-alone producer (A/B runs)
+    // Multi-hot Flipout first layer (BASELINE config 3: 90 671 x 128 mu / rho pairs) in a step that applies Adam (round 6): launch_flipout_sweep - finalize + Adam + the NEXT
+    // step's sigma * eps and KL in one pass, on the side stream beside the dW kernel.  pre0_step: the step whose Wp[0] / KL the last sweep produced (used iff that step also
+    // starts on the output layer's prefetched operands: one validity protocol, pre_valid / pre_step); l0_swept: this step's Adam of the layer's weights ran in the sweep
+    // (apply_adam leaves them out); g0_clean: the layer's gradient rows are all zero (the sweep clears what it reads: no memset in front of the scatter)
+    int l0_sweep = 1;                 // NTF_L0_SWEEP=0: k_flipout_grad_finalize + the flat Adam + the stand-alone producer, as in round 5 (A/B runs)
+    bool l0_swept = false, g0_clean = false, use_pre0 = false; uint64_t pre0_step = ~0ull; uint8_t* l0_touched = nullptr; int64_t pre0_used = 0;
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
     // evaluation steps of one ntf_eval_epoch call (run_epoch) run back to back on unchanged parameters: eval_chain != 0 while that loop runs; the first producer launch of
     // the chain keeps the output layer's KL term and the range verdict on the planes of mu (d_chain: [double KL, int flag]), the later ones reuse them (PerturbChain)
@@ -254,6 +260,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* pf = getenv("NTF_PREFETCH")) e->prefetch = atoi(pf);
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
+    if (const char* sw = getenv("NTF_L0_SWEEP")) e->l0_sweep = atoi(sw);
     if (const char* fc = getenv("NTF_F32_COPY_MERGED")) e->f32_copy_merged = atoi(fc);
     if (const char* eh = getenv("NTF_EP_HEAD_PREFETCH")) e->ep_head_prefetch = atoi(eh);
     if (const char* dr = getenv("NTF_DP_RANGES")) e->dp_ranges = atoi(dr);
@@ -295,6 +302,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->Wp.assign(e->L, nullptr); e->bp.assign(e->L, nullptr);
     if (cfg->bayesian) for (int l = 0; l < e->L; ++l) { A(dmalloc(e, &e->Wp[l], e->layers[l].nw())); A(dmalloc(e, &e->bp[l], e->layers[l].out)); }
     A(dmalloc(e, &e->partial, (int64_t)B * std::max(loss_dense_nchunk(M), fused_loss_slots(M)))); A(dmalloc(e, &e->row_fix, B));
+    if (cfg->bayesian && cfg->input_mode == NTF_INPUT_MULTIHOT) A(dmalloc(e, &e->l0_touched, (int64_t)(cfg->dims[0] + 255) / 256 * 256));
     A(dmalloc(e, &e->d_loss, 4)); A(dmalloc(e, &e->d_kl, 4)); A(dmalloc(e, &e->d_chain, 2)); A(dmalloc(e, &e->d_acc, 2)); A(dmalloc(e, &e->d_acc_steps, 2));
     A(dmalloc(e, &e->ent_mc, B)); A(dmalloc(e, &e->ent_mean, B)); A(dmalloc(e, &e->gemm_slab, kGemmSlabFloats));
     if (rc == NTF_OK && fused_ok(e)) {
@@ -335,6 +343,7 @@ extern "C" void ntf_engine_destroy(ntf_engine* e) {
     dfree(e->Zout); dfree(e->dZout); dfree(e->Pbuf); dfree(e->Zh); dfree(e->dAct[0]); dfree(e->dAct[1]);
     for (auto& p : e->Wp) dfree(p);
     for (auto& p : e->bp) dfree(p);
+    dfree(e->l0_touched);
     dfree(e->partial); dfree(e->row_fix); dfree(e->d_loss); dfree(e->d_kl); dfree(e->d_chain); dfree(e->d_acc); dfree(e->d_acc_steps);
     dfree(e->ent_mc); dfree(e->ent_mean); dfree(e->dh_slab); dfree(e->fws_set[0]); dfree(e->fws_set[1]); dfree(e->pl_mu); dfree(e->pl_wp); dfree(e->gemm_slab); dfree(e->tk_vals); dfree(e->tk_idx);
     for (auto* v : {&e->inj_eps_w, &e->inj_eps_b, &e->inj_s_in, &e->inj_s_out}) for (auto& p : *v) dfree(p);
@@ -512,10 +521,11 @@ extern "C" int ntf_reset_optimizer(ntf_engine* e) {
     return NTF_OK;
 }
 extern "C" int ntf_set_lr(ntf_engine* e, float lr) { if (!e) return NTF_EINVAL; e->lr = lr; return NTF_OK; }
-extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; e->pre_valid = false; e->hp.valid = false; return NTF_OK; }
+extern "C" int ntf_set_seed(ntf_engine* e, uint64_t seed, uint64_t step) { if (!e) return NTF_EINVAL; e->seed = seed; e->step = step; e->pre_valid = false; e->pre0_step = ~0ull; e->hp.valid = false; return NTF_OK; }
 extern "C" int ntf_skip_step(ntf_engine* e) { if (!e) return NTF_EINVAL; e->step += 1; return NTF_OK; }
 extern "C" int ntf_prefetched_steps(ntf_engine* e, int64_t* steps) { if (!e || !steps) return NTF_EINVAL; *steps = e->pre_used; return NTF_OK; }
 extern "C" int ntf_head_prefetch_hits(ntf_engine* e, int64_t* steps) { if (!e || !steps) return NTF_EINVAL; *steps = e->hp_used; return NTF_OK; }
+extern "C" int ntf_first_layer_sweeps(ntf_engine* e, int64_t* steps) { if (!e || !steps) return NTF_EINVAL; *steps = e->pre0_used; return NTF_OK; }
 extern "C" int ntf_range_fallbacks(ntf_engine* e, int64_t* steps) {
     if (!e || !steps) return NTF_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
@@ -650,6 +660,7 @@ static int forward_layers(ntf_engine* e, const StepCtx& c, bool want_logits, boo
             if (last) e->pre_valid = false;   // overwrites the output layer's Wp
             const bool kl = !want_logits;  // loss steps: this layer's KL rides on the producer's pass over rho (and mu)
             const double share = (e->ep && !last) ? 1.0 / (double)e->ep_world : 1.0;   // expert shards: a replicated layer's KL is counted once over the shards
+            if (!(l == 0 && e->use_pre0))      // (use_pre0: sigma * eps of this step and its KL term came out of the previous step's launch_flipout_sweep)
             launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_WEIGHT], kl ? W : nullptr, li.nw(), normal_spec(e, c, l, T_EPS_W), e->Wp[l],
                                    share / (double)li.nw(), e->d_kl);
             launch_flipout_perturb(e->st, e->P + li.off[NTF_P_RHO_BIAS], kl ? b : nullptr, li.out, normal_spec(e, c, l, T_EPS_B), e->bp[l],
@@ -936,8 +947,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     if (c.part >= 2) goto backward;   // expert-sharded step, later phases
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
     {
+        const bool pre0 = e->pre0_step == c.step;      // the previous step's launch_flipout_sweep left this step's first-layer operand and KL term (multi-hot Flipout layer 0)
         const bool pre_ok = fused && e->cfg.bayesian && e->pre_valid && e->pre_step == c.step && e->pl_wp != nullptr &&
-                            !(c.inj && c.inj->eps_w[e->L - 1]);   // (an injected eps: the operands are made from it in this step)
+                            !(c.inj && c.inj->eps_w[e->L - 1]) &&   // (an injected eps: the operands are made from it in this step)
+                            !(pre0 && c.inj);                       // (likewise the first layer's: its KL term sits in the prefetched sum - the step starts from scratch)
         e->pre_valid = false;   // consumed, or stale
         use_pre = pre_ok;
         // the previous step's side stream may have run this batch's head already (see `head prefetch` below)
@@ -999,7 +1012,11 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     if (!use_head && (r = make_input(e, c))) return r;
     if (!aux && !hp_hit) { if ((r = sample_negatives(e, c))) return r; }
     if (fused) {
-        if (!use_head && (r = forward_layers(e, c, false, true))) return r;
+        e->use_pre0 = use_pre && e->pre0_step == c.step;      // (decided with use_pre: a step that drops the prefetched scalars drops the first layer's KL term with them)
+        e->pre0_step = ~0ull;
+        if (e->use_pre0) e->pre0_used += 1;
+        if (!use_head && (r = forward_layers(e, c, false, true))) { e->use_pre0 = false; return r; }
+        e->use_pre0 = false;
         FusedOut f;
         f.B = B; f.H = lo.in; f.M = M; f.bayes = e->cfg.bayesian; f.train = c.train;
         f.h = e->act[e->L - 1];
@@ -1128,6 +1145,7 @@ backward:
             e->st = restore.main;
         }
     }
+    bool l0_sweep_now = false;
     for (int l = e->L - 1; l >= 0; --l) {
         const LayerInfo& li = e->layers[l];
         const bool last = (l == e->L - 1);
@@ -1218,9 +1236,17 @@ backward:
             { Scope t(e, F_BIAS_GRAD); launch_bias_grad(e->st, dZ, li.out, B, li.out, sout_, gb, gRb, e->gemm_slab, kGemmSlabFloats); }
             if (l == 0 && e->cfg.input_mode == NTF_INPUT_MULTIHOT) {
                 Scope t(e, F_MULTIHOT);
-                HIPCHK(e, hipMemsetAsync(gW, 0, (size_t)li.nw() * 4, e->st));
-                if (gRW) HIPCHK(e, hipMemsetAsync(gRW, 0, (size_t)li.nw() * 4, e->st));
-                launch_multihot_bwd(e->st, c.rows_dev, B, li.in, li.out, e->s_indptr, e->s_indices, dZ, sin_, sout_, gW, gRW);
+                // round 6: in a step whose Adam is applied in this call (the output layer's already ran in its dW epilogue), this layer's gradient goes straight into
+                // launch_flipout_sweep below, which also clears the rows it reads: no memset of the two 46-MB buffers, a byte per skill row says which rows the scatter touched
+                l0_sweep_now = e->l0_sweep && e->cfg.bayesian && c.fuse_adam && e->adam_in_dw && !c.defer_dw && c.part == 0 && !e->ep && e->l0_touched &&
+                               (li.nw() & 3) == 0 && (li.out & 3) == 0;
+                if (!(l0_sweep_now && e->g0_clean)) {
+                    HIPCHK(e, hipMemsetAsync(gW, 0, (size_t)li.nw() * 4, e->st));
+                    if (gRW) HIPCHK(e, hipMemsetAsync(gRW, 0, (size_t)li.nw() * 4, e->st));
+                }
+                e->g0_clean = false; e->pre0_step = ~0ull;
+                if (l0_sweep_now) HIPCHK(e, hipMemsetAsync(e->l0_touched, 0, (size_t)li.in, e->st));
+                launch_multihot_bwd(e->st, c.rows_dev, B, li.in, li.out, e->s_indptr, e->s_indices, dZ, sin_, sout_, gW, gRW, l0_sweep_now ? e->l0_touched : nullptr);
             } else {
                 Scope t(e, last ? F_OUT_BWD_DW : F_GEMM_HIDDEN);
                 GemmArgs g;
@@ -1257,6 +1283,23 @@ backward:
         }
         if (e->cfg.bayesian) {
             Scope t(e, F_FLIPOUT_FINAL);
+            if (l == 0 && l0_sweep_now) {
+                // finalize + Adam + the next step's sigma * eps and KL term of the 90 671 x 128 pairs in ONE pass (was: k_flipout_grad_finalize here, the flat Adam behind
+                // the join, k_flipout_perturb at the head of the next step - 0.28 + 0.11 + 0.09 ms at config 3)
+                FlipoutSweep a;
+                a.mu = e->P + li.off[NTF_P_WEIGHT]; a.rho = e->P + li.off[NTF_P_RHO_WEIGHT]; a.g_mu = gW; a.g_rho = gRW;
+                a.m_mu = e->M1 + li.off[NTF_P_WEIGHT]; a.v_mu = e->V2 + li.off[NTF_P_WEIGHT]; a.m_rho = e->M1 + li.off[NTF_P_RHO_WEIGHT]; a.v_rho = e->V2 + li.off[NTF_P_RHO_WEIGHT];
+                a.n = li.nw(); a.eps = normal_spec(e, c, l, T_EPS_W); a.klw = kl_share / ((float)li.nw() * (float)c.global_B);
+                const double b1 = 0.9, b2 = 0.999, tt = (double)(e->adam_t + 1);
+                a.lr = e->lr; a.b1 = (float)b1; a.b2 = (float)b2; a.adam_eps = 1e-8f; a.bc1 = (float)(1.0 - std::pow(b1, tt)); a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, tt));
+                StepCtx nx; nx.step = c.step + 1;
+                const bool produce = e->pre_valid && e->pre_step == c.step + 1;      // (the dW epilogue produced the output layer's operands for that step: same protocol, same slot)
+                a.nx_eps = normal_spec(e, nx, l, T_EPS_W); a.nx_wp = e->Wp[l]; a.nx_klw = 1.0 / (double)li.nw(); a.nx_kl = produce ? e->d_kl + 2 : nullptr;
+                a.touched = e->l0_touched; a.H = li.out;
+                launch_flipout_sweep(e->st, a);
+                e->l0_swept = true; e->g0_clean = true;
+                if (produce) e->pre0_step = c.step + 1;
+            } else
             if (!(last && fused))  // the fused dW kernel finalises the output layer's weights in its epilogue
                 launch_flipout_grad_finalize(e->st, e->P + li.off[NTF_P_WEIGHT], e->P + li.off[NTF_P_RHO_WEIGHT], gW, gRW, li.nw(),
                                              normal_spec(e, c, l, T_EPS_W), kl_share / ((float)li.nw() * (float)c.global_B));
@@ -1308,9 +1351,16 @@ static int apply_adam(ntf_engine* e) {
     e->adam_in_dw = false;
     const LayerInfo& lo = e->layers[e->L - 1];
     const int64_t w0 = lo.off[NTF_P_WEIGHT], w1 = lo.off[NTF_P_BIAS];  // segments are laid out weight, bias, rho_weight, rho_bias
-    int64_t rg[6]; int fin[3] = {0, 0, 0}; int n = 0;
+    int64_t rg[12]; int fin[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+    if (e->l0_swept) {
+        // the first layer's weight / rho_weight segments were updated by launch_flipout_sweep: its bias (up to rho_weight), its rho_bias and the later hidden layers remain
+        const LayerInfo& l0 = e->layers[0];
+        rg[2 * n] = l0.off[NTF_P_BIAS]; rg[2 * n + 1] = l0.off[NTF_P_RHO_WEIGHT]; ++n;
+        rg[2 * n] = l0.off[NTF_P_RHO_BIAS]; rg[2 * n + 1] = e->L > 2 ? e->layers[1].off[NTF_P_WEIGHT] : w0; ++n;
+        if (e->L > 2) { rg[2 * n] = e->layers[1].off[NTF_P_WEIGHT]; rg[2 * n + 1] = w0; ++n; }
+    } else
     if (!e->hidden_adam_done) { rg[2 * n] = 0; rg[2 * n + 1] = w0; ++n; }      // (head prefetch: the hidden layers' Adam ran on the side stream, in front of the next batch's head)
-    e->hidden_adam_done = false;
+    e->hidden_adam_done = false; e->l0_swept = false;
     if (e->cfg.bayesian) { const int64_t r0 = lo.off[NTF_P_RHO_WEIGHT], r1 = lo.off[NTF_P_RHO_BIAS];
         // the live lo.out floats of the two bias segments, not their 256-byte padding: a finalised range would push the KL gradient into the padding of rho_bias
         // (p = 0, g = 0 there) and read an injected eps_b past its lo.out floats

@@ -48,8 +48,9 @@ void launch_gather_dense_rows(hipStream_t st, const float* X, int d, const int64
 // multi-hot input: layer 0 as a gather-sum of W columns / scatter-add of its gradient over the skill CSR (no dense X)
 void launch_multihot_fwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,
                          const float* W, const float* b, const float* Wp /*nullable*/, const float* bp, SignSpec sin, SignSpec sout, float* act);
+// touched (nullable): [S] bytes, set to 1 for every skill row the scatter adds to (the caller clears it first): launch_flipout_sweep then reads gradients of those rows only
 void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,
-                         const float* dZ, SignSpec sin, SignSpec sout, float* gW /*zeroed*/, float* gWp /*nullable, zeroed*/);
+                         const float* dZ, SignSpec sin, SignSpec sout, float* gW /*zeroed*/, float* gWp /*nullable, zeroed*/, uint8_t* touched = nullptr);
 
 // Wp = softplus(rho) * eps  (eps generated or injected)
 // also accumulates w * KL(N(mu, softplus(rho)^2) || N(0,1)) summed over the tensor into kl_out when mu != nullptr
@@ -111,6 +112,19 @@ void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2
                         double* rotate = nullptr,    // up to four ranges per launch; fin / rotate: see k_adam_ranges
                         float* nx_bp = nullptr, const NormalSpec* nx_eps = nullptr, double nx_klw = 0.0,   // with rotate: also the next step's output-bias operand + its KL (k_adam_ranges, nx)
                         const F32CopyJob* f32c = nullptr);
+// One sweep over a Flipout weight tensor (mu, rho) of a hidden layer in a step that applies Adam (the multi-hot first layer of BASELINE config 3: 90 671 x 128 pairs):
+// Flipout chain rule of the rho gradient + KL gradients (k_flipout_grad_finalize) -> Adam on mu and rho in place (k_adam) -> the NEXT step's operand sigma' eps'
+// and KL(mu', rho') * nx_klw added to *nx_kl (k_flipout_perturb) - the output layer's dW epilogue arithmetic for a layer whose gradient is a scatter.  The gradients
+// are CONSUMED: read and overwritten with zeros (the buffer is then ready for the next step's scatter, no memset); with `touched` (row flags of launch_multihot_bwd,
+// row = element / H) only the flagged rows are read and cleared - the others hold zeros by that invariant.  n and H multiples of 4.  52-60 B of HBM traffic per pair.
+struct FlipoutSweep {
+    float *mu, *rho, *g_mu, *g_rho, *m_mu, *v_mu, *m_rho, *v_rho; int64_t n;
+    NormalSpec eps; float klw;
+    float lr, b1, b2, adam_eps, bc1, bc2_sqrt;
+    NormalSpec nx_eps; float* nx_wp; double nx_klw; double* nx_kl;
+    const uint8_t* touched; int H;
+};
+void launch_flipout_sweep(hipStream_t st, const FlipoutSweep& a);
 void launch_fill(hipStream_t st, float* p, int64_t n, float v);
 // probabilities: out = (accumulate ? out : 0) + sigmoid(leaky(Z)) * scale ; ent_acc[i] += sum_c -p log(p+1e-15)
 void launch_sigmoid_acc(hipStream_t st, const float* Act, int64_t n_rows, int M, float scale, int accumulate, float* out,

@@ -225,11 +225,12 @@ void launch_multihot_fwd(hipStream_t st, const int64_t* rows, int B, int S, int 
 // gW/gWp zeroed by the caller.  Hardware f32 atomics: the per-element sums have at most (batch frequency of s) terms.
 __global__ void k_multihot_bwd(const int64_t* __restrict__ rows, int S, int H, const int64_t* __restrict__ indptr,
                                const int32_t* __restrict__ indices, const float* __restrict__ dZ, SignSpec sin, SignSpec sout,
-                               float* __restrict__ gW, float* __restrict__ gWp) {
+                               float* __restrict__ gW, float* __restrict__ gWp, uint8_t* __restrict__ touched) {
     const int i = blockIdx.x, h = blockIdx.y * blockDim.x + threadIdx.x;
     if (h >= H) return;
     const int64_t team = rows[i], p0 = indptr[team], p1 = indptr[team + 1];
     const float dz = dZ[(int64_t)i * H + h];
+    if (touched && h == 0) for (int64_t p = p0; p < p1; ++p) touched[indices[p]] = 1;
     if (gWp) {
         const float dzs = dz * sign_at(sout, i, h);
         for (int64_t p = p0; p < p1; ++p) { const int64_t s = indices[p]; unsafeAtomicAdd(gW + s * H + h, dz); unsafeAtomicAdd(gWp + s * H + h, dzs * sign_at(sin, i, s)); }
@@ -238,11 +239,11 @@ __global__ void k_multihot_bwd(const int64_t* __restrict__ rows, int S, int H, c
     }
 }
 void launch_multihot_bwd(hipStream_t st, const int64_t* rows, int B, int S, int H, const int64_t* indptr, const int32_t* indices,
-                         const float* dZ, SignSpec sin, SignSpec sout, float* gW, float* gWp) {
+                         const float* dZ, SignSpec sin, SignSpec sout, float* gW, float* gWp, uint8_t* touched) {
     if (B <= 0) return;
     const int bs = H >= 256 ? 256 : (H + 63) / 64 * 64;
     hipLaunchKernelGGL(k_multihot_bwd, dim3((unsigned)B, (unsigned)((H + bs - 1) / bs)), dim3(bs), 0, st, rows, S, H, indptr, indices, dZ, sin, sout,
-                       gW, gWp);
+                       gW, gWp, touched);
 }
 
 // =====================================================================================
@@ -876,6 +877,60 @@ void launch_adam_ranges(hipStream_t st, float* P, float* G, float* M1, float* V2
         launched = true;
     }
     if (!launched && rotate) launch_step_scalars(st, rotate, 1);
+}
+
+// ---- launch_flipout_sweep (ntf_kernels.h): finalize + Adam + next-step operand of one Flipout weight tensor in one pass
+// fin_rho on the hardware transcendentals, as the output layer's dW epilogue takes it (ntf_fused_dw.hip dw_finish_ops): sigma by the series below e = 2^-6, log(1 + e) above
+__device__ __forceinline__ void fin_rho_fast(float& g, float r, float z, float klw) {
+    const float e = __builtin_amdgcn_exp2f(fminf(r, 80.f) * 1.44269504f), t = 1.f + e;
+    const float sigma = e < 0.015625f ? e * (1.f - e * (0.5f - e * (0.33333333f - 0.25f * e))) : __builtin_amdgcn_logf(t) * 0.69314718f;
+    const float sg = e * __builtin_amdgcn_rcpf(t), isig = __builtin_amdgcn_rcpf(sigma);
+    g = g * z * sg + klw * (sigma - isig) * sg;
+}
+__global__ __launch_bounds__(256) void k_flipout_sweep(FlipoutSweep a, float lr_over_bc1) {
+    const int64_t quads = a.n >> 2;
+    float kl = 0.f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e0 = q * 4;
+        float4 pm = reinterpret_cast<float4*>(a.mu)[q], pr = reinterpret_cast<float4*>(a.rho)[q];
+        float4 m1 = reinterpret_cast<float4*>(a.m_mu)[q], v1 = reinterpret_cast<float4*>(a.v_mu)[q], m2 = reinterpret_cast<float4*>(a.m_rho)[q], v2 = reinterpret_cast<float4*>(a.v_rho)[q];
+        const bool t = a.touched ? a.touched[(uint64_t)e0 / (uint32_t)a.H] != 0 : true;      // (the quad lies in one row: H % 4 == 0)
+        float4 gm = zero4, gr = zero4;
+        if (t) {
+            gm = reinterpret_cast<float4*>(a.g_mu)[q]; gr = reinterpret_cast<float4*>(a.g_rho)[q];
+            reinterpret_cast<float4*>(a.g_mu)[q] = zero4; reinterpret_cast<float4*>(a.g_rho)[q] = zero4;
+        }
+        float z[4];
+        normal4(a.eps, q, e0, a.n, z);
+        fin_mu(gm.x, pm.x, a.klw); fin_mu(gm.y, pm.y, a.klw); fin_mu(gm.z, pm.z, a.klw); fin_mu(gm.w, pm.w, a.klw);
+        fin_rho_fast(gr.x, pr.x, z[0], a.klw); fin_rho_fast(gr.y, pr.y, z[1], a.klw); fin_rho_fast(gr.z, pr.z, z[2], a.klw); fin_rho_fast(gr.w, pr.w, z[3], a.klw);
+        adam_one(pm.x, gm.x, m1.x, v1.x, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt); adam_one(pm.y, gm.y, m1.y, v1.y, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt);
+        adam_one(pm.z, gm.z, m1.z, v1.z, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt); adam_one(pm.w, gm.w, m1.w, v1.w, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt);
+        adam_one(pr.x, gr.x, m2.x, v2.x, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt); adam_one(pr.y, gr.y, m2.y, v2.y, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt);
+        adam_one(pr.z, gr.z, m2.z, v2.z, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt); adam_one(pr.w, gr.w, m2.w, v2.w, lr_over_bc1, a.b1, a.b2, a.adam_eps, a.bc2_sqrt);
+        reinterpret_cast<float4*>(a.mu)[q] = pm; reinterpret_cast<float4*>(a.rho)[q] = pr;
+        reinterpret_cast<float4*>(a.m_mu)[q] = m1; reinterpret_cast<float4*>(a.v_mu)[q] = v1; reinterpret_cast<float4*>(a.m_rho)[q] = m2; reinterpret_cast<float4*>(a.v_rho)[q] = v2;
+        // the next step's operand from the updated parameters (k_flipout_perturb's arithmetic)
+        normal4(a.nx_eps, q, e0, a.n, z);
+        const float rv[4] = {pr.x, pr.y, pr.z, pr.w}, mv[4] = {pm.x, pm.y, pm.z, pm.w};
+        float ov[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float ls;
+            const float sigma = softplus_rho_fast(rv[j], ls);
+            ov[j] = sigma * z[j];
+            kl += -ls + 0.5f * (sigma * sigma + mv[j] * mv[j]) - 0.5f;
+        }
+        reinterpret_cast<float4*>(a.nx_wp)[q] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+    const double s = block_reduce_sum_d((double)kl);
+    if (threadIdx.x == 0 && a.nx_kl) atomicAdd(a.nx_kl, s * a.nx_klw);
+}
+void launch_flipout_sweep(hipStream_t st, const FlipoutSweep& a) {
+    if (a.n <= 0) return;
+    const int blocks = (int)std::min<int64_t>(((a.n >> 2) + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_flipout_sweep, dim3(blocks), dim3(256), 0, st, a, a.lr / a.bc1);
 }
 
 __global__ void k_fill(float* p, int64_t n, float v) {

@@ -61,6 +61,7 @@ SYMBOLS = {
     "ntf_range_fallbacks": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_prefetched_steps": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_head_prefetch_hits": (C.c_int, [_P, C.POINTER(_I64)]),
+    "ntf_first_layer_sweeps": (C.c_int, [_P, C.POINTER(_I64)]),
     "ntf_get_dlogits": (C.c_int, [_P, _P, _I64]),
     "ntf_get_negatives": (C.c_int, [_P, _P, _I64]),
     "ntf_fwd_ranges": (C.c_int, [_P, C.c_int32, _P, _P]),
@@ -308,6 +309,12 @@ class Engine:
         """steps whose sampler / gather / hidden layer had run beside the previous step's dW kernel (include/opentf_amd.h)"""
         n = C.c_int64()
         self._ck(lib().ntf_head_prefetch_hits(self._h, C.byref(n)))
+        return n.value
+
+    def first_layer_sweeps(self):
+        """steps that started on a multi-hot Flipout first-layer operand written by the previous step's one-pass finalize + Adam + producer (include/opentf_amd.h)"""
+        n = C.c_int64()
+        self._ck(lib().ntf_first_layer_sweeps(self._h, C.byref(n)))
         return n.value
 
     def dlogits(self, B):

@@ -26,7 +26,7 @@ def _dataset(rng, N, S, D, M, mean_s, mean_m):
     return (s_ip, s_ix), table, (m_ip, m_ix)
 
 
-def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, nsd="uniform"):
+def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, nsd="uniform", multihot=False):
     import torch
     from oracle import ntf_oracle as O
     from opentf_amd import libntf
@@ -36,7 +36,12 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
     skill, table, member = _dataset(rng, N, S, D, M, mean_s, mean_m)
     sd = O.bnn_init(D, [H], M)
     order = rng.permutation(N).astype(np.int64)
-    Xall = torch.from_numpy(O.gather_meanpool_fast(skill[0], skill[1], table))
+    if multihot:       # BASELINE config 3's input: the team's 0 / 1 skill row itself (src/mdl/ntf.py:23), D = S
+        assert D == S
+        Xn = np.zeros((N, S), np.float32); Xn[np.repeat(np.arange(N), np.diff(skill[0])), skill[1].astype(np.int64)] = 1.0
+        Xall = torch.from_numpy(Xn); del Xn
+    else:
+        Xall = torch.from_numpy(O.gather_meanpool_fast(skill[0], skill[1], table))
 
     def labels(rows):
         y = torch.zeros(len(rows), M)
@@ -46,8 +51,9 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
     def as_torch(noise):
         return [{k: torch.from_numpy(v) for k, v in n.items()} for n in noise]
 
-    e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd=nsd, tpw=10.0, tnw=1.0, lr=1e-3, seed=seed, fuse_adam=1)     # what bench.py and the plugin create: Adam in the dW epilogue, operands / head prefetched
-    e.set_skill_table(table); e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd)
+    e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd=nsd, tpw=10.0, tnw=1.0, lr=1e-3, seed=seed, fuse_adam=1)     # what bench.py and the plugin create: Adam in the dW epilogue, operands / head prefetched
+    if not multihot: e.set_skill_table(table)
+    e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd)
     if nsd == "unigram": e.set_unigram(np.bincount(member[1], minlength=M) / N)      # src/mdl/fnn.py:82
     e.stage_order(order)
 
@@ -66,7 +72,7 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
 
     # ---- three default train steps from the same step index, then their replay through the oracle
     e.set_seed(seed, t0)
-    pre0, hit0 = e.prefetched_steps(), e.head_prefetch_hits()
+    pre0, hit0, sw0 = e.prefetched_steps(), e.head_prefetch_hits(), e.first_layer_sweeps()
     losses, negs, noises = [], [], []
     for k in range(nsteps):
         losses.append(e.step_staged(k * B, B, train=True, apply=True, want_loss=True))
@@ -74,7 +80,11 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
         noises.append(e.noise(t0 + k, B))
     # the pipelined default path really ran: steps 2.. started on operands the previous dW epilogue produced, with the head that ran beside that kernel
     assert e.prefetched_steps() - pre0 >= nsteps - 1, (e.prefetched_steps(), pre0)
-    assert e.head_prefetch_hits() - hit0 >= nsteps - 1, (e.head_prefetch_hits(), hit0)
+    if multihot:      # (no one-kernel head for this input; instead: steps 2.. took their first-layer sigma * eps and KL term from the previous step's one-pass sweep)
+        import os
+        want = 0 if os.environ.get("NTF_L0_SWEEP") == "0" else nsteps - 1
+        assert e.first_layer_sweeps() - sw0 == want, (e.first_layer_sweeps(), sw0)
+    else: assert e.head_prefetch_hits() - hit0 >= nsteps - 1, (e.head_prefetch_hits(), hit0)
     st = e.state_dict(); e.close()
 
     sd_ref = {k: v.clone() for k, v in sd.items()}
@@ -107,6 +117,16 @@ def test_three_default_steps_replayed_through_the_oracle_at_config2_size():
 def test_three_default_steps_replayed_through_the_oracle_on_a_ragged_shape():
     """a ragged last expert tile (M = 70 001: one expert into a 32-expert sub-tile, a 128-expert half-tile and a 256-expert tile) under a ragged row block (B = 129)"""
     _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=22, t0=40)
+
+
+@pytest.mark.parametrize("sweep", ["1", "0"])
+def test_three_default_steps_replayed_through_the_oracle_on_multihot_input(sweep, monkeypatch):
+    """BASELINE config 3's first layer (round 6): multi-hot skill rows into a Flipout layer 0 whose gradient finalisation, Adam and next-step operand are ONE pass
+    (launch_flipout_sweep, beside the dW kernel) - the default; NTF_L0_SWEEP=0: the three-kernel chain of round 5.  Both against the oracle on the device's own draws:
+    a sweep whose next-step eps were keyed one step off, whose KL term landed in the wrong slot, or that cleared gradient rows the scatter had not flagged shows as a
+    loss or parameter mismatch at step 2 or 3.  S = 1 500 skills with 6 per team: most rows of the layer are NOT touched by a batch (their gradient is the KL term alone)."""
+    monkeypatch.setenv("NTF_L0_SWEEP", sweep)
+    _replay(D=1500, H=128, M=20_001, B=129, S=1500, mean_s=6.0, mean_m=2.5, seed=24, t0=9, multihot=True)
 
 
 @pytest.mark.parametrize("nsd", ["unigram_b", "unigram"])
