@@ -279,6 +279,17 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep, evt_steps=None, adam_in_d
     return (out[0] if out else None), (out[1] if len(out) > 1 else None)
 
 
+def validation_step(ev, a, bayesian, eB, H, M):
+    """the evaluation step against the MFMA roof: one (Fnn) or two (Flipout) [rows, H] x [H, experts] products, forward only"""
+    if not ev: return None
+    flop = (2 if bayesian else 1) * 2.0 * eB * H * M
+    split = a.mfma != "f32" and not a.no_fused and a.hidden == 128
+    peak = BF16_MFMA_PEAK_TFLOPS / (6 if a.mfma == "bf16x6" else 3) if split else F32_MFMA_PEAK_TFLOPS
+    t = ev["ms_per_step"] * 1e-3
+    return {**ev, "flop_per_step": flop, "tflops": flop / t / 1e12, "mfma_peak": peak, "mfma_frac": flop / t / 1e12 / peak,
+            "note": "whole evaluation step (operand producer, head, forward + loss kernel, fix-up), timed over an eval_epoch call; kernel: k_out_fwd_h3e unless NTF_EVAL_KERNEL=0"}
+
+
 def step_roofline(a, bayesian, head, ds, multihot, step_s):
     """The WHOLE step against both roofs (the per-kernel `roofline` objects leave out what sits between the kernels): SURVEY 8d's algorithmic FLOPs per team
     (Bnn 12 H M + 8 D H, Fnn 6 (D H + H M); D = the dense input width, the multi-hot first layer counted as its gather: 2 nnz H per product) x the rows one
@@ -433,7 +444,14 @@ def main():
                 for fam in ("out_fused_fwd_loss_dh", "out_fused_dw_adam", "out_fwd_gemm", "out_bwd_dw_gemm"):      # a run of ONE timed region saw one of the two kernels only
                     if fam not in times and fam in full and full[fam][1] > 0: times[fam] = full[fam]; evt_steps[fam] = k3
             dt = float(np.median(regions))
-            res = {"par": par, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "region_losses": losses, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
+            # the validation phase's step (src/mdl/fnn.py:143-151: forward + loss on fresh eps, no backward): 566 of a fold-epoch's 1 697 batches at config 2
+            ev = None
+            if breakdown and world == 1 and not a.ep_emulate and not a.dp_emulate:
+                kev = max(10, min(40, steps))
+                dp.eval_epoch(order[: 3 * gB], gB); e.synchronize()
+                t0 = time.perf_counter(); ev_loss = dp.eval_epoch(order[: kev * gB], gB); e.synchronize()
+                ev = {"ms_per_step": (time.perf_counter() - t0) / kev * 1e3, "steps": kev, "mean_loss": ev_loss}
+            res = {"par": par, "eval": ev, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "region_losses": losses, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
                    "Mloc": (shard[1] - shard[0]) if ep else model_dims[-1], "engine": e,
                    "rccl_payload_bytes_per_step": (4 * gB * a.hidden) if ep else (8 * n_params if world > 1 else 0),
                    "emulated_bytes": getattr(dp, "emulated_bytes", None)}
@@ -512,6 +530,7 @@ def main():
             "config": {"workload": workload_label(a, ds, bayesian, multihot), "global_batch": gB,
                        "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else
                                        f"dp{world}" + (": rows split over the GPUs, gradients reduce-scattered / parameters all-gathered over RCCL, Adam on the owned 1/N shard" if world > 1 else ""))},
+            "validation_step": validation_step(head.get("eval"), a, bayesian, head["eB"], H, head["Mloc"]),
             "roofline": roof, "roofline_other": roof_other, "step_roofline": step_roofline(a, bayesian, head, ds, multihot, dt / a.steps), "cpu_baseline": state["cpu_baseline"], "exact_f32_mfma": state["exact_f32"], "mean_loss": head["mean_loss"],
             "mean_loss_finite_in_every_timed_region": state["loss_finite"],
             "kernel_ms_per_step": head["breakdown"], "kernel_ms_note": "separate pass of %d steps with events around every kernel family (side-stream families overlap the big kernels: the column does not sum to the step); the timed region carries events around the two output-layer kernels only" % head["k3"],

@@ -132,6 +132,10 @@ struct ntf_engine {
     // step's sigma * eps and KL in one pass, on the side stream beside the dW kernel.  pre0_step: the step whose Wp[0] / KL the last sweep produced (used iff that step also
     // starts on the output layer's prefetched operands: one validity protocol, pre_valid / pre_step); l0_swept: this step's Adam of the layer's weights ran in the sweep
     // (apply_adam leaves them out); g0_clean: the layer's gradient rows are all zero (the sweep clears what it reads: no memset in front of the scatter)
+    int eval_kernel = 1;              // NTF_EVAL_KERNEL=0 (A/B runs, tests): evaluation steps on k_out_fwd_b6 as in round 5 instead of k_out_fwd_h3e
+    int fnn_pipe = 1;                 // NTF_FNN_PIPE=0 (A/B runs): the non-Bayesian step as in round 5 - mu planes split at the head of every step (k_split_planes), hidden backward
+                                      // on the main stream, no head prefetch.  1 (round 6): the dW + Adam epilogue writes the NEXT step's planes of mu (FusedDw.produce without the
+                                      // Flipout half), the hidden backward and the next batch's head run on the side stream beside the dW kernel - the Bnn step's pipeline
     int l0_sweep = 1;                 // NTF_L0_SWEEP=0: k_flipout_grad_finalize + the flat Adam + the stand-alone producer, as in round 5 (A/B runs)
     bool l0_swept = false, g0_clean = false, use_pre0 = false; uint64_t pre0_step = ~0ull; uint8_t* l0_touched = nullptr; int64_t pre0_used = 0;
     int64_t pre_used = 0;             // steps that started on prefetched operands (diagnostics / tests)
@@ -261,6 +265,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* hd = getenv("NTF_HEAD")) e->head = atoi(hd);
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
     if (const char* sw = getenv("NTF_L0_SWEEP")) e->l0_sweep = atoi(sw);
+    if (const char* fp = getenv("NTF_FNN_PIPE")) e->fnn_pipe = atoi(fp);
+    if (const char* ek = getenv("NTF_EVAL_KERNEL")) e->eval_kernel = atoi(ek);
     if (const char* fc = getenv("NTF_F32_COPY_MERGED")) e->f32_copy_merged = atoi(fc);
     if (const char* eh = getenv("NTF_EP_HEAD_PREFETCH")) e->ep_head_prefetch = atoi(eh);
     if (const char* dr = getenv("NTF_DP_RANGES")) e->dp_ranges = atoi(dr);
@@ -908,8 +914,10 @@ static int prefetch_next_head(ntf_engine* e, const StepCtx& c, hipStream_t head_
         if ((r = set_batch_unigram(e, e->hp_next_host, n.B, ub_next, e->st4))) return r;
     }
     if ((r = sample_negatives(e, n))) return r;
-    const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
-    { Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1); }
+    if (e->cfg.bayesian) {
+        const SignSpec so = sign_spec(e, n, e->L - 1, T_S_OUT, lo.out);
+        Scope t(e, F_OUT_FUSED_AUX); launch_fused_prep_planes(e->st, n.B, lo.in, M, 1, ws_next, 2, kH16Scale, &so, 0, 1);
+    }
     HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
     e->st = head_st;
     { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr); }
@@ -919,6 +927,7 @@ static int prefetch_next_head(ntf_engine* e, const StepCtx& c, hipStream_t head_
 static bool head_prefetch_possible(const ntf_engine* e, const StepCtx& c, int B) {
     const bool can_head = e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
                           (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
+    if (!e->cfg.bayesian && !e->fnn_pipe) return false;
     return e->head_prefetch && can_head && c.fuse_adam && e->cfg.fuse_adam == 1 && e->pre_valid && e->pre_step == c.step + 1 && e->hp_next_B > 0 && !c.inj &&
            (e->cfg.nsd != NTF_NSD_UNIGRAM_B || e->hp_next_host != nullptr) && c.global_B == B;
 }
@@ -938,7 +947,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                           (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
     // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
     // (round 5: also of a deferred-dW step - a data-parallel rank's - whose dW chunks the host launches right behind this call: the join then waits behind the last chunk, join_side)
-    const bool side = fused && e->cfg.bayesian && e->L > 1 && c.train && c.part == 0 && (!c.defer_dw || e->dp_side_bwd) && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);   // (Fnn: the chain is too short to pay)
+    // (Fnn: the chain alone is too short to pay - it goes to the side stream when the next batch's head follows it there, round 6)
+    const bool fnn_side = !e->cfg.bayesian && e->fnn_pipe && e->prefetch && e->head_prefetch && c.fuse_adam && e->cfg.fuse_adam == 1 && !c.inj && !e->ep && use_head && c.global_B == B &&
+                          e->hp_next_B > 0 && (e->cfg.nsd != NTF_NSD_UNIGRAM_B || e->hp_next_host != nullptr) && range_ptr(e) && e->pl_mu && lo.in == 128;
+    const bool side = fused && (e->cfg.bayesian || fnn_side) && e->L > 1 && c.train && c.part == 0 && (!c.defer_dw || e->dp_side_bwd) && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);
     bool hp_hit = false, hp_stale = false;
     bool chain_ok = false, chain_lean = false, chain_fill = false; PerturbChain pch;
     FwdRange fr[4]; int fr_tot = 0;
@@ -948,8 +960,8 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     // the Flipout operand producers add each layer's KL to d_kl[0]; the 4 bytes behind it are this step's fp16x3 range flag
     {
         const bool pre0 = e->pre0_step == c.step;      // the previous step's launch_flipout_sweep left this step's first-layer operand and KL term (multi-hot Flipout layer 0)
-        const bool pre_ok = fused && e->cfg.bayesian && e->pre_valid && e->pre_step == c.step && e->pl_wp != nullptr &&
-                            !(c.inj && c.inj->eps_w[e->L - 1]) &&   // (an injected eps: the operands are made from it in this step)
+        const bool pre_ok = fused && e->pre_valid && e->pre_step == c.step && (e->cfg.bayesian ? e->pl_wp != nullptr : e->pl_mu != nullptr) &&      // (Fnn, round 6: the planes of mu alone)
+                            !(c.inj && e->cfg.bayesian && c.inj->eps_w[e->L - 1]) &&   // (an injected eps: the operands are made from it in this step)
                             !(pre0 && c.inj);                       // (likewise the first layer's: its KL term sits in the prefetched sum - the step starts from scratch)
         e->pre_valid = false;   // consumed, or stale
         use_pre = pre_ok;
@@ -971,7 +983,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     if (chain_fill) HIPCHK(e, hipMemsetAsync(e->d_chain, 0, 16, e->st));
     if (chain_fill) { pch.kl_out2 = e->d_chain; pch.mu_flag_out = reinterpret_cast<int*>(e->d_chain + 1); e->chain_valid = true; }
     if (chain_lean) pch.raise_if = reinterpret_cast<const int*>(e->d_chain + 1);
-    if (e->cfg.bayesian) { if (!(use_pre && e->pre_rotated)) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0, chain_lean ? e->d_chain : nullptr); }
+    if (e->cfg.bayesian || (range_ptr(e) && e->fnn_pipe)) { if (!(use_pre && e->pre_rotated)) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0, chain_lean ? e->d_chain : nullptr); }
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
     e->pre_rotated = false;
     if (fused && e->side_bwd && !hp_hit) {
@@ -1036,10 +1048,12 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
             f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
         }
+        if (!e->cfg.bayesian && use_pre) f.planes_ready = 1;      // (Fnn, round 6: the previous step's dW epilogue wrote the planes of the updated mu)
         f.bf16x6 = e->pl_mu != nullptr; f.mu_pl = e->pl_mu; f.wp_pl = e->pl_wp;
         f.np = mfma_np(e); f.w_scale = kW16Scale; f.h_scale = kH16Scale; f.dz_scale = dz_scale16(e, c.global_B);
         f.rflag = range_ptr(e);
         if (e->fwd_kernel >= 0) f.wide = e->fwd_kernel;   // A/B runs: NTF_FWD_KERNEL = 0, 1, 2 (ntf_fused.h), read when the engine is created
+        f.eval_kernel = e->eval_kernel;
         f.rows = c.rows_dev; f.m_indptr = e->m_indptr; f.m_indices = e->m_indices; f.neg = neg; f.ns = e->cfg.ns; f.row_fix = e->row_fix;
         f.c_lo = e->ep_lo;
         if (use_head) {
@@ -1065,7 +1079,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
-        if (use_pre && e->lean && !(hp_hit && e->f32_copy_step == c.step + 1)) {      // (f32_copy_step: the previous step's Adam launch carried this job - good only if the head that
+        if (use_pre && e->cfg.bayesian && e->lean && !(hp_hit && e->f32_copy_step == c.step + 1)) {      // (f32_copy_step: the previous step's Adam launch carried this job - good only if the head that
                                                                                       // ran beside that step IS this batch's: a head redone here may raise the flag anew)
             // this step's operands came from the previous step's dW epilogue, which (lean) left no f32 copy of sigma * eps: only a step that falls back to the exact-f32 kernels
             // reads one, and makes it here - a capped grid that exits at once unless the range flag is raised (behind the head: k_head may still raise it)
@@ -1224,6 +1238,11 @@ backward:
                     f.nx_klw = 1.0 / out_nw; f.nx_kl = e->d_kl + 2; f.nx_rflag = e->d_range + 4;
                     e->pre_valid = true; e->pre_step = c.step + 1;
                 }
+                if (e->prefetch && e->fnn_pipe && !e->cfg.bayesian && f.dz_packed && e->pl_mu && range_ptr(e)) {
+                    // Fnn: the epilogue's updated mu goes out as the next step's fp16 planes too (no eps, no KL: the range flag of the planes is all that travels with them)
+                    f.produce = 1; f.nx_pl_mu = e->pl_mu; f.nx_pl_wp = nullptr; f.nx_pscale = kW16Scale; f.nx_kl = e->d_kl + 2; f.nx_rflag = e->d_range + 4;
+                    e->pre_valid = true; e->pre_step = c.step + 1;
+                }
                 if (e->cfg.bayesian) { e->fin_pend = true; e->fin_eps = normal_spec(e, c, l, T_EPS_B); e->fin_klw = kl_share / ((float)out_nb * (float)c.global_B); }
             }
 #ifdef NTF_DIAG
@@ -1367,10 +1386,10 @@ static int apply_adam(ntf_engine* e) {
         (void)r0;
         rg[2 * n] = w1; rg[2 * n + 1] = w1 + lo.out; fin[n] = e->fin_pend ? 1 : 0; ++n; rg[2 * n] = r1; rg[2 * n + 1] = r1 + lo.out; fin[n] = e->fin_pend ? 2 : 0; ++n; }
     else { rg[2 * n] = w1; rg[2 * n + 1] = w1 + lo.out; ++n; }
-    const bool rotate = e->cfg.bayesian && e->pre_valid && e->pre_step == e->step;   // this step's dW epilogue left the next step's KL / range flag behind the current ones
+    const bool rotate = (e->cfg.bayesian || e->fnn_pipe) && e->pre_valid && e->pre_step == e->step;   // this step's dW epilogue left the next step's KL / range flag behind the current ones
     // the prefetched head of the next step left out what depends on the output layer's biases, which this launch updates: their Flipout operand sigma_b eps_b and KL of
     // the next step.  Round 5: produced by this very launch from the updated values it holds (round 4: k_head's bias workgroups alone in a launch behind it)
-    const bool bias_nx = e->hp.valid && rotate && e->hp.step == e->step && e->merge_bias;
+    const bool bias_nx = e->cfg.bayesian && e->hp.valid && rotate && e->hp.step == e->step && e->merge_bias;
     NormalSpec nx_eps;
     if (bias_nx) { StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B; nx_eps = normal_spec(e, nx, e->L - 1, T_EPS_B); }
 #ifdef NTF_DIAG
@@ -1389,7 +1408,7 @@ static int apply_adam(ntf_engine* e) {
     launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, n, e->lr, (float)b1, (float)b2, 1e-8f, (float)bc1, (float)std::sqrt(bc2), fin, &e->fin_eps, e->fin_klw,
                        rotate ? e->d_kl : nullptr, bias_nx ? e->bp[e->L - 1] : nullptr, bias_nx ? &nx_eps : nullptr, 1.0 / (double)e->Mg, with_copy ? &f32c : nullptr);
     e->pre_rotated = rotate; e->fin_pend = false;
-    if (e->hp.valid && rotate && e->hp.step == e->step && !bias_nx) {
+    if (e->cfg.bayesian && e->hp.valid && rotate && e->hp.step == e->step && !bias_nx) {
         StepCtx nx; nx.step = e->hp.step; nx.B = e->hp.B; nx.global_B = e->hp.B; nx.rows_dev = e->hp.rows; nx.train = true;
         Scope t2(e, F_FLIPOUT_OPERAND);
         head_launch(e, e->st, nx, e->fws_set[nx.step & 1], false, e->d_kl, true, nullptr, false);

@@ -29,6 +29,7 @@ struct FusedOut {
     int wide = 5;                                   // np = 2 training step: 5 (default, round 4) k_out_fwd_h3p - a logit wave and a gradient wave per 32 rows, two waves per SIMD, 32-expert steps;
                                                     // 3 k_out_fwd_h3x - one wave per SIMD, 64-expert tiles, phases rotated across tiles (round 3's default); 0 the 32-expert-tile kernel
                                                     // k_out_fwd_b6.  NTF_FWD_KERNEL selects the A/B forms (round 3's sixteen-row-wave form, 4, was retired in round 5)
+    int eval_kernel = 1;                            // np = 2 evaluation loss: 1 (default, round 6) k_out_fwd_h3e - eight logit waves on 256 rows, the two waves of a SIMD half a step apart; 0 k_out_fwd_b6
     int ncg_limit = 0;                              // > 0 (diagnostics, NTF_COSCHED): at most this many column groups, i.e. a forward grid of NRB * ncg_limit workgroups that leaves CUs free
     int split_fallback = 0;                         // the exact-f32 forward launch behind the split-product kernel is NOT part of phase 2 but a phase of its own (8)
     // the split-product forward over a RANGE of the experts (k_out_fwd_h3p only; data-parallel ranks launch one range per all-gathered parameter chunk): 64-expert tiles

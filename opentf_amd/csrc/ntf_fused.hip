@@ -1556,6 +1556,187 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_out_fwd_h3e (round 6): the fp16x3 forward-ONLY pass for the loss of an evaluation step (the validation phase of src/mdl/fnn.py:143-151: 566 of a fold-epoch's 1 697
+// batches at config 2) as EIGHT logit waves of k_out_fwd_h3p - no gradient wave, no hand-over, no dz.  A workgroup owns 256 batch rows (32 per wave) and walks a column
+// group of 32-expert sub-tiles through the same three-stage LDS ring (2 matrices x 2 planes x [32 rows][256 B] + biases, filled by LDS-DMA one step ahead: waves 0-3
+// the first matrix and the biases, waves 4-7 the second).  The two waves of a SIMD are STAGGERED by half a step: waves 0-3 run [zT MFMAs of s, logits of s], waves 4-7
+// [logits of s - 1, zT MFMAs of s] - one barrier a step, matrix work of one beside vector work of the other (the pairing the training kernel has by its roles; two
+// workgroups of k_out_fwd_b6 per CU get it only by accident of their phases: 0.40 ms a launch against this kernel's figure in profiles/r6_eval_ab.md).  The late waves'
+// logits read their accumulators before the MFMAs of the same step overwrite them and the biases of stage s - 1, which the DMA of step s (stage s + 1) does not touch.
+// Sub-tile order, products per accumulator and the logit arithmetic are wave A's: per row the loss is the same sum of the same terms in another order.
+// ------------------------------------------------------------------------------------------------
+template <bool BAYES, bool INJ>
+__global__ __launch_bounds__(512) void k_out_fwd_h3e(OutFwd6Args pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const OutFwdArgs& p = pp.a;
+    constexpr int H = 128, NJT = 4, NKS = H / 16, SUB = 32;
+    constexpr int PLANE = SUB * H * 2, TM = 2 * PLANE, NMAT = BAYES ? 2 : 1, SLOT = NMAT * TM + 512;
+    const int tid = threadIdx.x, lane = tid & 63, il = lane & 31, half = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave_u & 3, late = wave_u >> 2;
+    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) return;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int cg = bid / p.NRB, rb = bid % p.NRB;      // (NRB: 256-row blocks here)
+    const int tspan = p.t_hi - p.t_lo;
+    const int s_beg = 2 * (p.t_lo + (int)((int64_t)cg * tspan / p.NCG)), s_end = 2 * (p.t_lo + (int)((int64_t)(cg + 1) * tspan / p.NCG));
+    const int i0 = rb * 256 + wave_u * 32, i = i0 + il;
+    const bool row_ok = i < p.B, row_in = i < p.Bpad;      // (the zero-padded h and the loss partials have Bpad rows, a multiple of 128)
+    const uint32_t smem_base = lds_addr(smem);
+    typedef const __attribute__((address_space(3))) char* ldsp_t;
+    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
+    auto sign_w = [&](int s) -> uint32_t {
+        if (!BAYES || !row_ok) return 0u;
+        const uint32_t w = INJ ? p.sbits[(int64_t)i * p.nCB + s] : sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)s);
+        return w >> (4 * half);
+    };
+    auto mask_past_m = [&](int s) {      // (workgroup-uniform) experts past M: l = -20 through the bias
+        if (32 * s + SUB > p.M) {
+            if (tid < SUB && 32 * s + tid >= p.M) reinterpret_cast<float*>(smem + (s % 3) * SLOT + NMAT * TM)[tid] = -2000.f;
+            __syncthreads();
+        }
+    };
+    u32x4 hp[NKS][2], hs[NKS][2];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (row_in) { v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half); v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4); }
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const uint32_t sw_in = BAYES ? (INJ ? (row_in ? p.sinbits[(int64_t)i * NJT + (s >> 1)] : 0u) : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)(s >> 1)) : 0u)) : 0u;
+        const uint32_t w8 = sw_in >> (16 * (s & 1) + 8 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t pq[3];
+            split_pair_np<2>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
+            const uint32_t hm = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
+            hp[s][0][q] = pq[0]; hp[s][1][q] = pq[1];
+            hs[s][0][q] = pq[0] ^ hm; hs[s][1][q] = pq[1] ^ hm;
+        }
+    }
+    // DMA: 16 one-KiB pieces per matrix image: waves 0-3 take the first matrix (4 each) and the bias piece, waves 4-7 the second matrix
+    constexpr int PER_WAVE = TM / 1024 / 4;
+    uint32_t dsrc[PER_WAVE];
+#pragma unroll
+    for (int n = 0; n < PER_WAVE; ++n) {
+        const int pos = (pair * PER_WAVE + n) * 1024 + lane * 16;
+        const int plane = pos / PLANE, row = (pos >> 8) & 31, chp = (pos >> 4) & 15;
+        dsrc[n] = (uint32_t)(((plane * 32 + row) * 256) + 16 * (chp ^ (((row & 3) << 2) | ((row >> 2) & 3))));
+    }
+    constexpr int NPIECE = PER_WAVE + 1;
+    auto stage_piece = [&](int s, int slot, int n) {      // piece n of this wave's share of sub-tile s into ring slot `slot`
+        const uint32_t sb = smem_base + slot * SLOT;
+        if (n < PER_WAVE) {
+            if (late && !BAYES) return;
+            const char* base = reinterpret_cast<const char*>(late ? pp.wp_pl : pp.mu_pl) + (size_t)s * TM;
+            glds16s(base, dsrc[n], sb + late * TM + (pair * PER_WAVE + n) * 1024);
+        } else if (!late) {
+            const int which = BAYES ? (pair & 1) : 0;
+            glds4((which ? p.bp : p.mu_b) + min(32 * s + il, p.M - 1), sb + NMAT * TM + which * 256);
+        }
+    };
+    if (s_beg < s_end) {
+#pragma unroll
+        for (int n = 0; n < NPIECE; ++n) stage_piece(s_beg, s_beg % 3, n);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int zrow[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) zrow[s] = 256 * il + 16 * ((2 * s + half) ^ fil);
+    LossAcc lacc;
+    const float rmask = row_ok ? 1.f : 0.f;
+    constexpr int NHG = NKS * NMAT, BG = 2, NB = NHG / BG;
+    f32x16 X1, X2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { X1[r] = 0.f; X2[r] = 0.f; }
+    uint32_t sw_cur = 0u;       // s_out signs of the sub-tile whose products X1 / X2 hold
+    auto products = [&](int s) {
+        const uint32_t sbase = smem_base + (s % 3) * SLOT;
+        ldsp_t zb[NKS];
+#pragma unroll
+        for (int k = 0; k < NKS; ++k) zb[k] = (ldsp_t)(size_t)(sbase + zrow[k]);
+        u32x4 fb[2][BG][2];
+        auto z_load = [&](int hg, u32x4 (&fr)[2]) {
+            const int k = hg / NMAT, mat = hg % NMAT;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) fr[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(zb[k] + (mat * TM + q * PLANE));
+        };
+        auto z_mma = [&](int hg, const u32x4 (&fr)[2]) {
+            const int k = hg / NMAT, mat = hg % NMAT;
+            f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            f32x16 acc = mat == 0 ? (k == 0 ? zero : X1) : (k == 0 ? zero : X2);
+            const u32x4 (&b)[2] = mat == 0 ? hp[k] : hs[k];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(fr[1]), as_frag_h(b[0]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(fr[0]), as_frag_h(b[1]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag_h(fr[0]), as_frag_h(b[0]), acc, 0, 0, 0);
+            if (mat == 0) X1 = acc; else X2 = acc;
+        };
+#pragma unroll
+        for (int k = 0; k < BG; ++k) z_load(k, fb[0][k]);
+        const int sn = min(s + 1, s_end - 1);
+#pragma unroll
+        for (int lb = 0; lb < NB; ++lb) {
+            if (lb + 1 < NB) {
+#pragma unroll
+                for (int k = 0; k < BG; ++k) z_load((lb + 1) * BG + k, fb[(lb + 1) & 1][k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < BG; ++k) {
+                const int hg = lb * BG + k;
+                z_mma(hg, fb[lb & 1][k]);
+                if (hg < NPIECE) stage_piece(sn, (s + 1) % 3, hg);
+            }
+        }
+        sw_cur = sign_w(s);
+    };
+    auto logits = [&](int s) {      // softplus(leaky_relu(z)) of the 32 x 32 logits in X1 / X2 (sub-tile s) into the row's loss
+        const char* sb = smem + (s % 3) * SLOT;
+        const uint32_t swu = sw_cur;
+        float bm[16], bq[16];
+        const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half;
+        const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 m = *reinterpret_cast<const float4*>(bias_mu + 8 * j);
+            bm[4 * j] = m.x; bm[4 * j + 1] = m.y; bm[4 * j + 2] = m.z; bm[4 * j + 3] = m.w;
+            if (BAYES) { const float4 q = *reinterpret_cast<const float4*>(bias_p + 8 * j); bq[4 * j] = q.x; bq[4 * j + 1] = q.y; bq[4 * j + 2] = q.z; bq[4 * j + 3] = q.w; }
+        }
+        float lt = 0.f;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            float l[4], tt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * j4 + j, cr = (r & 3) + 8 * (r >> 2);
+                float z = fmaf(X1[r], pp.u_z, bm[r]);
+                if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[r], pp.u_z, bq[r])) ^ ((swu << (31 - cr)) & 0x80000000u));
+                l[j] = fmaxf(z > 0.f ? z : z * kLeakySlope, -21.f);      // (the clamp: see k_out_fwd_h3p - the product of four 1 + e^-l must stay finite)
+                tt[j] = 1.f + __builtin_amdgcn_exp2f(l[j] * -1.4426950408889634f);
+            }
+            lt += fmaf(__builtin_amdgcn_logf((tt[0] * tt[1]) * (tt[2] * tt[3])), 0.6931471805599453f, (l[0] + l[1]) + (l[2] + l[3]));
+        }
+        lacc.tile = lt * rmask; lacc.end_tile();
+    };
+    for (int s = s_beg; s <= s_end; ++s) {
+        if (s < s_end) mask_past_m(s);
+        if (!late) {
+            if (s < s_end) { products(s); logits(s); }
+        } else {
+            if (s > s_beg) logits(s - 1);
+            if (s < s_end) products(s);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float lsum = lacc.sum;
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (half == 0 && row_in) p.lossp[(int64_t)i * p.ncg_tot + p.cg_off + cg] = p.tnw * lsum;
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int H, bool BAYES>
 static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a, const SpecialArgs& s, int grid, int phases) {
     constexpr int STAGE = (BAYES ? 2 : 1) * BN * 4 * H + 512;
@@ -1580,6 +1761,10 @@ static void fwd_dispatch(hipStream_t st, const FusedOut& f, const OutFwdArgs& a,
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     Geom g = geom(f.B, f.M);
     if (!f.train && f.H == 128) g.NCG = eval_ncg(g);      // forward-only launches: two workgroups per CU (k_out_fwd_b6)
+    // the loss of an evaluation step in fp16x3 (round 6): k_out_fwd_h3e - 256-row workgroups of eight logit waves, one per CU.  NTF_EVAL_KERNEL=0: k_out_fwd_b6 (A/B runs, tests)
+    const bool evalp = f.eval_kernel && !f.train && !f.probs && f.bf16x6 && f.H == 128 && f.np == 2 && f.chunk_ncg_tot == 0;
+    const int nrbe = (g.Bpad + 255) / 256;
+    if (evalp) g.NCG = std::max(1, std::min({NCG_MAX / nrbe, g.T, NCG_MAX}));
     if (f.ncg_limit > 0) g.NCG = std::max(1, std::min(g.NCG, f.ncg_limit));
     const WsLayout w = ws_layout(f.B, f.H, f.M);
     char* ws = static_cast<char*>(f.ws);
@@ -1636,6 +1821,15 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_L6(BY, TR, DHF, IJ, PR) do { if (np == 2) NTF_L6N(BY, TR, DHF, IJ, PR, 2); else NTF_L6N(BY, TR, DHF, IJ, PR, 3); } while (0)
 #define NTF_L6B(BY, IJ) do { if (f.probs) NTF_L6(BY, false, false, IJ, true); else if (!f.train) NTF_L6(BY, false, false, IJ, false);  \
                              else if (dh) NTF_L6(BY, true, true, IJ, false); else NTF_L6(BY, true, false, IJ, false); } while (0)
+            if (evalp) {
+                const size_t ldse = 3 * ((size_t)(f.bayes ? 2 : 1) * 2 * 32 * 128 * 2 + 512);
+                OutFwd6Args ae = a6; ae.a.NRB = nrbe;
+#define NTF_LE(BY, IJ) do { auto kf = k_out_fwd_h3e<BY, IJ>;                                                                    \
+                set_max_lds(reinterpret_cast<const void*>(kf), (int)ldse);  \
+                hipLaunchKernelGGL(kf, dim3(nrbe * g.NCG), dim3(512), ldse, st, ae); } while (0)
+                if (f.bayes) { if (inj) NTF_LE(true, true); else NTF_LE(true, false); } else NTF_LE(false, false);
+#undef NTF_LE
+            } else
             if (np == 2 && f.train && dh && f.wide) {    // the fp16x3 training step: 64-expert tiles (a.T counts them already)
                 const size_t ldsw = 2 * ((size_t)(f.bayes ? 2 : 1) * 2 * 64 * 128 * 2 + 512);
 #define NTF_LXA(BY, IJ, AB) do { auto kf = k_out_fwd_h3x<BY, IJ, AB>;                                                                    \

@@ -81,9 +81,18 @@ __device__ __forceinline__ void dw_produce_next(const DwArgs& p, int64_t idx0, c
     planes_store_quad<2>(p.nx_pl_wp, row, j, 128, ov[0], ov[1], ov[2], ov[3], p.nx_pscale);
     planes_store_quad<2>(p.nx_pl_mu, row, j, 128, mu4[0], mu4[1], mu4[2], mu4[3], p.nx_pscale);
 }
+// Fnn (round 6): no Flipout operand - the next step's operand is the fp16 planes of the UPDATED mu alone (k_split_planes made them in a pass of its own over the layer at
+// the head of every step: 4 B read + 4 B written per weight on the way to the forward kernel)
+__device__ __forceinline__ void dw_produce_next_fnn(const DwArgs& p, int64_t idx0, const float (&mu4)[4], float& amax) {
+    const int64_t row = idx0 >> 7; const int j = (int)(idx0 & 127);      // H = 128
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(mu4[0]), fabsf(mu4[1])), fmaxf(fabsf(mu4[2]), fabsf(mu4[3]))));
+    planes_store_quad<2>(p.nx_pl_mu, row, j, 128, mu4[0], mu4[1], mu4[2], mu4[3], p.nx_pscale);
+}
 // ... and once per workgroup: the KL' sum (one double atomic, as the stand-alone producer) and the range flag.  red = 8-byte-aligned LDS scratch of >= nwaves doubles
+template <bool BAYES = true>
 __device__ __forceinline__ void dw_produce_finish(const DwArgs& p, float kl, float amax, double* red, int nwaves) {
     if (!(amax * p.nx_pscale <= 65504.f)) *p.nx_rflag = 1;
+    if (!BAYES) return;
     const double s = wave_reduce_sum_d((double)kl);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -235,10 +244,10 @@ __device__ __forceinline__ void out_dw_f32_body(const DwArgs& p, char* smem) {  
                     p.m_rho[idx0 + jt] = m2; p.v_rho[idx0 + jt] = v2;
                 }
             }
-            if constexpr (BAYES && H == 128) { if (p.produce) dw_produce_next(p, idx0, nmu, nrho, nx_kl, nx_amax); }   // (this kernel as the fp16x3 step's range fallback)
+            if constexpr (H == 128) { if (p.produce) { if constexpr (BAYES) dw_produce_next(p, idx0, nmu, nrho, nx_kl, nx_amax); else dw_produce_next_fnn(p, idx0, nmu, nx_amax); } }   // (this kernel as the fp16x3 step's range fallback)
         }
     }
-    if constexpr (BAYES && ADAM && H == 128) { if (p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem), DW_WAVES); }
+    if constexpr (ADAM && H == 128) { if (p.produce) dw_produce_finish<BAYES>(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem), DW_WAVES); }
 }
 
 template <int H, bool BAYES, bool ADAM>
@@ -512,7 +521,7 @@ __device__ __forceinline__ void dw_finish_ops(const DwArgs& p, int64_t idx0, con
     else {
         st_vec<N>(p.w_mu + idx0, o_mu); st_vec<N>(p.m_mu + idx0, o.m1); st_vec<N>(p.v_mu + idx0, o.v1);
         if (BAYES) { st_vec<N>(p.w_rho + idx0, o_rho); st_vec<N>(p.m_rho + idx0, o.m2); st_vec<N>(p.v_rho + idx0, o.v2); }
-        if constexpr (BAYES && N == 4) { if (p.produce) dw_produce_next(p, idx0, o_mu, o_rho, nx_kl, nx_amax); }
+        if constexpr (N == 4) { if (p.produce) { if constexpr (BAYES) dw_produce_next(p, idx0, o_mu, o_rho, nx_kl, nx_amax); else dw_produce_next_fnn(p, idx0, o_mu, nx_amax); } }
     }
 }
 template <bool BAYES, bool ADAM, int N>
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
         p.g_b[q + p.part_row0] = b1; if (BAYES) p.g_bp[q + p.part_row0] = b2;
     }
     float nx_kl = 0.f, nx_amax = 0.f;
-    const bool produce = BAYES && ADAM && p.produce;
+    const bool produce = ADAM && p.produce;
     const bool live = il0 < p.slab && idx0 < (int64_t)p.M * 128;
     if (!live && !produce) return;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
     }
     dw_finish_vec<BAYES, ADAM, 4>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
-    if (produce) { __shared__ double red[4]; dw_produce_finish(p, nx_kl, nx_amax, red, 4); }
+    if (produce) { __shared__ double red[4]; dw_produce_finish<BAYES>(p, nx_kl, nx_amax, red, 4); }
 }
 
 // dW of the fp16x3 training step (H = 128).  Same tiling as k_out_dw_b6 (8 waves x 32 experts, K = batch in 32-row blocks, two LDS stages by LDS-DMA),
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
             if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + il0, s2);
         } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
     }
-    if (BAYES && ADAM && !split && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
+    if (ADAM && !split && p.produce) dw_produce_finish<BAYES>(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -974,7 +983,7 @@ __global__ __launch_bounds__(64 * QW, 2) void k_out_dw_q(DwArgs p) {
         o[0] = st_t[0]; o[1] = st_t[1]; o[2] = st_t[2]; o[3] = st_t[3]; o[4] = ((unsigned long long)xcc << 32) | hw_id; o[5] = lds_base;
         o[6] = st_c[0]; o[7] = st_c[1]; o[8] = st_c[2]; o[9] = 0;
     }
-    if (BAYES && ADAM && p.produce) dw_produce_finish(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), QW);   // (scratch behind the stages)
+    if (ADAM && p.produce) dw_produce_finish<BAYES>(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), QW);   // (scratch behind the stages)
 }
 
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
@@ -994,7 +1003,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     if (grid <= 0) return;
     a.hb = reinterpret_cast<const uint16_t*>(ws + w.hb);
     a.rflag = f.rflag; a.rmode = 0;
-    a.produce = (f.produce && f.adam && f.bayes && f.H == 128) ? 1 : 0;
+    a.produce = (f.produce && f.adam && f.H == 128) ? 1 : 0;      // (Fnn: the planes of the updated mu and the range flag only)
     a.cur_eps = f.cur_eps; a.lean = (a.produce && f.lean) ? 1 : 0;
     a.nx_eps = f.nx_eps; a.nx_wp = f.nx_wp; a.nx_pl_wp = f.nx_pl_wp; a.nx_pl_mu = f.nx_pl_mu; a.nx_pscale = f.nx_pscale; a.nx_klw = f.nx_klw; a.nx_kl = f.nx_kl; a.nx_rflag = f.nx_rflag;
     a.ntile = 0; a.stagger = 0; a.stamps = nullptr;

@@ -135,6 +135,11 @@ class DataParallel:
         self.rank = 0 if self.emulate else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.emulated_bytes = {"reduce_scatter_in": 0, "all_reduce": 0, "all_gather_out": 0, "steps": 0}
         self.sync_every = max(1, int(os.environ.get("NTF_DP_SYNC_EVERY", "64")))
+        # The ranged head (forward kernel range by range behind its own chunks' all-gathers) costs a rank compute - four forward launches instead of one: +0.10 ms in the
+        # one-rank emulation (profiles/r5_dp), +0.02 ms at world 1 under real RCCL self-collectives (profiles/r6_ab_dp_world1_ranges_*.json) - and pays only where an
+        # all-gather has bytes to move.  Default by that evidence (round 6): ranged iff the group really has peers; NTF_DP_RANGES=1 / 0 forces it on / off (A/B runs, tests).
+        rng_env = os.environ.get("NTF_DP_RANGES")
+        self.ranged_head = (rng_env != "0") if rng_env is not None else (self.world > 1 and not self.emulate)
         self._grad = engine.grad_tensor()  # flat view of the engine's gradient buffer (HBM; aliases, no copy)
         # NTF_DP_FORCE_ALLREDUCE=1: run the collectives even at world_size 1 (exercises RCCL on the aliased buffers on a 1-GPU box)
         self.force_allreduce = (dist.is_initialized() and os.environ.get("NTF_DP_FORCE_ALLREDUCE", "0") == "1") or bool(self.emulate)
@@ -225,7 +230,7 @@ class DataParallel:
         # Pipelined head (round 5, engine.fwd_ranges): the output layer's operand producer and forward kernel run range by range, each behind the all-gathers of ITS dW
         # chunks only - RCCL moves the next range while the forward kernel works on this one.  Everything else the step reads (hidden layers, biases: updated on every
         # rank) is complete before it starts.
-        spans = self.engine.fwd_ranges(hi - lo) if (have_rows and self.n_chunks and self.shard and self._pending_chunk and hasattr(self.engine, "fwd_ranges")) else []
+        spans = self.engine.fwd_ranges(hi - lo) if (self.ranged_head and have_rows and self.n_chunks and self.shard and self._pending_chunk and hasattr(self.engine, "fwd_ranges")) else []
         self._finish_gathers(keep_chunks=bool(spans))
         works, owned, gathered = [], [], []
 

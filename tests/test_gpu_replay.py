@@ -26,7 +26,7 @@ def _dataset(rng, N, S, D, M, mean_s, mean_m):
     return (s_ip, s_ix), table, (m_ip, m_ix)
 
 
-def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, nsd="uniform", multihot=False):
+def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, nsd="uniform", multihot=False, bayesian=True, pipelined=True):
     import torch
     from oracle import ntf_oracle as O
     from opentf_amd import libntf
@@ -34,7 +34,7 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
     rng = np.random.default_rng(seed)
     N = (nsteps + 1) * B                                   # one batch more than is stepped: the last step still has a next batch to prefetch a head for
     skill, table, member = _dataset(rng, N, S, D, M, mean_s, mean_m)
-    sd = O.bnn_init(D, [H], M)
+    sd = O.bnn_init(D, [H], M) if bayesian else O.fnn_init(D, [H], M)
     order = rng.permutation(N).astype(np.int64)
     if multihot:       # BASELINE config 3's input: the team's 0 / 1 skill row itself (src/mdl/ntf.py:23), D = S
         assert D == S
@@ -49,9 +49,9 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
         return y
 
     def as_torch(noise):
-        return [{k: torch.from_numpy(v) for k, v in n.items()} for n in noise]
+        return [{k: torch.from_numpy(v) for k, v in n.items()} for n in noise] if noise is not None else None
 
-    e = libntf.Engine([D, H, M], bayesian=True, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd=nsd, tpw=10.0, tnw=1.0, lr=1e-3, seed=seed, fuse_adam=1)     # what bench.py and the plugin create: Adam in the dW epilogue, operands / head prefetched
+    e = libntf.Engine([D, H, M], bayesian=bayesian, input_mode=libntf.INPUT_MULTIHOT if multihot else libntf.INPUT_MEANPOOL, max_batch=B, ns=5, nsd=nsd, tpw=10.0, tnw=1.0, lr=1e-3, seed=seed, fuse_adam=1)     # what bench.py and the plugin create: Adam in the dW epilogue, operands / head prefetched
     if not multihot: e.set_skill_table(table)
     e.set_skill_csr(skill); e.set_member(member); e.load_state_dict(sd)
     if nsd == "unigram": e.set_unigram(np.bincount(member[1], minlength=M) / N)      # src/mdl/fnn.py:82
@@ -61,8 +61,8 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
     rows0 = order[:B]
     e.set_seed(seed, t0)
     got = e.logits(rows0)                                   # consumes step index t0
-    noise0 = as_torch(e.noise(t0, B))
-    for n in noise0:
+    noise0 = as_torch(e.noise(t0, B)) if bayesian else None
+    for n in noise0 or []:
         assert set(np.unique(n["s_in"].numpy())) <= {-1.0, 1.0} and set(np.unique(n["s_out"].numpy())) <= {-1.0, 1.0}
         assert abs(float(n["eps_w"].mean())) < 0.02 and abs(float(n["eps_w"].std()) - 1.0) < 0.02
     ref = O.model_forward(sd, Xall[rows0], noise0).detach().numpy()
@@ -77,10 +77,12 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
     for k in range(nsteps):
         losses.append(e.step_staged(k * B, B, train=True, apply=True, want_loss=True))
         negs.append(e.negatives(B).copy())
-        noises.append(e.noise(t0 + k, B))
+        noises.append(e.noise(t0 + k, B) if bayesian else None)
     # the pipelined default path really ran: steps 2.. started on operands the previous dW epilogue produced, with the head that ran beside that kernel
-    assert e.prefetched_steps() - pre0 >= nsteps - 1, (e.prefetched_steps(), pre0)
-    if multihot:      # (no one-kernel head for this input; instead: steps 2.. took their first-layer sigma * eps and KL term from the previous step's one-pass sweep)
+    if not pipelined: assert e.prefetched_steps() == pre0 and e.head_prefetch_hits() == hit0
+    else: assert e.prefetched_steps() - pre0 >= nsteps - 1, (e.prefetched_steps(), pre0)
+    if not pipelined: pass
+    elif multihot:      # (no one-kernel head for this input; instead: steps 2.. took their first-layer sigma * eps and KL term from the previous step's one-pass sweep)
         import os
         want = 0 if os.environ.get("NTF_L0_SWEEP") == "0" else nsteps - 1
         assert e.first_layer_sweeps() - sw0 == want, (e.first_layer_sweeps(), sw0)
@@ -117,6 +119,16 @@ def test_three_default_steps_replayed_through_the_oracle_at_config2_size():
 def test_three_default_steps_replayed_through_the_oracle_on_a_ragged_shape():
     """a ragged last expert tile (M = 70 001: one expert into a 32-expert sub-tile, a 128-expert half-tile and a 256-expert tile) under a ragged row block (B = 129)"""
     _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=22, t0=40)
+
+
+@pytest.mark.parametrize("pipe", ["1", "0"])
+def test_three_default_fnn_steps_replayed_through_the_oracle(pipe, monkeypatch):
+    """The non-Bayesian half of the path (src/mdl/fnn.py alone) on its default pipeline (round 6): the dW + Adam epilogue writes the next step's fp16 planes of mu, the hidden
+    backward, the hidden Adam and the next batch's head run beside the dW kernel (asserted: steps 2.. start on prefetched planes and a prefetched head); NTF_FNN_PIPE=0: round
+    5's serial step.  Negatives are the device's own draws."""
+    monkeypatch.setenv("NTF_FNN_PIPE", pipe)
+    _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=25, t0=3, bayesian=False, pipelined=pipe == "1")
+    if pipe == "1": _replay(D=128, H=128, M=233_629, B=1000, S=4000, mean_s=8.57, mean_m=3.06, seed=26, t0=8, bayesian=False)
 
 
 @pytest.mark.parametrize("sweep", ["1", "0"])

@@ -166,7 +166,7 @@ def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own
         l4 = _full_epoch(e, order[500:], 1000)
         out.append(((l1, v, l2, *v2, l3, l4), p, e.state_dict(), e.head_prefetch_hits())); e.close()
     (la, pa, sa, ha), (lb, pb, sb, hb) = out
-    assert ha == 0 and hb == ((2 + 2 + 1 + 1) if bayesian else 0), (ha, hb)      # (Fnn: no side stream, no prefetch)
+    assert ha == 0 and hb == 2 + 2 + 1 + 1, (ha, hb)      # (round 6: Fnn steps run the same pipeline - planes of the updated mu from the dW epilogue, hidden backward and the next head on the side stream)
     for x, y in zip(la, lb): assert abs(x - y) <= 1e-9 * abs(x), (x, y)
     assert np.array_equal(pa, pb)
     for k in sa: assert np.array_equal(sa[k], sb[k]), k
@@ -393,6 +393,28 @@ def test_wave_pair_forward_equals_the_one_wave_kernel(bayesian, M, B, monkeypatc
     for x, y in zip(a[:6], b[:6]): assert abs(x - y) <= 2e-6 * abs(x), (x, y)
     for t in (6, 7, 8):
         for k in a[t]: np.testing.assert_array_equal(np.asarray(a[t][k]), np.asarray(b[t][k]), err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------ the evaluation-loss kernel (k_out_fwd_h3e, round 6)
+@pytest.mark.parametrize("bayesian", [True, False])
+@pytest.mark.parametrize("M,B", [(70_000, 1000), (3000, 333), (70_001, 129), (40, 70), (233_629, 257)])     # ragged / empty last sub-tile, a ragged and a half-empty 256-row block, one tile only
+def test_eval_loss_kernel_equals_the_forward_only_kernel_of_round_5(bayesian, M, B, monkeypatch):
+    """k_out_fwd_h3e (eight staggered logit waves on 256 rows) against k_out_fwd_b6<.., TRAIN = false> (NTF_EVAL_KERNEL=0): the loss of evaluation steps on the device's
+    own draws - the same fp16x3 products and logit arithmetic, the row sums taken in another order (2e-6) - one by one, as an epoch call, and behind a train step
+    (prefetched operands); then against the exact-f32 engine (2e-5)."""
+    ds = make_dataset("dblp", d=128, seed=14, n_rows=2600, n_experts=M)
+    dims = [128, 128, ds["M"]]
+    order = np.random.default_rng(8).permutation(ds["N"])[:2 * B + B // 3].astype(np.int64)
+    out = []
+    for k, mfma in (("0", None), ("1", None), ("1", "f32")):
+        monkeypatch.setenv("NTF_EVAL_KERNEL", k)
+        e = _mk(ds, dims, bayesian, B, "uniform", mfma=mfma)
+        ls = [e.eval_step(order[:B]), e.eval_step(order[B:2 * B]), e.eval_epoch(order, B)]
+        e.train_step(order[:B]); ls.append(e.eval_step(order[B:2 * B]))
+        assert e.range_fallbacks() == 0
+        out.append(ls); e.close()
+    for x, y in zip(out[0], out[1]): assert np.isfinite(x) and abs(x - y) <= 2e-6 * abs(x), (x, y)
+    for x, y in zip(out[1][:3], out[2][:3]): assert abs(x - y) <= 2e-5 * abs(y), (x, y)      # (behind the train step the two arithmetics' parameters differ)
 
 
 # ------------------------------------------------------------------------------------------ inference (Fnn.test, src/mdl/fnn.py:172-219) at BASELINE config 2's expert count
