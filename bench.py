@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--experts", type=int, default=0, help="override the number of experts (debug)")
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--fuse-adam", type=int, default=1, help="N=1 only. 1 (default): the output layer's Adam runs in the dW kernel's epilogue (52 instead of 76 B of HBM traffic per mu/rho pair, no gradient round trip); 0: one flat Adam kernel after backward; 2: dW in chunks, Adam of a finished chunk on a side stream")
-    ap.add_argument("--mfma", default="default", choices=["default", "f32", "bf16x6", "fp16x3"], help="arithmetic of the fused output-layer products (include/opentf_amd.h ntf_mfma)")
+    ap.add_argument("--mfma", default="default", choices=["default", "f32", "fp16x3"], help="arithmetic of the fused output-layer products (include/opentf_amd.h ntf_mfma)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-bench", action="store_true", help="(default at N=1) also time the whole-dataset gather (get_dense_vecs)")
     ap.add_argument("--no-gather-bench", action="store_true")
@@ -131,7 +131,7 @@ def launched_kernel(family, a):
     """name (prefix) of the output-layer kernel a default-shaped run launches for a timed family - what a committed PMC file must be about before its bytes are quoted"""
     if a.no_fused or a.hidden != 128: return None
     if a.mfma == "f32": return {"out_fused_fwd_loss_dh": "k_out_fwd<", "out_fused_dw_adam": "k_out_dw<"}.get(family)
-    fwd = {None: "k_out_fwd_h3p", "5": "k_out_fwd_h3p", "3": "k_out_fwd_h3x", "0": "k_out_fwd_b6"}.get(os.environ.get("NTF_FWD_KERNEL"))
+    fwd = {None: "k_out_fwd_h3p", "5": "k_out_fwd_h3p", "0": "k_out_fwd_b6"}.get(os.environ.get("NTF_FWD_KERNEL"))
     dw = {None: "k_out_dw_q", "1": "k_out_dw_q"}.get(os.environ.get("NTF_DW_KERNEL"))
     return {"out_fused_fwd_loss_dh": fwd, "out_fused_dw_adam": dw}.get(family)
 
@@ -264,13 +264,12 @@ def rooflines(times, a, bayesian, eB, H, Mloc, ds, ep, evt_steps=None, adam_in_d
                         "mfma_tflops_algorithmic": flops_per_launch[fam] / t / 1e12, **part})
             continue
         ach = flops_per_launch[fam] / t / 1e12
-        # arithmetic of the kernel: "bf16x6" = every f32 operand split exactly into 3 bf16 values, a product = 6 bf16 MFMA products
-        # accumulated in f32 (f32-accurate).  The roof for ALGORITHMIC flops is then the dense bf16 MFMA peak / 6.
+        # arithmetic of the kernel: fp16x3 = every f32 operand (times an exact power of two) split into 2 fp16 values, a product = 3 fp16 MFMA products
+        # accumulated in f32.  The roof for ALGORITHMIC flops is then the dense fp16 MFMA peak / 3.
         split = a.mfma != "f32" and not a.no_fused and ((fam == "out_fused_dw_adam") or (fam == "out_fused_fwd_loss_dh" and a.hidden == 128))
-        nprod = (6 if a.mfma == "bf16x6" else 3) if split else 1
+        nprod = 3 if split else 1
         peak = BF16_MFMA_PEAK_TFLOPS / nprod if split else F32_MFMA_PEAK_TFLOPS
         arith = {1: "f32 MFMA (v_mfma_f32_32x32x2_f32)",
-                 6: "bf16x6: operands split exactly into 3 bf16 values, 6 bf16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 6",
                  3: "fp16x3: operands * 2^k split into 2 fp16 values (22 bits), 3 fp16 MFMA products per f32 product, f32 accumulate; peak = 2516.6 / 3"}[nprod]
         out.append({"bound": "mfma", "kernel": fam, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                     "traffic_source": src and f"per-launch mean of the separate rocprofv3 --pmc passes committed as profiles/{src} (FETCH_SIZE doubled per MI355X_MICROARCH.md), not counted in this run",
@@ -284,7 +283,7 @@ def validation_step(ev, a, bayesian, eB, H, M):
     if not ev: return None
     flop = (2 if bayesian else 1) * 2.0 * eB * H * M
     split = a.mfma != "f32" and not a.no_fused and a.hidden == 128
-    peak = BF16_MFMA_PEAK_TFLOPS / (6 if a.mfma == "bf16x6" else 3) if split else F32_MFMA_PEAK_TFLOPS
+    peak = BF16_MFMA_PEAK_TFLOPS / 3 if split else F32_MFMA_PEAK_TFLOPS
     t = ev["ms_per_step"] * 1e-3
     return {**ev, "flop_per_step": flop, "tflops": flop / t / 1e12, "mfma_peak": peak, "mfma_frac": flop / t / 1e12 / peak,
             "note": "whole evaluation step (operand producer, head, forward + loss kernel, fix-up), timed over an eval_epoch call; kernel: k_out_fwd_h3e unless NTF_EVAL_KERNEL=0"}
@@ -299,7 +298,7 @@ def step_roofline(a, bayesian, head, ds, multihot, step_s):
     D = (ds["skill"][0][-1] / ds["N"]) if multihot else a.d
     flop = eB * ((12.0 * H * M + 8.0 * D * H) if bayesian else 6.0 * (D * H + H * M))
     split = a.mfma != "f32" and not a.no_fused and a.hidden == 128
-    peak = BF16_MFMA_PEAK_TFLOPS / (6 if a.mfma == "bf16x6" else 3) if split else F32_MFMA_PEAK_TFLOPS
+    peak = BF16_MFMA_PEAK_TFLOPS / 3 if split else F32_MFMA_PEAK_TFLOPS
     Bpad = (eB + 127) // 128 * 128; Mpad = (M + 255) // 256 * 256
     k = 2 if bayesian else 1
     fwd_b = 4.0 * k * H * M + 4.0 * Bpad * Mpad                        # two fp16 planes of mu (and of sigma * eps) read once; the packed dz written
@@ -443,6 +442,21 @@ def main():
                 bd = {f: round(v[0] / k3, 4) for f, v in full.items() if v[1] > 0}
                 for fam in ("out_fused_fwd_loss_dh", "out_fused_dw_adam", "out_fwd_gemm", "out_bwd_dw_gemm"):      # a run of ONE timed region saw one of the two kernels only
                     if fam not in times and fam in full and full[fam][1] > 0: times[fam] = full[fam]; evt_steps[fam] = k3
+            # N > 1 (or --force-dist): what the collectives cost this rank, from a SEPARATE short pass with an event pair around every stream-ordered wait (dp.CollectiveTrace.
+            # exposed_waits: the stream does nothing between the pair but wait) - exposed wait per collective class and, by difference, the rank's own compute per step
+            waits = None
+            tr = getattr(dp, "trace", None)
+            if (world > 1 or a.force_dist) and tr is not None and getattr(tr, "stream_ordered", False):
+                kw = max(5, min(20, steps))
+                tr.measure_waits = True
+                e.synchronize(); torch.cuda.synchronize()
+                if world > 1: dist.barrier()
+                t0 = time.perf_counter(); dp.train_epoch(order[: kw * gB], gB); e.synchronize(); torch.cuda.synchronize()
+                tw = (time.perf_counter() - t0) / kw * 1e3
+                ex = {c: v / kw for c, v in tr.exposed_waits().items()}
+                tr.measure_waits = False
+                waits = {"steps": kw, "ms_per_step_of_this_pass": tw, "exposed_wait_ms_per_step": ex, "rank_compute_ms_per_step": tw - sum(ex.values()),
+                         "note": "rank 0's figures; the pass carries two events per collective wait (not the timed regions)"}
             dt = float(np.median(regions))
             # the validation phase's step (src/mdl/fnn.py:143-151: forward + loss on fresh eps, no backward): 566 of a fold-epoch's 1 697 batches at config 2
             ev = None
@@ -451,7 +465,7 @@ def main():
                 dp.eval_epoch(order[: 3 * gB], gB); e.synchronize()
                 t0 = time.perf_counter(); ev_loss = dp.eval_epoch(order[: kev * gB], gB); e.synchronize()
                 ev = {"ms_per_step": (time.perf_counter() - t0) / kev * 1e3, "steps": kev, "mean_loss": ev_loss}
-            res = {"par": par, "eval": ev, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "region_losses": losses, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
+            res = {"par": par, "eval": ev, "collective_waits": waits, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "region_losses": losses, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
                    "Mloc": (shard[1] - shard[0]) if ep else model_dims[-1], "engine": e,
                    "rccl_payload_bytes_per_step": (4 * gB * a.hidden) if ep else (8 * n_params if world > 1 else 0),
                    "emulated_bytes": getattr(dp, "emulated_bytes", None)}
@@ -526,7 +540,7 @@ def main():
             "metric": "teams/sec (train) bnn_emb d=128 on DBLP", "value": a.steps * gB / dt, "unit": "teams/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_spread": spread, "timed_regions": len(head["regions"]),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"f32": "f32", "bf16x6": "f32 (bf16x6 split products, f32 accumulate)"}.get(a.mfma, "f32 (fp16x3 split products, f32 accumulate)"), "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f32": "f32"}.get(a.mfma, "f32 (fp16x3 split products, f32 accumulate)"), "data": "synthetic",
             "config": {"workload": workload_label(a, ds, bayesian, multihot), "global_batch": gB,
                        "parallelism": (f"ep{world}: expert-sharded output layer, every GPU steps the global minibatch on 1/{world} of the experts, d(hidden) all-reduced" if ep else
                                        f"dp{world}" + (": rows split over the GPUs, gradients reduce-scattered / parameters all-gathered over RCCL, Adam on the owned 1/N shard" if world > 1 else ""))},
@@ -536,6 +550,7 @@ def main():
             "kernel_ms_per_step": head["breakdown"], "kernel_ms_note": "separate pass of %d steps with events around every kernel family (side-stream families overlap the big kernels: the column does not sum to the step); the timed region carries events around the two output-layer kernels only" % head["k3"],
             "rccl_ranks": world if world > 1 else 1, "rank0_device": f"cuda:{local} {devices[0]}",
             "rccl_payload_bytes_per_step": head["rccl_payload_bytes_per_step"],
+            "collective_waits": head.get("collective_waits"),
         }
         out.update(extra_modes)
         if not final: out["cut_off"] = "printed by rank 0's watchdog: an extra leg did not return"
@@ -572,7 +587,7 @@ def main():
     if world > 1 and a.parallel == "auto" and not a.ep_emulate:
         def brief(r, scaling):
             return {"parallelism": r["par"], "scaling": scaling, "global_batch": r["gB"], "rows_per_rank": r["eB"], "ms_per_step": r["dt"] / a.steps * 1e3,
-                    "value": a.steps * r["gB"] / r["dt"], "unit": "teams/s", "rccl_payload_bytes_per_step": r["rccl_payload_bytes_per_step"], "mean_loss": r["mean_loss"]}
+                    "value": a.steps * r["gB"] / r["dt"], "unit": "teams/s", "rccl_payload_bytes_per_step": r["rccl_payload_bytes_per_step"], "mean_loss": r["mean_loss"], "collective_waits": r.get("collective_waits")}
         # The headline is measured; nothing below may lose it.  Each extra leg: (1) every rank builds its engine, the ranks agree over the gloo control group, and the
         # leg is skipped everywhere unless all succeeded; (2) a Python exception inside the leg becomes {"error": ...} under its key on all ranks (agreed the same way);
         # (3) once a leg has failed while running, the collectives' state is unknown: the remaining legs are skipped; (4) a leg that does not come back at all is cut

@@ -42,7 +42,7 @@ enum ntf_nsd { NTF_NSD_NONE = 0, NTF_NSD_UNIFORM = 1, NTF_NSD_UNIGRAM = 2, NTF_N
  * mu_weight, rho_weight, mu_bias, rho_bias (src/mdl/bnn.py:25 via bayesian-torch LinearFlipout) */
 enum ntf_param_kind { NTF_P_WEIGHT = 0, NTF_P_BIAS = 1, NTF_P_RHO_WEIGHT = 2, NTF_P_RHO_BIAS = 3 };
 
-enum ntf_mfma { NTF_MFMA_DEFAULT = 0, NTF_MFMA_F32 = 1, NTF_MFMA_BF16X6 = 2, NTF_MFMA_FP16X3 = 3 };
+enum ntf_mfma { NTF_MFMA_DEFAULT = 0, NTF_MFMA_F32 = 1, NTF_MFMA_BF16X6_RETIRED = 2 /* rejected by ntf_engine_create since round 6 */, NTF_MFMA_FP16X3 = 3 };
 
 typedef struct ntf_config {
     int32_t abi_version;        /* NTF_ABI_VERSION */
@@ -62,11 +62,10 @@ typedef struct ntf_config {
     int32_t fuse_adam;          /* single-GPU train steps only.  0: one flat Adam kernel after backward.  1: the output layer's Adam runs inside
                                    the dW kernel's epilogue (its gradients are not materialised).  2: the dW kernel is launched in expert chunks
                                    and Adam of a finished chunk runs on a side stream beside the next chunk's dW */
-    int32_t mfma;               /* arithmetic of the fused output-layer products: NTF_MFMA_DEFAULT (0) = the engine's choice,
-                                   NTF_MFMA_F32 = v_mfma_f32_32x32x2_f32 (bit-exact f32 fma chain), NTF_MFMA_BF16X6 = each f32 operand split exactly into
-                                   three bf16 values and a product taken as six bf16 MFMA products accumulated in f32 (f32-accurate, ~2.7x the rate),
-                                   NTF_MFMA_FP16X3 = each operand times an exact power of two split into two fp16 values (22 bits), three fp16 MFMA products per f32
-                                   product (error against f64 ~1.2x that of the f32 MFMA, half the matrix work of BF16X6) */
+    int32_t mfma;               /* arithmetic of the fused output-layer products: NTF_MFMA_DEFAULT (0) = NTF_MFMA_FP16X3 = each operand times an exact power of two
+                                   split into two fp16 values (22 bits), three fp16 MFMA products per f32 product, f32 accumulate (error against f64 ~1.2x that of
+                                   the f32 MFMA; operands outside the fp16 window send the step to the exact-f32 kernels, ntf_range_fallbacks);
+                                   NTF_MFMA_F32 = v_mfma_f32_32x32x2_f32 (a bit-exact f32 fma chain).  2 (bf16x6, rounds 1-5) is rejected */
     /* Expert-sharded output layer (every field 0 = off).  This engine owns the experts [expert_lo, expert_lo + dims[n_layers]) of an
        output layer of `experts_global` experts that is split over `ep_world` engines (one per GPU); hidden layers are replicated.  Every engine
        steps the WHOLE minibatch: labels (member CSR) and sampled negatives keep global expert ids, the device generators are keyed by global

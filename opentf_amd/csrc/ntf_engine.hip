@@ -98,7 +98,6 @@ struct ntf_engine {
     int cosched = 0; bool cosched_have = false; FusedDw cosched_dw; hipEvent_t ev_co0 = nullptr, ev_co1 = nullptr;
 #endif
     int lean = 1;                     // NTF_LEAN=0: the dW epilogue also writes the f32 copy of the next step's sigma * eps (round 3's 64 B per pair; A/B runs)
-    int dw_kernel = 1;                // NTF_DW_KERNEL=0: k_out_dw_p2 (one 256-expert workgroup per CU) instead of k_out_dw_q (A/B runs)
     int dw_tail = 0;                  // NTF_DW_TAIL=1|2|3 (-DNTF_DIAG builds only; measured SLOWER): the last partial round of half-tiles as split-K launches (dw_launch_whole)
     int n_cu = 256;
     int dw_ksplit = 0;                // 0: automatic (few expert tiles -> split the dW kernel's K range), else forced (NTF_DW_KSPLIT)
@@ -239,6 +238,8 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (!cfg || cfg->abi_version != NTF_ABI_VERSION) { g_create_error = "bad config / abi_version"; return NTF_EINVAL; }
     if (cfg->n_layers < 1 || cfg->n_layers > NTF_MAX_LAYERS || cfg->max_batch < 1 || cfg->ns < 0) { g_create_error = "bad n_layers/max_batch/ns"; return NTF_EINVAL; }
     for (int i = 0; i <= cfg->n_layers; ++i) if (cfg->dims[i] < 1) { g_create_error = "bad dims"; return NTF_EINVAL; }
+    if (cfg->mfma == NTF_MFMA_BF16X6_RETIRED) { g_create_error = "mfma = 2 (bf16x6: three bf16 values per operand, six products) was retired in round 6: the default fp16x3 has its accuracy at half the matrix work; use NTF_MFMA_DEFAULT or NTF_MFMA_F32"; return NTF_EINVAL; }
+    if (cfg->mfma < 0 || cfg->mfma > NTF_MFMA_FP16X3) { g_create_error = "bad mfma"; return NTF_EINVAL; }
     if (cfg->input_mode == NTF_INPUT_MULTIHOT && cfg->n_layers < 2) { g_create_error = "multi-hot input needs a hidden layer (src/mdl/fnn.py:17-19)"; return NTF_EINVAL; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device: the engine has no CPU fallback"; return NTF_EHIP; }
@@ -249,9 +250,11 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     e->L = cfg->n_layers;
     e->lr = cfg->lr;
     e->seed = cfg->seed;
-    if (const char* fk = getenv("NTF_FWD_KERNEL")) e->fwd_kernel = atoi(fk);
+    if (const char* fk = getenv("NTF_FWD_KERNEL")) {
+        e->fwd_kernel = atoi(fk);
+        if (e->fwd_kernel != 0 && e->fwd_kernel != 5) { g_create_error = "NTF_FWD_KERNEL: 5 (k_out_fwd_h3p, the default) or 0 (k_out_fwd_b6); the forms 1-4 of rounds 2-3 are retired"; delete e; return NTF_EINVAL; }
+    }
     if (const char* ks = getenv("NTF_DW_KSPLIT")) e->dw_ksplit = atoi(ks);
-    if (const char* dk = getenv("NTF_DW_KERNEL")) e->dw_kernel = atoi(dk);
     if (const char* ln = getenv("NTF_LEAN")) e->lean = atoi(ln);
 #ifdef NTF_DIAG
     if (const char* dt = getenv("NTF_DW_TAIL")) e->dw_tail = atoi(dt);
@@ -286,6 +289,13 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
         if (l < e->L - 1) e->maxhid = std::max(e->maxhid, li.out);
     }
     e->n_params = off;
+    if (cfg->fused && !fused_supported(e->layers[e->L - 1].in) && (int64_t)cfg->dims[e->L] >= 4096 && !getenv("NTF_QUIET")) {
+        // (a hidden width outside {32, 64, 128} fell to the generic chain - k_gemm + dense [B, M] loss - without a word: 59 k teams/s against ~740 k at config 2's size)
+        static bool warned = false;
+        if (!warned) fprintf(stderr, "opentf_amd: h[-1] = %d has no fused output-layer kernels (32, 64 and 128 have; 128 also the split-product ones): this model runs on the "
+                                     "generic GEMM + dense-loss chain, an order of magnitude slower at %d experts (INTEGRATION.md, limits)\n", e->layers[e->L - 1].in, cfg->dims[e->L]);
+        warned = true;
+    }
     e->Mg = cfg->experts_global > 0 ? cfg->experts_global : cfg->dims[e->L];
     e->ep_lo = cfg->expert_lo; e->ep_world = std::max(1, cfg->ep_world);
     e->ep = cfg->experts_global > 0 || e->ep_lo != 0 || e->ep_world > 1;   // a shard may also be the whole layer (ep_world = 1)
@@ -593,7 +603,7 @@ static NormalSpec normal_spec(ntf_engine* e, const StepCtx& c, int layer, int te
 }
 
 // split-product arithmetic of the fused output layer: number of planes and the exact power-of-two scales of fp16x3
-static inline int mfma_np(const ntf_engine* e) { return e->cfg.mfma == NTF_MFMA_BF16X6 ? 3 : 2; }   // default: fp16x3
+static inline int mfma_np(const ntf_engine*) { return 2; }   // fp16x3: two fp16 planes per operand (the three-plane bf16x6 arithmetic was retired in round 6)
 constexpr float kW16Scale = 256.f, kH16Scale = 16.f;          // weights (|w| << 256), hidden activations (|h| << 4096)
 static inline float dz_scale16(const ntf_engine* e, int global_B) {   // |dz| <= max(tpw, tnw) / B  ->  scaled below 2^14
     const float dzmax = std::max(std::max(e->cfg.tpw, e->cfg.tnw), 1e-30f) / (float)std::max(global_B, 1);
@@ -826,7 +836,7 @@ static int dw_launch_whole(ntf_engine* e, const FusedDw& f) {
     return NTF_OK;
 #else
     const int slots = 2 * e->n_cu, total_q = (f.M + 127) / 128, full_q = total_q / slots * slots, tail_q = total_q - full_q;
-    const bool can = e->dw_tail > 0 && f.kernel == 1 && f.dz_packed && f.adam && f.ksplit <= 1 && f.wg_count <= 0 && f.H == 128 && full_q > 0 && tail_q > 0 &&
+    const bool can = e->dw_tail > 0 && f.dz_packed && f.adam && f.ksplit <= 1 && f.wg_count <= 0 && f.H == 128 && full_q > 0 && tail_q > 0 &&
                      tail_q * 10 <= slots * 8 && e->Zout != nullptr;
     if (!can) { launch_fused_out_dw(e->st, f); return NTF_OK; }
     const int tail_p2 = (tail_q + 1) / 2, nib = fused_ldb(f.B) / 32;
@@ -952,7 +962,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
                           e->hp_next_B > 0 && (e->cfg.nsd != NTF_NSD_UNIGRAM_B || e->hp_next_host != nullptr) && range_ptr(e) && e->pl_mu && lo.in == 128;
     const bool side = fused && (e->cfg.bayesian || fnn_side) && e->L > 1 && c.train && c.part == 0 && (!c.defer_dw || e->dp_side_bwd) && e->side_bwd && !(c.fuse_adam && e->cfg.fuse_adam == 2);
     bool hp_hit = false, hp_stale = false;
-    bool chain_ok = false, chain_lean = false, chain_fill = false; PerturbChain pch;
+    bool chain_ok = false, chain_lean = false, chain_fill = false, chain_nof32 = false; PerturbChain pch;
     FwdRange fr[4]; int fr_tot = 0;
     const int nfr = (c.chunk_cb && c.defer_dw && c.train && c.part == 0 && !c.inj && e->dp_ranges) ? fwd_ranges(e, B, fr, &fr_tot) : 0;      // > 0: producer + forward kernel range by range
     if (fused) e->fws = e->fws_set[c.step & 1];     // (every kernel of a step works in ONE of the two workspace sets: a prefetched head of step t + 1 fills the other beside step t's dW kernel)
@@ -983,6 +993,9 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     if (chain_fill) HIPCHK(e, hipMemsetAsync(e->d_chain, 0, 16, e->st));
     if (chain_fill) { pch.kl_out2 = e->d_chain; pch.mu_flag_out = reinterpret_cast<int*>(e->d_chain + 1); e->chain_valid = true; }
     if (chain_lean) pch.raise_if = reinterpret_cast<const int*>(e->d_chain + 1);
+    // a lean evaluation step of a chain reads the fp16 planes only: its producer writes no f32 copy of sigma * eps (120 of its 360 MB at config 2); a step whose range flag
+    // is raised makes the copy itself, below (the conditional launch a train step on prefetched operands uses)
+    chain_nof32 = chain_lean && e->lean && e->pl_wp != nullptr;
     if (e->cfg.bayesian || (range_ptr(e) && e->fnn_pipe)) { if (!(use_pre && e->pre_rotated)) launch_step_scalars(e->st, e->d_kl, use_pre ? 1 : 0, chain_lean ? e->d_chain : nullptr); }
     else if (range_ptr(e)) HIPCHK(e, hipMemsetAsync(e->d_range, 0, 4, e->st));
     e->pre_rotated = false;
@@ -999,7 +1012,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
             HIPCHK(e, hipStreamWaitEvent(e->st3, e->ev_fork, 0));
             e->st = e->st3;
             { Scope t(e, F_FLIPOUT_OPERAND);
-              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], chain_lean ? nullptr : e->P + lo.off[NTF_P_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], chain_lean ? nullptr : e->P + lo.off[NTF_P_WEIGHT], lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), chain_nof32 ? nullptr : e->Wp[e->L - 1],
                                      1.0 / out_nw, e->d_kl, e->pl_wp, (e->pl_wp && !chain_lean) ? e->pl_mu : nullptr, e->P + lo.off[NTF_P_WEIGHT], lo.in, mfma_np(e), kW16Scale, range_ptr(e), nullptr, pch); }
             HIPCHK(e, hipEventRecord(e->ev_join, e->st3));
             prod_side = true;
@@ -1039,7 +1052,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         f.h_mask = e->L > 1 ? e->act[e->L - 1] : nullptr;
         if (e->cfg.bayesian) {
             if (!prod_side && !use_pre && !nfr) { Scope t(e, F_FLIPOUT_OPERAND);
-              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], chain_lean ? nullptr : f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1],
+              launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], chain_lean ? nullptr : f.mu, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), chain_nof32 ? nullptr : e->Wp[e->L - 1],
                                      1.0 / out_nw, e->d_kl, e->pl_wp, (e->pl_wp && !chain_lean) ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e), nullptr, pch); }   // + the split planes of Wp and mu
             if (!aux && !use_head) { Scope t(e, F_FLIPOUT_OPERAND);
               launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], f.mu_b, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1],
@@ -1079,7 +1092,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         }
         if (prod_side) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_join, 0));
         if (aux) HIPCHK(e, hipStreamWaitEvent(e->st, e->ev_aux, 0));   // (the sparse fix-up reads the negatives, the dW kernel the s_out words: both long done by now)
-        if (use_pre && e->cfg.bayesian && e->lean && !(hp_hit && e->f32_copy_step == c.step + 1)) {      // (f32_copy_step: the previous step's Adam launch carried this job - good only if the head that
+        if (chain_nof32 || (use_pre && e->cfg.bayesian && e->lean && !(hp_hit && e->f32_copy_step == c.step + 1))) {      // (f32_copy_step: the previous step's Adam launch carried this job - good only if the head that
                                                                                       // ran beside that step IS this batch's: a head redone here may raise the flag anew)
             // this step's operands came from the previous step's dW epilogue, which (lean) left no f32 copy of sigma * eps: only a step that falls back to the exact-f32 kernels
             // reads one, and makes it here - a capped grid that exits at once unless the range flag is raised (behind the head: k_head may still raise it)
@@ -1182,7 +1195,6 @@ backward:
             f.np = mfma_np(e); f.a_scale = dz_scale16(e, c.global_B); f.h_scale = kH16Scale; f.rflag = range_ptr(e);
             f.dz_packed = f.bf16x6 && f.np == 2 && li.in == 128 && e->pl_mu != nullptr;   // the fp16x3 forward kernels (H = 128) store packed plane pairs
             e->last_dz_packed_scale = f.dz_packed ? f.a_scale : 0.f;
-            f.kernel = e->dw_kernel;
             if (f.dz_packed && !c.defer_dw && !(c.fuse_adam && e->cfg.fuse_adam == 2)) {
                 // few expert tiles (a narrow expert shard under a wide minibatch, or a small model) leave most CUs idle at one workgroup per 256 experts:
                 // split every tile's K (batch) range over several workgroups.  Scratch: the dense-logits buffer of the generic path, idle in a fused step.

@@ -24,11 +24,10 @@ struct FusedOut {
     int c_lo = 0;                                   // expert shard of the output layer: m_indices / neg hold GLOBAL expert ids, mu .. are rows [c_lo, c_lo + M)
     // bf16x6 arithmetic (H = 128): scratch for the bf16 split planes of mu / Wp, fused_planes_elems(M, H) uint16 each
     int bf16x6 = 0; uint16_t* mu_pl = nullptr; uint16_t* wp_pl = nullptr;
-    int np = 3;                                     // 3: bf16x6, 2: fp16x3 (operands scaled by exact powers of two before their two-way fp16 split)
+    int np = 2;                                     // 2: fp16x3 (operands scaled by exact powers of two before their two-way fp16 split); 3 (bf16x6) is no longer instantiated
     float w_scale = 1.f, h_scale = 1.f, dz_scale = 1.f;
-    int wide = 5;                                   // np = 2 training step: 5 (default, round 4) k_out_fwd_h3p - a logit wave and a gradient wave per 32 rows, two waves per SIMD, 32-expert steps;
-                                                    // 3 k_out_fwd_h3x - one wave per SIMD, 64-expert tiles, phases rotated across tiles (round 3's default); 0 the 32-expert-tile kernel
-                                                    // k_out_fwd_b6.  NTF_FWD_KERNEL selects the A/B forms (round 3's sixteen-row-wave form, 4, was retired in round 5)
+    int wide = 5;                                   // np = 2 training step: 5 (default) k_out_fwd_h3p - a logit wave and a gradient wave per 32 rows, two waves per SIMD, 32-expert steps;
+                                                    // 0 the 32-expert-tile kernel k_out_fwd_b6 (NTF_FWD_KERNEL=0: A/B runs).  Round 3's one-wave form (3) and sixteen-row-wave form (4) are retired
     int eval_kernel = 1;                            // np = 2 evaluation loss: 1 (default, round 6) k_out_fwd_h3e - eight logit waves on 256 rows, the two waves of a SIMD half a step apart; 0 k_out_fwd_b6
     int ncg_limit = 0;                              // > 0 (diagnostics, NTF_COSCHED): at most this many column groups, i.e. a forward grid of NRB * ncg_limit workgroups that leaves CUs free
     int split_fallback = 0;                         // the exact-f32 forward launch behind the split-product kernel is NOT part of phase 2 but a phase of its own (8)
@@ -59,14 +58,13 @@ struct FusedDw {
     // adam != 0 (single GPU): Adam on mu / rho runs in the epilogue (in place), g_mu / g_rho are not written
     int adam = 0;
     int bf16x6 = 0;                                 // 1: split-product MFMAs (f32-accurate, see ntf_fused.hip) instead of the f32 MFMA
-    int np = 3;                                     // 3: bf16 three-way split, six products; 2: fp16 two-way split of scaled operands, three products
+    int np = 2;                                     // 2: fp16 two-way split of scaled operands, three products (3, the bf16 three-way split, is no longer instantiated)
     float a_scale = 1.f, h_scale = 1.f;             // np = 2: exact power-of-two scales of dz (applied in the kernel) and of the h planes (applied by the producer)
     int wg_begin = 0, wg_count = 0;                 // wg_count > 0: launch only the expert tiles [wg_begin, wg_begin + wg_count) of fused_dw_tile() experts each
     int* rflag = nullptr;                           // fp16x3 range guard, see FusedOut
     int dz_packed = 0;                              // np = 2, H = 128: dzT holds the forward kernel's packed fp16 plane pairs (see pack_planes)
-    int kernel = 1;                                 // dz_packed, unsplit K: 1 = k_out_dw_q (two 128-expert workgroups per CU, epilogue beside main loop), 0 = k_out_dw_p2
     int ksplit = 1; float* part = nullptr;          // dz_packed path: split every launched expert tile's K (batch) range over ksplit workgroups; part = scratch
-                                                    // of fused_dw_part_floats(M, H, ksplit) floats.  For few expert tiles (a narrow expert shard under a wide minibatch).
+                                                    // of fused_dw_part_floats(M, H, ksplit) floats (k_out_dw_q<.., SPLIT> + k_out_dw_finish).  For few expert tiles (a narrow expert shard under a wide minibatch).
     int no_fallback = 0, fallback_only = 0;         // a step whose dW is issued as several launches (the tail split): the split-product launches carry no exact-f32 launch behind
                                                     // them (no_fallback), ONE launch over the whole layer follows (fallback_only: nothing but that kernel)
     float *w_mu = nullptr, *w_rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr, *v_rho = nullptr;
@@ -95,7 +93,7 @@ int fused_dw_tile();   // experts per workgroup of the dW kernel (dzT rows are p
 // phases: 1 = operand preparation (zero-padded h, h*s_in, sign images), 2 = the fused MFMA kernel, 4 = sparse fix-up + dh reduction, 8 = (split_fallback) the exact-f32 forward launch of a range fallback
 void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases = 7);
 // s_out != null: also the transposed s_out sign words the packed fp16x3 dW kernel reads (k_sign_words_T)
-void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 3, float h_scale = 1.f, const SignSpec* s_out = nullptr, int s_out_inj = 0, int which = 3);
+void launch_fused_prep_planes(hipStream_t st, int B, int H, int M, int bayes, void* ws, int np = 2, float h_scale = 1.f, const SignSpec* s_out = nullptr, int s_out_inj = 0, int which = 3);
 void launch_fused_out_dw(hipStream_t st, const FusedDw& f);
 // after a probs pass: ent_rows[i] += scale * the pass's entropy terms (nullable); transpose: P [B, M] = PT^T
 // unpack_inv_scale > 0: PT holds packed fp16 plane pairs (the fp16x3 step's dzT): P = (hi + lo) * unpack_inv_scale

@@ -381,7 +381,7 @@ struct OutFwd6Args {
     const uint16_t *mu_pl, *wp_pl;   // k_split_planes images of mu and Wp
     float pscale; int pacc;          // PROBS: dzT[c][i] (+)= sigmoid(leaky_relu(z)) * pscale; pacc: accumulate onto the previous MC passes
     int plogit;                      // PROBS: store the logit leaky_relu(z) itself instead (ntf_logits: the quantity the 1e-4 parity bar is stated on)
-    unsigned long long* stamps;           // diagnostics (k_out_fwd_h3x<.., ABL = 9>): per wave 8 cycle sums, see NTF_FWD_STAMP
+    unsigned long long* stamps;           // diagnostics (k_out_fwd_h3p<.., STAMP>, -DNTF_DIAG builds): per wave cycle sums
     float h_scale, dz_scale, u_z, u_dh;   // fp16x3 (NP = 2): scales applied to h / dz before their split, and 1/(w scale * h scale), 1/(dz scale * w scale); 1 for bf16x6
 };
 // fp16x3 training step: dzT holds, per element, the two fp16 planes of dz * dz_scale packed in one dword (hi | lo << 16) - the split the forward
@@ -677,481 +677,8 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
 }
 
 // ------------------------------------------------------------------------------------------------
-// Training forward (loss + dz + dh) of the fp16x3 step: 64-expert tiles = two 32-expert sub-tiles u, two LDS stages of 2 matrices x 2 planes x [64 rows][256 B]
-// (+ biases) = 2 x 64.5 KiB, everything else as in k_out_fwd_b6<.., NP = 2>.  A tile is four phases of 48 MFMAs - zT(u) = planes(u) . hT and dh += dz(u) . planes(u)
-// for u = 0, 1 - and ~1.1 k vector instructions of epilogue (bias, sign, leaky_relu, BCE, dz, its fp16 split and stores).  The phases are ROTATED ACROSS TILES so that
-// every one of them carries half an epilogue (round 2's kernel, phases in tile order, rode the vector work on the two middle phases only: ~11 vector instructions per
-// MFMA there, vector-bound at twice their MFMA time, while the outer two ran bare - retired in round 4, 0.82 against 0.70 ms):
-//   zT(0,t) | dh(1,t-1) | zT(1,t) | dh(0,t)        with the epilogue of sub-tile (1,t-1) over [dh(0,t-1), zT(0,t)] and of (0,t) over [dh(1,t-1), zT(1,t)]:
-// an epilogue needs its zT finished and must finish before its dh starts, which leaves it exactly those two phases.  Stage t-1 stays alive until dh(1,t-1)
-// is through (a barrier), then takes the DMA of tile t+1, issued one piece per MFMA group of zT(1,t).  dh accumulates the sub-tiles in the order (0,t-1), (1,t-1),
-// (0,t), ...; the first tile's "previous" sub-tile is a zero one (its dz planes are zero, its stores go to an empty buffer resource, its loss terms are masked).
-// The dz split needs no range clamp (|dz| <= max weight / B is scaled below 2^14 by construction) and takes its scale from the row constant; accumulators start from
-// the MFMA's zero operand instead of 64 register clears per tile.
-// ------------------------------------------------------------------------------------------------
-// ABL (-DNTF_DIAG builds only, NTF_FWD_ABL; results are wrong for ABL != 0, 9): 1 = no epilogue arithmetic, 2 = no epilogue at all (no splits, no dz stores), 3 = no MFMAs,
-// 9 = phase cycle stamps
-#ifndef H3X_PIPE
-#define H3X_PIPE 5
-#endif
-template <bool BAYES, bool INJ, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const OutFwdArgs& p = pp.a;
-    constexpr int H = 128, NJT = 4, NKS = H / 16, NP = 2, BNT = 64;
-    constexpr int PLANE = BNT * H * 2;          // 16 KiB
-    constexpr int TM = NP * PLANE;              // one matrix of a tile
-    constexpr int NMAT = BAYES ? 2 : 1;
-    constexpr int STAGE = NMAT * TM + 512;      // + two 64-float bias tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    const long long k_c0 = ABL == 9 ? clock64() : 0, k_w0 = ABL == 9 ? wall_clock64() : 0;
-    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) {
-        // an operand of this step left the fp16 window (raised where the operands are split): the step runs in exact f32 - the f32 kernel's body, same grid, same
-        // LDS size, here instead of a second launch that would exit at once in every other step (round 2: two no-op launches per step on the critical path)
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(p.rflag + 1, 1);
-        OutFwdArgs q = p; q.rmode = 0;
-        out_fwd_f32_body<128, BAYES, true, true, INJ>(q, smem);
-        return;
-    }
-
-    int bid = blockIdx.x;
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int cg = bid / p.NRB, rb = bid % p.NRB;
-    const int t_beg = (int)((int64_t)cg * p.T / p.NCG), t_end = (int)((int64_t)(cg + 1) * p.T / p.NCG);   // p.T = 64-expert tiles
-    const int i0 = rb * BM + wave * 32;
-    const int i = i0 + il;
-    const bool row_ok = i < p.B;
-
-    u32x4 hp[NKS][3];
-    uint32_t sinw[NJT];
-#pragma unroll
-    for (int w = 0; w < NJT; ++w)
-        sinw[w] = BAYES ? (INJ ? p.sinbits[(int64_t)i * NJT + w] : (row_ok ? sign_word(p.si_k0, p.si_k1, (uint32_t)i, (uint32_t)w) : 0u)) : 0u;
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half);   // p.h = zero-padded copy
-        const float4 v1 = *reinterpret_cast<const float4*>(p.h + (int64_t)i * H + 16 * s + 8 * half + 4);
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t pq[3];
-            split_pair_np<NP>(x[2 * q], x[2 * q + 1], pp.h_scale, pq);
-            hp[s][0][q] = pq[0]; hp[s][1][q] = pq[1]; hp[s][2][q] = 0u;
-        }
-    }
-    const float rmask = row_ok ? 1.f : 0.f;
-    const float rscale_pos = row_ok ? p.tnw * p.inv_B * pp.dz_scale : 0.f;    // dz * dz_scale = this * sigmoid(l)   (z > 0), ...
-    const float rscale_neg = rscale_pos * kLeakySlope;                         // ... * leaky slope                       (z <= 0)
-
-    const int fil = ((il & 3) << 2) | ((il >> 2) & 3);
-    int troff[2][NJT];                              // transposed read (rr, jt): rows 8*rr + 4*half + q (+ 16 per k-step, 32 per sub-tile as immediates)
-    {
-        const int gl = lane & 15, q = gl >> 2, pq = gl & 3, bsel = (lane >> 4) & 1;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                const int row = 8 * rr + 4 * half + q;
-                const int f = ((row & 3) << 2) | ((row >> 2) & 3);
-                troff[rr][jt] = 256 * row + 16 * ((4 * jt + 2 * bsel + (pq >> 1)) ^ f) + 8 * (pq & 1);
-            }
-    }
-
-    f32x16 Y1[NJT], Y2[NJT];
-#pragma unroll
-    for (int j = 0; j < NJT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { Y1[j][r] = 0.f; Y2[j][r] = 0.f; }
-    LossAcc lacc;
-
-    const uint32_t smem_base = lds_addr(smem);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    constexpr int PER_WAVE = TM / 1024 / 4;     // 1 KiB wave-instructions per wave per matrix
-    constexpr int NPIECE = NMAT * PER_WAVE + 1; // DMA pieces per wave and tile (+ the bias piece)
-    // DMA source offsets of this wave's PER_WAVE pieces of a matrix image (the same for mu and Wp, for every tile): bytes from the tile's first plane
-    uint32_t dsrc[PER_WAVE];
-#pragma unroll
-    for (int n = 0; n < PER_WAVE; ++n) {
-        const int inst = wave_u * PER_WAVE + n;
-        const int pos = inst * 1024 + lane * 16;            // destination inside the matrix image: plane, row (0..63), physical chunk
-        const int plane = pos / PLANE, row = (pos >> 8) & 63, chp = (pos >> 4) & 15;
-        const int ch = chp ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        // the planes are stored per 32-expert tile: [tile32][plane][32 rows][256 B]
-        dsrc[n] = (uint32_t)((((row >> 5) * (32 * NP) + plane * 32 + (row & 31)) * 256) + 16 * ch);
-    }
-    auto stage_piece = [&](int t, int buf, int n) {
-        const uint32_t sb = smem_base + buf * STAGE;
-        if (n < NMAT * PER_WAVE) {
-            const int mat = n / PER_WAVE, nn = n % PER_WAVE;
-            const int inst = wave_u * PER_WAVE + nn;
-            const char* base = reinterpret_cast<const char*>(mat ? pp.wp_pl : pp.mu_pl) + (size_t)t * (2 * 32 * NP * 256);    // wave-uniform: the tile's planes
-            glds16s(base, dsrc[nn], sb + mat * TM + inst * 1024);
-        } else {   // the two bias tiles, branch-free: even waves fetch mu_b's, odd waves bp's (twice each: the same bytes to the same place)
-            const int c0 = t * BNT;
-            const int which = BAYES ? (wave_u & 1) : 0;
-            glds4((which ? p.bp : p.mu_b) + min(c0 + lane, p.M - 1), sb + NMAT * TM + which * 256);
-        }
-    };
-    auto sign_words = [&](int t) -> uint2 {         // s_out signs of (row i, experts 64t .. 64t+63)
-        if (!BAYES || !row_ok) return make_uint2(0u, 0u);
-        if (INJ) return *reinterpret_cast<const uint2*>(p.sbits + (int64_t)i * p.nCB + 2 * t);
-        return make_uint2(sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t)), sign_word(p.so_k0, p.so_k1, (uint32_t)i, (uint32_t)(2 * t + 1)));
-    };
-    if (t_beg < t_end) {
-        // the first tile into BOTH stages: the zero "previous" sub-tile multiplies whatever stage 1 holds - it must be finite
-#pragma unroll
-        for (int n = 0; n < NPIECE; ++n) { stage_piece(t_beg, 0, n); stage_piece(t_beg, 1, n); }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // per-sub-tile state; index 1 is carried across iterations (sub-tile (1, t-1) is finished in iteration t)
-    f32x16 X1[2], X2[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { X1[1][r] = 0.f; X2[1][r] = 0.f; X1[0][r] = 0.f; X2[0][r] = 0.f; }
-    u32x4 ad[2][2][3];      // [u][k-step of 16 experts][plane]: fp16 planes of dz, the A operand of the dh products
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) ad[u][k][q] = u32x4{0u, 0u, 0u, 0u};
-    uint32_t swp = 0u;                  // s_out word of sub-tile (1, t-1), shifted by 4 * half
-    float rm_prev = 0.f, rsp_prev = 0.f, rsn_prev = 0.f;    // row constants of sub-tile (1, t-1): zero for the virtual one before the first tile
-    constexpr int dz_row_bytes = 128;   // dzT tile layout, see dzt_index
-    const int dz_voff = ((i >> 5) * 8192 + 4 * half * 32 + (i & 31)) * 4;
-    __amdgpu_buffer_rsrc_t rsrc_prev = __builtin_amdgcn_make_buffer_rsrc(p.dzT, 0, 0, 0x00020000);   // zero records: the virtual sub-tile's stores are dropped
-
-    constexpr int NHG = NKS * NMAT;     // half-groups (k-step, matrix) of one sub-tile's zT: 2 fragment reads + 3 MFMAs each
-    constexpr int NGD = 2 * NJT * NMAT; // groups (k-step of 16 experts, jt, matrix) of one sub-tile's dh: 4 transposed reads + 3 MFMAs each
-    static_assert(NHG == NGD, "the four phases have the same number of MFMA groups");
-    constexpr int NG = NHG, BG = 2;
-
-    // ---- pieces (all take the stage base of the tile they work on)
-    // LDS addresses: a per-lane base register (set once per tile) + a compile-time offset in the instruction (hipcc otherwise spends one vector add per read:
-    // 232 of the tile's ~930 vector instructions)
-    typedef const __attribute__((address_space(3))) char* ldsp_t;
-    int zrow[NKS];                                   // row read of k-step s: 256 * il + 16 * ((2 s + half) ^ fil)
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) zrow[s] = 256 * il + 16 * ((2 * s + half) ^ fil);
-    auto z_load = [&](const ldsp_t (&zb)[NKS], int u, int hg, u32x4 (&fr)[3]) {
-        const int s = hg / NMAT, mat = hg % NMAT;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) fr[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(zb[s] + (8192 * u + mat * TM + q * PLANE));
-    };
-    auto z_mma = [&](int u, int hg, const u32x4 (&fr)[3]) {
-        const int s = hg / NMAT, mat = hg % NMAT;
-        f32x16 zero;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-        if (ABL == 3) { asm volatile("" :: "v"(fr[0][0]), "v"(fr[1][3])); if (mat == 0) { if (s == 0) X1[u] = zero; asm volatile("" :: "v"(hp[s][0][0]), "v"(hp[s][1][3])); } else if (s == 0) X2[u] = zero; return; }
-        if (mat == 0) X1[u] = mfma_np<NP>(fr, hp[s], s == 0 ? zero : X1[u]);
-        else {
-            u32x4 hs[3];
-            const uint32_t w8 = sinw[s >> 1] >> (16 * (s & 1) + 8 * half);
-            u32x4 hm;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hm[q] = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) hs[q] = hp[s][q] ^ hm;
-            hs[2] = hm;
-            X2[u] = mfma_np<NP>(fr, hs, s == 0 ? zero : X2[u]);
-        }
-    };
-    // epilogue of register r of sub-tile u: lane = batch row i, register r <-> expert c0 + 32u + rowmap(r, half); leaves dz * dz_scale in X1[u][r]
-    // the biases of half an epilogue (8 registers = two runs of four experts, per matrix) are fetched at the START of the phase that carries it: a bias read inside
-    // the riders makes hipcc drain the whole LDS queue (lgkmcnt(0)) - the prefetched MFMA fragments included - once per register
-    auto load_bias = [&](const char* sb, int u, int hf, float (&bm)[8], float (&bq)[8]) {
-        const float* bias_mu = reinterpret_cast<const float*>(sb + NMAT * TM) + 4 * half + 32 * u + 16 * hf;
-        const float* bias_p = reinterpret_cast<const float*>(sb + NMAT * TM + 256) + 4 * half + 32 * u + 16 * hf;
-        const float4 m0 = *reinterpret_cast<const float4*>(bias_mu), m1 = *reinterpret_cast<const float4*>(bias_mu + 8);
-        bm[0] = m0.x; bm[1] = m0.y; bm[2] = m0.z; bm[3] = m0.w; bm[4] = m1.x; bm[5] = m1.y; bm[6] = m1.z; bm[7] = m1.w;
-        if (BAYES) {
-            const float4 q0 = *reinterpret_cast<const float4*>(bias_p), q1 = *reinterpret_cast<const float4*>(bias_p + 8);
-            bq[0] = q0.x; bq[1] = q0.y; bq[2] = q0.z; bq[3] = q0.w; bq[4] = q1.x; bq[5] = q1.y; bq[6] = q1.z; bq[7] = q1.w;
-        }
-    };
-    auto epilogue = [&](const float (&bm)[8], const float (&bq)[8], int u, int r, uint32_t swu, float rm, float rsp, float rsn, float& ltile) {
-        const int cr = 32 * u + (r & 3) + 8 * (r >> 2);
-        if (ABL == 1) { X1[u][r] = fmaf(X1[u][r], rsp, X2[u][r]); return; }
-        float z = fmaf(X1[u][r], pp.u_z, bm[r & 7]);
-        if (BAYES) z += __uint_as_float(__float_as_uint(fmaf(X2[u][r], pp.u_z, bq[r & 7])) ^ ((swu << (31 - (cr & 31))) & 0x80000000u));
-        const bool pos = z > 0.f;
-        const float l = pos ? z : z * kLeakySlope;
-        // (no clamp of l at -80 here: leaky_relu keeps a real logit above -0.01 |z|, and the experts past M are masked with a bias of -8000, i.e. l = -80, in this
-        //  kernel - what the clamp made of the other kernels' -1e30: e^80 is finite, softplus = dz = 0 to rounding)
-        const float tt = 1.f + __builtin_amdgcn_exp2f(l * -1.4426950408889634f);
-        ltile = fmaf(fmaf(__builtin_amdgcn_logf(tt), 0.6931471805599453f, l), rm, ltile);
-        X1[u][r] = __builtin_amdgcn_rcpf(tt) * (pos ? rsp : rsn);
-    };
-    // registers r0, r0 + 1 (r0 even) of sub-tile u -> fp16 planes (A operand of dh) + the packed store
-    auto split_pair_a = [&](int u, int r0, __amdgpu_buffer_rsrc_t rsrc) {
-        const uint32_t d0 = split_packed(X1[u][r0]), d1 = split_packed(X1[u][r0 + 1]);    // (no clamp: |dz| * dz_scale < 2^14)
-        ad[u][r0 >> 3][0][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);         // hi plane of the pair
-        ad[u][r0 >> 3][1][(r0 & 7) >> 1] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);         // lo plane
-        __builtin_amdgcn_raw_buffer_store_b32(d0, rsrc, dz_voff, (32 * u + (r0 & 3) + 8 * (r0 >> 2)) * dz_row_bytes, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(d1, rsrc, dz_voff, (32 * u + ((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2)) * dz_row_bytes, 0);
-    };
-    auto signed_a = [&](int u, int s2, uint32_t swu, u32x4 (&o)[3]) {   // planes of dz * s_out
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r0 = 8 * s2 + 2 * q, c0r = (r0 & 3) + 8 * (r0 >> 2);
-            const uint32_t m = (((swu << (31 - c0r)) & 0x80000000u) >> 16) | ((swu << (30 - c0r)) & 0x80000000u);
-            o[0][q] = ad[u][s2][0][q] ^ m; o[1][q] = ad[u][s2][1][q] ^ m;
-        }
-        o[2] = o[0];
-    };
-    auto tr_load = [&](const ldsp_t (&tb)[2][NJT], int u, int g, u32x4 (&bf)[3]) {   // g = (s2, jt, mat)
-        const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            constexpr int dummy = 0; (void)dummy;
-            const int o = 8192 * u + 4096 * s2 + q * PLANE + mat * TM;
-            const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[0][jt] + o)));
-            const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb[1][jt] + o)));
-            bf[q][0] = lo.x; bf[q][1] = lo.y; bf[q][2] = hi.x; bf[q][3] = hi.y;
-        }
-    };
-    auto d_mma = [&](int u, int g, uint32_t swu, const u32x4 (&bf)[3]) {
-        const int mat = g % NMAT, jt = (g / NMAT) % NJT, s2 = g / (NMAT * NJT);
-        if (ABL == 3) { asm volatile("" :: "v"(bf[0][0]), "v"(bf[1][3]), "v"(ad[u][s2][0][0]), "v"(ad[u][s2][1][3])); if (mat) { u32x4 asg[3]; signed_a(u, s2, swu, asg); asm volatile("" :: "v"(asg[0][0]), "v"(asg[1][3])); } return; }
-        if (mat == 0) Y1[jt] = mfma_np<NP>(ad[u][s2], bf, Y1[jt]);
-        else { u32x4 asg[3]; signed_a(u, s2, swu, asg); Y2[jt] = mfma_np<NP>(asg, bf, Y2[jt]); }
-    };
-    // half an epilogue (registers 8 hf .. 8 hf + 7 of sub-tile u) spread over the NG groups of a phase, TWO REGISTERS AT A TIME: a lone wave issues in order, and
-    // a vector instruction that needs the result of the one before it costs 8.4 cycles against 5.3 for an independent one (6.5 with two chains interleaved;
-    // profiles/probes/probe_valu.hip) - a register's epilogue is one such chain of ~17.  The pair (r0, r0 + 1) that is split together goes through four stages
-    // (logit | exp | log, loss, dz | split + store), stage by stage over both registers, a stage per group (two per group without Flipout).
-    constexpr int GPP = NG / 4;         // groups per register pair (4 with Flipout, 2 without)
-    constexpr int SPG = 4 / GPP;        // stages per group
-    float e_l[2] = {0.f, 0.f}, e_sel[2] = {0.f, 0.f}, e_tt[2] = {1.f, 1.f};     // the pair's state between its stages
-    auto ride = [&](const float (&bm)[8], const float (&bq)[8], int u, int hf, int g, uint32_t swu, float rm, float rsp, float rsn, __amdgpu_buffer_rsrc_t rsrc, float& ltile) {
-        if (ABL == 2) return;
-        const int r0 = 8 * hf + 2 * (g / GPP);
-#pragma unroll
-        for (int st = (g % GPP) * SPG; st < (g % GPP + 1) * SPG; ++st) {
-            if (ABL == 1) { if (st == 2) { X1[u][r0] = fmaf(X1[u][r0], rsp, X2[u][r0]); X1[u][r0 + 1] = fmaf(X1[u][r0 + 1], rsp, X2[u][r0 + 1]); } if (st == 3) split_pair_a(u, r0, rsrc); continue; }
-            if (st == 0) {          // logit: bias, s_out sign, leaky_relu; the factor of dz that depends on its branch
-                float z[2], y[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) z[j] = fmaf(X1[u][r0 + j], pp.u_z, bm[(r0 + j) & 7]);
-                if (BAYES) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) y[j] = fmaf(X2[u][r0 + j], pp.u_z, bq[(r0 + j) & 7]);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int cr = 32 * u + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2);
-                        y[j] = __uint_as_float(__float_as_uint(y[j]) ^ ((swu << (31 - (cr & 31))) & 0x80000000u));
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) z[j] += y[j];
-                }
-                // (no clamp of l at -80 here: leaky_relu keeps a real logit above -0.01 |z|, and the experts past M are masked with a bias of -8000, i.e. l = -80, in
-                //  this kernel - what the clamp made of the other kernels' -1e30: e^80 is finite, softplus = dz = 0 to rounding)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { const bool pos = z[j] > 0.f; e_l[j] = pos ? z[j] : z[j] * kLeakySlope; e_sel[j] = pos ? rsp : rsn; }
-            } else if (st == 1) {   // 1 + e^-l
-#pragma unroll
-                for (int j = 0; j < 2; ++j) e_tt[j] = e_l[j] * -1.4426950408889634f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) e_tt[j] = __builtin_amdgcn_exp2f(e_tt[j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) e_tt[j] += 1.f;
-            } else if (st == 2) {   // softplus(l) = log(1 + e^-l) + l into the row's loss; dz * dz_scale = sigmoid(l) * (row constant of the branch)
-                float lg[2], rc[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) lg[j] = __builtin_amdgcn_logf(e_tt[j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) rc[j] = __builtin_amdgcn_rcpf(e_tt[j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) lg[j] = fmaf(lg[j], 0.6931471805599453f, e_l[j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) X1[u][r0 + j] = rc[j] * e_sel[j];
-                ltile = fmaf(lg[0] + lg[1], rm, ltile);
-            } else split_pair_a(u, r0, rsrc);
-        }
-    };
-
-    // One phase = NG groups of 3 MFMAs in BUNDLES of BG: the fragments of a whole bundle (BG x 8 registers) are fetched while the previous bundle's 3 BG MFMAs run.
-    // kind 0: zT of sub-tile (u, this tile) from stage sb; kind 1: dh of sub-tile u from stage sb.  `extra(g)` = the vector work riding on group g.
-    u32x4 fb[2][BG][3];
-
-
-    // ABL == 9: cycle stamps (s_memtime) around the phases, summed per wave and written to pp.stamps (never part of a result)
-    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
-    auto stamp = [&](int slot) {
-        if (ABL != 9) return;
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long tnow;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (slot >= 0) st_sum[slot] += tnow - st_prev;
-        st_prev = tnow;
-    };
-    constexpr int NS0 = (BG + NMAT - 1) / NMAT;     // k-steps the first bundle of a tile touches
-    if (t_beg < t_end) {
-        ldsp_t zb0[NKS] = {};
-#pragma unroll
-        for (int s = 0; s < NS0; ++s) zb0[s] = (ldsp_t)(size_t)(smem_base + zrow[s]);
-#pragma unroll
-        for (int k = 0; k < BG; ++k) z_load(zb0, 0, k, fb[0][k]);
-    }
-    stamp(-1);
-    // the s_out words are fetched ONE TILE AHEAD: a lane reads its own row's words (64 cache lines per wave-instruction), and a load issued at the top of the
-    // tile that uses it puts an L2 round trip - and the drain of the previous phase's dzT stores, vmcnt being in order - in front of every tile
-    uint2 w2n = t_beg < t_end ? sign_words(t_beg) : make_uint2(0u, 0u);
-    for (int t = t_beg; t < t_end; ++t) {
-        const int buf = (t - t_beg) & 1;
-        const uint2 w2 = w2n;
-        w2n = sign_words(min(t + 1, t_end - 1));
-        char* sb = smem + buf * STAGE;
-        char* sbp = smem + (buf ^ 1) * STAGE;                 // stage of tile t - 1 (tile t_beg again in the first iteration)
-        const uint32_t sbase = lds_addr(sb), sbasep = lds_addr(sbp);
-        const int c0 = t * BNT;
-        const int tn = min(t + 1, t_end - 1);
-        if (c0 + BNT > p.M) {  // ragged last tile (workgroup-uniform): mask the experts past M through their bias
-            if (tid < BNT && c0 + tid >= p.M) reinterpret_cast<float*>(sb + NMAT * TM)[tid] = -8000.f;
-            __syncthreads();
-        }
-        const uint32_t sw[2] = {w2.x >> (4 * half), w2.y >> (4 * half)};
-        const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dzT + dzt_tile_base(c0, p.Bpad), 0, ((p.Bpad >> 5) * 8192 - ((c0 & 255) << 5)) * 4, 0x00020000);
-        float lt = 0.f;
-
-        // the four phases; each is its own fully unrolled loop over its NG / BG bundles (one loop over all 16 bundles exceeds the unroller's budget and
-        // leaves the fragment buffers in scratch).  The last bundle of a phase fetches the first bundle of the next one.
-        ldsp_t zb[NKS], tb[2][NJT], tbp[2][NJT];
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) zb[s] = (ldsp_t)(size_t)(sbase + zrow[s]);
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) { tb[rr][jt] = (ldsp_t)(size_t)(sbase + troff[rr][jt]); tbp[rr][jt] = (ldsp_t)(size_t)(sbasep + troff[rr][jt]); }
-        auto load_for = [&](int ph, int g, u32x4 (&dst)[3]) {
-            if (ph == 0) z_load(zb, 0, g, dst);             // zT(0, t)
-            else if (ph == 1) tr_load(tbp, 1, g, dst);      // dh(1, t-1) from the previous tile's stage
-            else if (ph == 2) z_load(zb, 1, g, dst);        // zT(1, t)
-            else tr_load(tb, 0, g, dst);                    // dh(0, t)
-        };
-        auto run_phase = [&](auto phc) {
-            constexpr int ph = decltype(phc)::value;
-            constexpr int NBP = NG / BG;
-            static_assert(NBP % 2 == 0, "the fragment double buffer keeps its parity across phases");
-            float bm[8], bq[8];
-            if (ph == 0) load_bias(sbp, 1, 1, bm, bq); else if (ph == 1) load_bias(sb, 0, 0, bm, bq); else if (ph == 2) load_bias(sb, 0, 1, bm, bq); else load_bias(sb, 1, 0, bm, bq);
-#pragma unroll
-            for (int lb = 0; lb < NBP; ++lb) {
-                if (lb + 1 < NBP) {
-#pragma unroll
-                    for (int k = 0; k < BG; ++k) load_for(ph, (lb + 1) * BG + k, fb[(lb + 1) & 1][k]);
-                } else if (ph < 3) {
-#pragma unroll
-                    for (int k = 0; k < BG; ++k) load_for(ph + 1, k, fb[0][k]);
-                } else {
-                    // the last bundle of the tile fetches the first bundle of the NEXT tile's zT(0): the DMA of tile t+1 (issued over phase 2) is older than
-                    // everything but the 6 dzT stores this phase has made so far - wait for it here, one bundle before the tile ends, instead of after it, where
-                    // the next tile's first fragments would then be read with no MFMA left to cover them (round 4: ~800 cycles a tile between the tiles)
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    ldsp_t zbn[NKS] = {};
-#pragma unroll
-                    for (int s = 0; s < NS0; ++s) zbn[s] = (ldsp_t)(size_t)(sbasep + zrow[s]);
-#pragma unroll
-                    for (int k = 0; k < BG; ++k) z_load(zbn, 0, k, fb[0][k]);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // the next bundle's fragment reads stay ABOVE this bundle's MFMAs (hipcc otherwise sinks them next to their uses)
-#pragma unroll
-                for (int k = 0; k < BG; ++k) {
-                    const int g = lb * BG + k;
-                    if (ph == 0) { z_mma(0, g, fb[lb & 1][k]); ride(bm, bq, 1, 1, g, swp, rm_prev, rsp_prev, rsn_prev, rsrc_prev, lt); }   // second half of the epilogue of (1, t-1)
-                    else if (ph == 1) { d_mma(1, g, swp, fb[lb & 1][k]); ride(bm, bq, 0, 0, g, sw[0], rmask, rscale_pos, rscale_neg, dz_rsrc, lt); }
-                    else if (ph == 2) {
-                        z_mma(1, g, fb[lb & 1][k]); ride(bm, bq, 0, 1, g, sw[0], rmask, rscale_pos, rscale_neg, dz_rsrc, lt);
-                        // stage t-1 is free since the barrier that closed phase 1.  Unconditional (a branch per piece would cut the phase into 16 basic blocks):
-                        // behind the last tile the free stage takes that tile once more
-                        if (g < NPIECE - 1) stage_piece(tn, buf ^ 1, g);                          // (one piece per group: two per group over half the phase cost +20 % of it)
-                        if (g == 0) stage_piece(tn, buf ^ 1, NPIECE - 1);
-                    }
-                    else { d_mma(0, g, sw[0], fb[lb & 1][k]); ride(bm, bq, 1, 0, g, sw[1], rmask, rscale_pos, rscale_neg, dz_rsrc, lt); }
-                }
-#if H3X_PIPE
-                // the bundle's order: one MFMA, then what rides in its shadow (32 cycles of matrix pipe, 8 of them holding the vector issue) - hipcc's own order
-                // clumps up to 45 vector instructions behind one MFMA and then issues six MFMAs bare
-#pragma unroll
-                for (int q = 0; q < 3 * BG; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, H3X_PIPE, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-                }
-#endif
-            }
-        };
-        stamp(0);
-        run_phase(std::integral_constant<int, 0>{});
-        stamp(1);
-        run_phase(std::integral_constant<int, 1>{});
-        stamp(2);
-        // dh(1, t-1) is through: every wave's reads of stage t-1 have returned (its MFMAs consumed them) - the stage may take tile t+1
-        __builtin_amdgcn_s_barrier();
-        stamp(3);
-        run_phase(std::integral_constant<int, 2>{});
-        stamp(4);
-        run_phase(std::integral_constant<int, 3>{});
-        stamp(5);
-        lacc.tile = lt; lacc.end_tile();
-        swp = sw[1]; rm_prev = rmask; rsp_prev = rscale_pos; rsn_prev = rscale_neg; rsrc_prev = dz_rsrc;
-        stamp(6);
-    }
-
-    if (t_beg < t_end) {
-        // ---- drain: second half of the epilogue of (1, last), then dh(1, last)
-        const int t = t_end - 1, buf = (t - t_beg) & 1;
-        const char* sb = smem + buf * STAGE;
-        const uint32_t sbase = lds_addr(sb);
-        float lt = 0.f;
-        float bm[8], bq[8];
-        load_bias(sb, 1, 1, bm, bq);
-#pragma unroll
-        for (int r = 8; r < 16; ++r) { epilogue(bm, bq, 1, r, swp, rm_prev, rsp_prev, rsn_prev, lt); if (r & 1) split_pair_a(1, r - 1, rsrc_prev); }
-        ldsp_t tbd[2][NJT];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) tbd[rr][jt] = (ldsp_t)(size_t)(sbase + troff[rr][jt]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { u32x4 bf[3]; tr_load(tbd, 1, g, bf); d_mma(1, g, swp, bf); }
-        lacc.tile = lt; lacc.end_tile();
-    }
-
-    float lsum = lacc.sum;
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (half == 0) p.lossp[(int64_t)i * p.NCG + cg] = p.tnw * lsum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int irow = i0 + rowmap(r, half);
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            float v = Y1[jt][r] * pp.u_dh;
-            if (BAYES) {
-                const uint32_t w = INJ ? p.sinbits[(int64_t)irow * NJT + jt] : sign_word(p.si_k0, p.si_k1, (uint32_t)irow, (uint32_t)jt);
-                const float y2 = Y2[jt][r] * pp.u_dh;
-                v += ((w >> il) & 1u) ? -y2 : y2;
-            }
-            p.slab[((int64_t)cg * p.Bpad + irow) * H + 32 * jt + il] = v;
-        }
-    }
-    if (ABL == 9 && pp.stamps && lane == 0) {   // per wave: 7 phase sums, tiles, shader-clock and 100 MHz wall-clock ticks from kernel entry to the loop's end and to the kernel's end
-        unsigned long long* o = pp.stamps + ((int64_t)blockIdx.x * 4 + wave) * 12;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = q == 7 ? (unsigned long long)(t_end - t_beg) : st_sum[q];
-        o[8] = (unsigned long long)(clock64() - k_c0); o[9] = (unsigned long long)(wall_clock64() - k_w0); o[10] = (unsigned long long)(st_prev - (unsigned long long)k_c0); o[11] = 0;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // k_out_fwd_h3p (round 4): the fp16x3 training forward as PRODUCER / CONSUMER WAVE PAIRS, two waves per SIMD.
-// k_out_fwd_h3x's lone wave per SIMD issues everything it does in order - 192 MFMAs (8 issue cycles each), ~860 vector instructions, ~210 LDS reads, 17 DMA
+// Round 3's one-wave form (k_out_fwd_h3x: 64-expert tiles, phases rotated across tiles; retired in round 6 - bit-identical dz / dh while both existed) issued everything in order - 192 MFMAs (8 issue cycles each), ~860 vector instructions, ~210 LDS reads, 17 DMA
 // pieces, 32 stores a tile: ~10.5 k cycles of issue against 6.1 k of matrix pipe, and the issue is what its 10.9 k cycles a tile are (without its MFMAs the
 // kernel takes 0.59 of its 0.71 ms, without its epilogue 0.57; re-ordering or trimming the vector work moves nothing).  Sixteen-row waves (round 3's k_out_fwd_h3y, retired in round 5) double
 // the LDS traffic and the MFMA issue instead.  Here the 32 rows of a wave pair stay together and the WORK is split:
@@ -1166,11 +693,11 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_h3x(OutFwd6Args pp) {
 // half of B's vector work riding on its first MFMAs, the roles on the other wave age, priorities per segment - cost 3 to 15 %: vector issue is arbitrated by
 // age, and two vector streams side by side starve the younger one's MFMAs).  Measured per step and wave (`-DNTF_DIAG`, NTF_FWD_ABL=9, profiles/r4_fwd_pair_stamps.txt):
 // A 535 (top, first fragments) + 1 820 (48 MFMAs + DMA) + 345 (4 stores) + 1 625 (logits); B 830 (top, hand-over and first fragment reads) + 1 280 (dz) + 2 200
-// (48 MFMAs beside A's vector work) = 4.7 k cycles a sub-tile against k_out_fwd_h3x's 5.5 k - 1.07 M cycles a wave at 1.65 GHz against 1.27 M at 1.76 (the package
+// (48 MFMAs beside A's vector work) = 4.7 k cycles a sub-tile against the one-wave kernel's 5.5 k - 1.07 M cycles a wave at 1.65 GHz against 1.27 M at 1.76 (the package
 // power limit gives a third of the saving back): 0.72 -> 0.65-0.67 ms on the same box.
 // LDS: a ring of three 32-expert stages (2 matrices x 2 planes x [32 rows][256 B] + biases = 32.5 KiB each: zT reads stage s, dh stage s-1, the DMA fills s+1)
-// + two hand-over slots of 16 KiB = 129.5 KiB.  Sub-tile order, MFMA order per accumulator, epilogue arithmetic and the packed dz are k_out_fwd_h3x's: dzT and
-// the dh slabs are bit-identical, the loss differs in the order of its sums.  An operand outside the fp16 window: the kernel returns (exact-f32 launch behind it).
+// + two hand-over slots of 16 KiB = 129.5 KiB.  Sub-tile order, MFMA order per accumulator, epilogue arithmetic and the packed dz are the one-wave kernel's (dzT and
+// the dh slabs were bit-identical to it, the loss differs in the order of its sums).  An operand outside the fp16 window: the kernel returns (exact-f32 launch behind it).
 // ------------------------------------------------------------------------------------------------
 template <bool BAYES, bool INJ, bool STAMP = false>      // STAMP (-DNTF_DIAG builds, NTF_FWD_ABL=9): cycle sums per wave and step segment into pp.stamps
 __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
@@ -1762,7 +1289,8 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     Geom g = geom(f.B, f.M);
     if (!f.train && f.H == 128) g.NCG = eval_ncg(g);      // forward-only launches: two workgroups per CU (k_out_fwd_b6)
     // the loss of an evaluation step in fp16x3 (round 6): k_out_fwd_h3e - 256-row workgroups of eight logit waves, one per CU.  NTF_EVAL_KERNEL=0: k_out_fwd_b6 (A/B runs, tests)
-    const bool evalp = f.eval_kernel && !f.train && !f.probs && f.bf16x6 && f.H == 128 && f.np == 2 && f.chunk_ncg_tot == 0;
+    // (Flipout only: with one matrix a sub-tile is 24 MFMAs against the same logit work, and the two workgroups per CU of k_out_fwd_b6 measured 0.309 against 0.317 ms a step)
+    const bool evalp = f.eval_kernel && (f.bayes || f.eval_kernel == 2) && !f.train && !f.probs && f.bf16x6 && f.H == 128 && f.np == 2 && f.chunk_ncg_tot == 0;
     const int nrbe = (g.Bpad + 255) / 256;
     if (evalp) g.NCG = std::max(1, std::min({NCG_MAX / nrbe, g.T, NCG_MAX}));
     if (f.ncg_limit > 0) g.NCG = std::max(1, std::min(g.NCG, f.ncg_limit));
@@ -1802,7 +1330,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
     const bool range_launch = ranged && f.chunk_ncg > 0 && (phases & 2);      // THIS call launches one range
     if (range_launch) { a.t_lo = f.chunk_t_lo; a.t_hi = f.chunk_t_hi; a.cg_off = f.chunk_cg_off; a.ncg_tot = f.chunk_ncg_tot; a.NCG = f.chunk_ncg; grid = g.NRB * f.chunk_ncg; }
     if (f.bf16x6 && f.H == 128) {
-        const int np = f.np == 2 ? 2 : 3;
+        constexpr int np = 2;
         if ((phases & 1) && !f.planes_ready) {
             const int64_t Mp = ((int64_t)f.M + BN6 - 1) / BN6 * BN6, n = Mp * (f.H / 2);
             hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f.mu, f.M, f.H, np, f.w_scale, f.mu_pl, guard ? f.rflag : nullptr);
@@ -1818,7 +1346,7 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
 #define NTF_L6N(BY, TR, DHF, IJ, PR, NPV) do { auto kf = k_out_fwd_b6<BY, TR, DHF, IJ, PR, NPV>;                               \
             set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);       \
             hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lds, st, a6); } while (0)
-#define NTF_L6(BY, TR, DHF, IJ, PR) do { if (np == 2) NTF_L6N(BY, TR, DHF, IJ, PR, 2); else NTF_L6N(BY, TR, DHF, IJ, PR, 3); } while (0)
+#define NTF_L6(BY, TR, DHF, IJ, PR) NTF_L6N(BY, TR, DHF, IJ, PR, 2)      /* (NP = 3, the bf16x6 arithmetic, is no longer instantiated: retired in round 6) */
 #define NTF_L6B(BY, IJ) do { if (f.probs) NTF_L6(BY, false, false, IJ, true); else if (!f.train) NTF_L6(BY, false, false, IJ, false);  \
                              else if (dh) NTF_L6(BY, true, true, IJ, false); else NTF_L6(BY, true, false, IJ, false); } while (0)
             if (evalp) {
@@ -1830,34 +1358,8 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                 if (f.bayes) { if (inj) NTF_LE(true, true); else NTF_LE(true, false); } else NTF_LE(false, false);
 #undef NTF_LE
             } else
-            if (np == 2 && f.train && dh && f.wide) {    // the fp16x3 training step: 64-expert tiles (a.T counts them already)
-                const size_t ldsw = 2 * ((size_t)(f.bayes ? 2 : 1) * 2 * 64 * 128 * 2 + 512);
-#define NTF_LXA(BY, IJ, AB) do { auto kf = k_out_fwd_h3x<BY, IJ, AB>;                                                                    \
-                set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsw);  \
-                hipLaunchKernelGGL(kf, dim3(grid), dim3(256), ldsw, st, a6); } while (0)
-#define NTF_LX(BY, IJ) NTF_LXA(BY, IJ, 0)
-#ifdef NTF_DIAG
-                static const int fwd_abl = getenv("NTF_FWD_ABL") ? atoi(getenv("NTF_FWD_ABL")) : 0;
-                if (f.wide != 5 && fwd_abl == 9 && f.bayes && !inj) {
-                    static unsigned long long* d_st = nullptr; static int n_launch = 0;
-                    if (!d_st) hipMalloc(&d_st, (size_t)grid * 4 * 12 * 8);
-                    a6.stamps = d_st;
-                    static const int rep = getenv("NTF_FWD_REPEAT") ? atoi(getenv("NTF_FWD_REPEAT")) : 1;    // the (idempotent) kernel several times back to back - its clock without the other kernels
-                    for (int r = 0; r < rep; ++r) NTF_LXA(true, false, 9);
-                    if (++n_launch == 30) {
-                        std::vector<unsigned long long> hst((size_t)grid * 48);
-                        hipStreamSynchronize(st); hipMemcpy(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost);
-                        double sum[12] = {0}; for (size_t w = 0; w < (size_t)grid * 4; ++w) for (int q = 0; q < 12; ++q) sum[q] += (double)hst[w * 12 + q];
-                        fprintf(stderr, "[fwd stamps] per wave, kernel entry to exit: %.0f shader-clock cycles in %.0f ticks of 100 MHz = %.3f GHz, %.3f ms; entry to end of the tile loop %.0f cycles\n",
-                                sum[8] / (grid * 4.0), sum[9] / (grid * 4.0), sum[8] / (sum[9] * 10.0), sum[9] / (grid * 4.0) / 1e5, sum[10] / (grid * 4.0));
-                        fprintf(stderr, "[fwd stamps] cycles per tile and wave: load0 %.0f | ph0 %.0f | ph1 %.0f | barrier %.0f | ph2 %.0f | ph3 %.0f | wait+barrier %.0f  (tiles/wave %.1f)\n",
-                                sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7], sum[7] / (grid * 4.0));
-                    }
-                }
-                else if (f.wide != 5 && fwd_abl && f.bayes && !inj) { if (fwd_abl == 1) NTF_LXA(true, false, 1); else if (fwd_abl == 2) NTF_LXA(true, false, 2); else NTF_LXA(true, false, 3); }
-                else
-#endif
-                if (f.wide == 5) {      // producer / consumer wave pairs, two waves per SIMD (NTF_FWD_KERNEL=5)
+            if (np == 2 && f.train && dh && f.wide == 5) {    // the fp16x3 training step: producer / consumer wave pairs, two waves per SIMD (a.T counts 64-expert tiles)
+                {
                     const size_t ldsp = 3 * ((size_t)(f.bayes ? 2 : 1) * 2 * 32 * 128 * 2 + 512) + 2 * 16384;
 #define NTF_LP(BY, IJ) do { auto kf = k_out_fwd_h3p<BY, IJ>;                                                                    \
                 set_max_lds(reinterpret_cast<const void*>(kf), (int)ldsp);  \
@@ -1892,20 +1394,16 @@ void launch_fused_out_fwd(hipStream_t st, const FusedOut& f, int phases) {
                     if (f.bayes) { if (inj) NTF_LP(true, true); else NTF_LP(true, false); } else NTF_LP(false, false);
 #undef NTF_LP
                 }
-                else { if (f.bayes) { if (inj) NTF_LX(true, true); else NTF_LX(true, false); } else NTF_LX(false, false); }
-#undef NTF_LX
-#undef NTF_LXA
             } else if (f.bayes) { if (inj) NTF_L6B(true, true); else NTF_L6B(true, false); } else NTF_L6B(false, false);
 #undef NTF_L6B
 #undef NTF_L6
 #undef NTF_L6N
-            const bool merged_fallback = np == 2 && f.train && dh && f.wide != 0 && f.wide != 5;   // k_out_fwd_h3x runs the f32 body itself when the flag is raised
 #ifdef NTF_DIAG
             static const bool skip_fb = getenv("NTF_SKIP_FALLBACK") != nullptr;     // timing only: what the conditional exact-f32 launch behind k_out_fwd_h3p costs
 #else
             constexpr bool skip_fb = false;
 #endif
-            if (guard && np == 2 && !f.probs && !merged_fallback && !skip_fb && !f.split_fallback && !range_launch) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
+            if (guard && np == 2 && !f.probs && !skip_fb && !f.split_fallback && !range_launch) {   // the same pass on the exact-f32 kernel, run only when an operand left the fp16 window
                 OutFwdArgs af = a; af.rmode = 2;
                 if (f.bayes) fwd_dispatch<128, true>(st, f, af, s, grid, 2); else fwd_dispatch<128, false>(st, f, af, s, grid, 2);
             }

@@ -1,9 +1,9 @@
 // Weight-gradient side of the fused output layer for gfx950 (split from ntf_fused.hip in round 4): dmu = dzT . h, dWp = (dzT * s_out) . (h * s_in) with K = batch, the
 // Flipout rho-gradient + KL, Adam in place and the NEXT step's Flipout operands in the epilogue.
 //   k_out_dw          exact-f32 MFMA (v_mfma_f32_32x32x2_f32); k_out_dw_fallback: the same as the range fallback behind a split-product kernel
-//   k_out_dw_b6       bf16x6 / fp16x3 split products on f32 dz (H = 32, 64, 128)
-//   k_out_dw_p2       fp16x3 on the forward kernel's packed dz planes, one 256-expert workgroup per CU (round 2-3 default; split-K form for narrow expert shards)
-//   k_out_dw_q        the same products as two 128-expert workgroups per CU, one's epilogue beside the other's main loop (round 4 default)
+//   k_out_dw_b6       fp16x3 split products on f32 dz (H = 32, 64; H = 128 without the packed forward kernel)
+//   k_out_dw_q        fp16x3 on the forward kernel's packed dz planes: two 128-expert workgroups per CU, one's epilogue beside the other's main loop; <.., SPLIT>: a K range
+//                     per workgroup for narrow expert shards.  (Round 2-3's one-workgroup-per-CU form k_out_dw_p2 - bit-identical sums - was retired in round 6)
 //   k_out_dw_finish   sum of split-K partial slabs + the epilogue
 // plus the operand images these kernels read: K-block-tiled planes of h (k_prep_planes_T), transposed s_out / s_in sign words (k_sign_words_T, k_sin_words_T).
 #include "ntf_fused_common.h"
@@ -27,11 +27,11 @@ struct DwArgs {
     const uint32_t* sinT;    // k_sin_words_T image: s_in signs of (K block, hidden unit) over the block's 32 rows (k_out_dw_q)
     const uint16_t* hb;   // split planes of h / h*s_in (k_prep_planes_T)
     float a_scale, unscale;   // fp16x3: dz is scaled by a_scale before its split; accumulators are multiplied by unscale = 1 / (a_scale * h scale)
-    // split-K (k_out_dw_p2 only): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
+    // split-K (k_out_dw_q<.., SPLIT>): few expert tiles (a narrow expert shard under a wide minibatch) are launched ksplit times, each workgroup summing a
     // contiguous part of the K blocks into part[(split * 2 + matrix) * slab ..] (bias sums behind the slabs); k_out_dw_finish adds the parts and runs the epilogue
     int ksplit; float* part; int64_t slab; int part_row0;   // part_row0: first expert of the launched tile range - the slabs hold that range only
     unsigned long long* stamps;   // diagnostics (k_out_dw_q<.., STAMP>, NTF_DW_STAMP_FILE)
-    int ntile, stagger;   // k_out_dw_p2, unsplit: expert tiles of this launch (walked by persistent workgroups), start delay of every second workgroup (100 MHz ticks)
+    int ntile, stagger;   // k_out_dw_q, unsplit: expert tiles of this launch (walked by persistent workgroups), start delay of every second workgroup (100 MHz ticks)
     // produce != 0 (fused Adam, Flipout, fp16x3 planes): the epilogue holds the UPDATED mu' / rho' of its elements - it also is the next step's operand producer:
     // eps' (Philox keyed by step + 1), Wp' = softplus(rho') eps' (f32, in place over this step's Wp), the fp16 split planes of Wp' and mu' that the forward kernel
     // streams, the layer's KL' and fp16 range flag of the next step.  Saves k_flipout_perturb's own pass over the layer (0.72 GB, 0.12 ms at config 2) and takes
@@ -565,171 +565,6 @@ __global__ __launch_bounds__(256) void k_out_dw_finish(DwArgs p) {
     if (produce) { __shared__ double red[4]; dw_produce_finish<BAYES>(p, nx_kl, nx_amax, red, 4); }
 }
 
-// dW of the fp16x3 training step (H = 128).  Same tiling as k_out_dw_b6 (8 waves x 32 experts, K = batch in 32-row blocks, two LDS stages by LDS-DMA),
-// but the A operand arrives READY: dzT holds the two fp16 planes of dz * scale packed per element by the forward kernel, so a lane's fragment is two
-// ds_read_b128 + eight v_perm_b32 instead of an f32 split (the round-1 kernel spent a third of its time on that vector work: with MFMAs, DMA and
-// epilogue ablated it still took 0.20 of 0.63 ms); the s_out words come transposed from k_sign_words_T (one ds_read_b32 per K block instead of a
-// hash + five shuffle stages); the bias gradients are v_dot2_f32_f16 sums over the plane registers.
-// Since round 4 the unsplit launch of a whole step runs k_out_dw_q (below); this kernel stays as its A/B form (NTF_DW_KERNEL=0) and as the split-K kernel of narrow
-// expert shards.  (Round 3's persistent-grid / staggered-start / phase-stamp variants of it measured no gain and are gone: DESIGN.md section 4.)
-template <bool BAYES, bool ADAM>
-__global__ __launch_bounds__(64 * DW_WAVES, 2) void k_out_dw_p2(DwArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int H = 128, NJT = 4, NP = 2;
-    constexpr int NPL = (BAYES ? 2 : 1) * NP;
-    constexpr int TA = DW_TC * 32 * 4;            // packed dz tile [256 experts][32 rows] dwords, 16-byte chunks XOR-swizzled ((row>>1)&7)
-    constexpr int PLANE = H * 64;                 // [H][32 rows] fp16
-    constexpr int TB = NPL * PLANE;
-    constexpr int TS = BAYES ? DW_TC * 4 : 0;     // s_out words of the tile's experts for this K block
-    constexpr int STAGE = TA + TB + TS;
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, half = lane >> 5;
-    const bool split = p.ksplit > 1;
-    if (p.rmode == 1 && __builtin_nontemporal_load(p.rflag) != 0) {
-        // the step runs in exact f32 (see k_out_fwd_h3x): the f32 kernel's body for this tile, here; the split-K form leaves it to the launch behind the finish kernel
-        if (!split) { DwArgs q = p; q.rmode = 0; out_dw_f32_body<128, BAYES, ADAM>(q, smem); }
-        return;
-    }
-    const int ntile = split ? (int)gridDim.x / p.ksplit : (int)gridDim.x;
-    const int ksi = split ? (int)blockIdx.x / ntile : 0;                  // which K range (the splits of one tile sit ntile workgroups apart)
-    const int tile = split ? (int)blockIdx.x % ntile : (int)blockIdx.x;
-    const int crow = wave * 32 + il;
-    const int nib = p.Bpad / 32;
-    const int ib0 = split ? (int)((int64_t)ksi * nib / p.ksplit) : 0, ib1 = split ? (int)((int64_t)(ksi + 1) * nib / p.ksplit) : nib;
-    const uint32_t smem_base = lds_addr(smem);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const char* hb = reinterpret_cast<const char*>(p.hb);
-
-    const h2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
-    constexpr int NA = TA / 1024 / DW_WAVES, NB = (TB / 1024 + DW_WAVES - 1) / DW_WAVES;   // DMA pieces per wave: 4 of the dz tile, 2 or 4 of the planes
-    auto stage_piece = [&](int c0, int ib, int buf, int n) {      // piece n of this wave's NA + NB (+ the sign words with the last piece)
-        const uint32_t sb = smem_base + buf * STAGE;
-        if (n < NA) {
-            const float* src_a = p.dzT + ((int64_t)(c0 >> 8) * nib + ib) * 8192;   // contiguous 32 KiB
-            const int inst = wave_u * NA + n;
-            const int row = inst * 8 + (lane >> 3), pch = lane & 7;
-            const int q = pch ^ ((row >> 1) & 7);
-            glds16(src_a + row * 32 + 4 * q, sb + inst * 1024);
-        } else {
-            const char* src = hb + (size_t)ib * TB;
-            static_assert((TB / 1024) % DW_WAVES == 0, "every wave moves the same number of plane pieces");
-            const int inst = wave_u * NB + (n - NA);
-            const int pos = inst * 1024 + lane * 16;
-            const int j = (pos % PLANE) >> 6, cd = (pos >> 4) & 3;
-            glds16(src + (pos & ~63) + 16 * (cd ^ ((j >> 2) & 3)), sb + TA + inst * 1024);
-            // the tile's 1 KiB of s_out words: fetched by EVERY wave (the same bytes to the same place) - a wave-uniform branch here splits the K block's body
-            if (BAYES && n == NA + NB - 1) glds16(p.sT + ((int64_t)(c0 >> 8) * nib + ib) * 256 + lane * 4, sb + TA + TB);
-        }
-    };
-    auto stage = [&](int c0, int ib, int buf) {
-#pragma unroll
-        for (int n = 0; n < NA + NB; ++n) stage_piece(c0, ib, buf, n);
-    };
-    float nx_kl = 0.f, nx_amax = 0.f;
-    const int c0 = (p.wg_begin + tile) * DW_TC;
-    stage(c0, ib0, 0);
-    const int c = c0 + crow;
-    f32x16 acc1[NJT], acc2[NJT];
-#pragma unroll
-    for (int j = 0; j < NJT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc1[j][r] = 0.f; acc2[j][r] = 0.f; }
-    float sum1 = 0.f, sum2 = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // one K block; MORE: the next K block's DMA rides on the first MFMA groups.  (Round 3: a compile-time flag and two call sites instead of a run-time test per DMA
-    // piece, and no run-time ablation switches: they cut the unrolled body into ~40 basic blocks that hipcc could not schedule across)
-    auto k_block = [&](int ib, auto more_c) {
-        constexpr bool MORE = decltype(more_c)::value;
-        const int buf = (ib - ib0) & 1;
-        const char* sA = smem + buf * STAGE;
-        const char* sB = sA + TA;
-        uint32_t word = 0u;
-        if (BAYES) word = *reinterpret_cast<const uint32_t*>(sA + TA + TB + crow * 4);
-        constexpr int NHG = 2 * NJT * (BAYES ? 2 : 1);
-        const char* bbase = sB + il * 64;
-        const int swz = (il >> 2) & 3;
-        auto load_b = [&](int hg, u32x4 (&dst)[3]) {
-            const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT, jt = g % NJT;
-            const char* bp = bbase + jt * 2048 + 16 * ((2 * ks + half) ^ swz) + which * NP * PLANE;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) dst[q] = *reinterpret_cast<const u32x4*>(bp + q * PLANE);
-        };
-        u32x4 a[2][3], as[2][3];
-        auto prep_a = [&](int ks) {      // rows 16 ks + 8 half .. + 7 of this lane's expert: 8 packed dwords -> the hi and the lo plane fragment
-            const int ch = 4 * ks + 2 * half, sw = (crow >> 1) & 7;
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(sA + crow * 128 + 16 * (ch ^ sw));
-            const u32x4 hi = *reinterpret_cast<const u32x4*>(sA + crow * 128 + 16 * ((ch + 1) ^ sw));
-            const uint32_t x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const uint32_t w8 = word >> (ks * 16 + half * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t p1 = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x05040100u), p2 = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x07060302u);
-                a[ks][0][q] = p1; a[ks][1][q] = p2; a[ks][2][q] = 0u;
-                sum1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, p1), ones, sum1, false);
-                sum1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, p2), ones, sum1, false);
-                if (BAYES) {
-                    const uint32_t m = ((w8 << (15 - 2 * q)) & 0x8000u) | ((w8 << (30 - 2 * q)) & 0x80000000u);
-                    const uint32_t s1 = p1 ^ m, s2 = p2 ^ m;
-                    as[ks][0][q] = s1; as[ks][1][q] = s2; as[ks][2][q] = 0u;
-                    sum2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, s1), ones, sum2, false);
-                    sum2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, s2), ones, sum2, false);
-                }
-            }
-        };
-        u32x4 bq[2][3];
-        load_b(0, bq[0]);
-        prep_a(0);
-#pragma unroll
-        for (int hg = 0; hg < NHG; ++hg) {
-            if (hg + 1 < NHG) load_b(hg + 1, bq[(hg + 1) & 1]);
-            asm volatile("" ::: "memory");
-            const int which = BAYES ? (hg & 1) : 0, g = BAYES ? (hg >> 1) : hg, ks = g / NJT;
-            const int jt = g % NJT;
-            if (which) acc2[jt] = mfma_np<NP>(as[ks], bq[hg & 1], acc2[jt]);
-            else acc1[jt] = mfma_np<NP>(a[ks], bq[hg & 1], acc1[jt]);
-            if (hg == (NHG / 2 > 1 ? 1 : 0)) prep_a(1);
-            // the next K block's DMA, one piece per half-group: a burst of 8-9 LDS-DMA issues in one gap stalls the wave's own MFMA stream
-            if (MORE) {   // NTF_DW_BURST (experiment): pieces per MFMA group
-                constexpr int PPG = DW_PPG;
-                if (hg * PPG < NA + NB) {
-#pragma unroll
-                    for (int q = 0; q < PPG; ++q) if (hg * PPG + q < NA + NB) stage_piece(c0, ib + 1, buf ^ 1, hg * PPG + q);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-    for (int ib = ib0; ib < ib1 - 1; ++ib) k_block(ib, std::true_type{});
-    k_block(ib1 - 1, std::false_type{});
-    sum1 += __shfl_xor(sum1, 32, 64);
-    sum2 += __shfl_xor(sum2, 32, 64);
-    const float inv_a = 1.f / p.a_scale;
-    if (half == 0 && c < p.M) {
-        if (split) {
-            float* pb = p.part + (int64_t)p.ksplit * 2 * p.slab; const int64_t Mp = p.slab / 128; const int cl = c - p.part_row0;
-            pb[(int64_t)(ksi * 2) * Mp + cl] = sum1 * inv_a; if (BAYES) pb[(int64_t)(ksi * 2 + 1) * Mp + cl] = sum2 * inv_a;
-        } else { p.g_b[c] = sum1 * inv_a; if (BAYES) p.g_bp[c] = sum2 * inv_a; }
-    }
-
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cr = c0 + wave * 32 + rowmap(r, half);
-        if (cr >= p.M) continue;
-        const int64_t idx0 = (int64_t)cr * H + NJT * il;      // NJT consecutive hidden units per lane, see k_out_dw_b6
-        float s1[NJT], s2[NJT];
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) { s1[jt] = acc1[jt][r] * p.unscale; s2[jt] = acc2[jt][r] * p.unscale; }
-        if (split) {   // raw partial sums of this K range; k_out_dw_finish adds the ranges and finalises
-            const int64_t il0 = idx0 - (int64_t)p.part_row0 * H;
-            st_vec<NJT>(p.part + (int64_t)(ksi * 2) * p.slab + il0, s1);
-            if (BAYES) st_vec<NJT>(p.part + (int64_t)(ksi * 2 + 1) * p.slab + il0, s2);
-        } else dw_finish_vec<BAYES, ADAM, NJT>(p, idx0, s1, s2, nx_kl, nx_amax);
-    }
-    if (ADAM && !split && p.produce) dw_produce_finish<BAYES>(p, nx_kl, nx_amax, reinterpret_cast<double*>(smem + 2 * STAGE), DW_WAVES);   // (scratch behind the stages)
-}
-
 // ------------------------------------------------------------------------------------------------
 // s_in sign words of the dW kernel k_out_dw_q: sinT[K block ib][hidden unit j] = the signs of (batch rows 32 ib .. 32 ib + 31, j), in the bit order that kernel's B
 // fragments take their masks from - the fragment (k step ks, lane half hf) of a hidden unit holds rows 8 g .. 8 g + 7, g = 2 ks + hf, dword q = rows 8 g + 2 q (low
@@ -1018,7 +853,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
     if (f.bf16x6 && f.np == 2 && f.dz_packed) {   // fp16x3 step, H = 128: the forward kernel left packed plane pairs in dzT
         a.a_scale = f.a_scale; a.unscale = 1.f / (f.a_scale * f.h_scale); a.rmode = guard ? 1 : 0;
         const int ks = (f.ksplit > 1 && f.part) ? std::min(f.ksplit, std::max(1, g.Bpad / 32)) : 1;
-        if (ks > 1 && f.kernel == 1) {   // ... on half-tile workgroups, two per CU (k_out_dw_q<.., SPLIT>): the narrow expert shards' launch since round 5
+        if (ks > 1) {   // few expert tiles (a narrow expert shard under a wide minibatch): every half-tile's K range split over ks workgroups (k_out_dw_q<.., SPLIT>), k_out_dw_finish adds the parts and runs the epilogue
             a.sinT = reinterpret_cast<const uint32_t*>(ws + w.sinT);
             const int total_q = (f.M + QTC - 1) / QTC, qb = f.wg_count > 0 ? 2 * f.wg_begin : 0;
             const int qgrid = f.wg_count > 0 ? std::min(2 * f.wg_count, total_q - qb) : total_q;
@@ -1037,21 +872,7 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
             a.rmode = 2; a.ksplit = 1; a.wg_begin = wg256; a.part_row0 = 0;
             goto exact_f32;
         }
-        if (ks > 1) {   // few expert tiles (a narrow shard, or the tail of a whole layer): every tile's K range is split over ks workgroups, k_out_dw_finish adds the parts and runs the epilogue
-            a.ksplit = ks; a.part = f.part; a.slab = (int64_t)grid * DW_TC * 128; a.part_row0 = a.wg_begin * DW_TC;      // slabs over the launched tile range only
-            const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0));
-            const int64_t nq = (int64_t)grid * DW_TC * 128 / 4;
-#define NTF_DWS(BY, AD) do { auto kf = k_out_dw_p2<BY, false>;                                                                  \
-            set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);      \
-            hipLaunchKernelGGL(kf, dim3(grid * ks), dim3(64 * DW_WAVES), lds, st, a);                                          \
-            hipLaunchKernelGGL((k_out_dw_finish<BY, AD>), dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, a); } while (0)
-            if (f.bayes) { if (f.adam) NTF_DWS(true, true); else NTF_DWS(true, false); } else { if (f.adam) NTF_DWS(false, true); else NTF_DWS(false, false); }
-#undef NTF_DWS
-            if (!guard || f.no_fallback) return;
-            a.rmode = 2; a.ksplit = 1;
-            goto exact_f32;
-        }
-        if (f.kernel == 1) {   // two half-tile workgroups per CU, the epilogue of one beside the main loop of the other (k_out_dw_q)
+        {   // two half-tile workgroups per CU, the epilogue of one beside the main loop of the other (k_out_dw_q)
             a.sinT = reinterpret_cast<const uint32_t*>(ws + w.sinT);
             const int total_q = (f.M + QTC - 1) / QTC, qb = f.wg_count > 0 ? 2 * f.wg_begin : 0;
             const int qgrid = f.wg_count > 0 ? std::min(2 * f.wg_count, total_q - qb) : total_q;
@@ -1091,22 +912,15 @@ void launch_fused_out_dw(hipStream_t st, const FusedDw& f) {
             a.rmode = 2; a.wg_begin = wg256; a.ntile = 0; a.stagger = 0;   // the exact-f32 kernel behind it runs only when the range flag is raised
             goto exact_f32;
         }
-        const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(f.bayes ? 2 : 1) * 2 * 128 * 64 + (f.bayes ? DW_TC * 4 : 0)) + 64;
-#define NTF_DWP(BY, AD) do { auto kf = k_out_dw_p2<BY, AD>;                                                                    \
-        set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);          \
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
-        if (f.bayes) { if (f.adam) NTF_DWP(true, true); else NTF_DWP(true, false); } else { if (f.adam) NTF_DWP(false, true); else NTF_DWP(false, false); }
-#undef NTF_DWP
-        return;   // (one tile per workgroup: the kernel runs the f32 body itself when the range flag is raised)
     }
     if (f.bf16x6) {
-        const int np = f.np == 2 ? 2 : 3;
+        constexpr int np = 2;
         a.rmode = guard ? 1 : 0;
         a.a_scale = np == 2 ? f.a_scale : 1.f; a.unscale = np == 2 ? 1.f / (f.a_scale * f.h_scale) : 1.f;
 #define NTF_DWB2(HH, BY, AD, NPV) do { auto kf = k_out_dw_b6<HH, BY, AD, NPV>; const size_t lds = 2 * ((size_t)DW_TC * 128 + (size_t)(BY ? 2 : 1) * NPV * HH * 64); \
         set_max_lds(reinterpret_cast<const void*>(kf), (int)lds);                                      \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * DW_WAVES), lds, st, a); } while (0)
-#define NTF_DWB1(HH, BY, AD) do { if (np == 2) NTF_DWB2(HH, BY, AD, 2); else NTF_DWB2(HH, BY, AD, 3); } while (0)
+#define NTF_DWB1(HH, BY, AD) NTF_DWB2(HH, BY, AD, 2)
 #define NTF_DWB(HH) do { if (f.bayes) { if (f.adam) NTF_DWB1(HH, true, true); else NTF_DWB1(HH, true, false); }                                            \
                          else { if (f.adam) NTF_DWB1(HH, false, true); else NTF_DWB1(HH, false, false); } } while (0)
         if (f.H == 128) NTF_DWB(128); else if (f.H == 64) NTF_DWB(64); else NTF_DWB(32);

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
                 ov[j] = sigma * z[j];
                 if (mu) kl += -ls + 0.5f * (sigma * sigma + mv[j] * mv[j]) - 0.5f;
             }
-            *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            if (out) *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);      // (null: the planes alone - a lean evaluation step; a range fallback makes the f32 copy itself)
             if (planes_w) {   // H % 4 == 0: the quad lies in one row
                 const int64_t row = e0 / H; const int j = (int)(e0 - row * H);
                 const float4 m4 = planes_mu ? *reinterpret_cast<const float4*>(pmu + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
         } else {
             for (int j = 0; j < 4 && e0 + j < n; ++j) {
                 const float sigma = softplus_rho(rho[e0 + j]);
-                out[e0 + j] = sigma * z[j];
+                if (out) out[e0 + j] = sigma * z[j];
                 if (mu) { const float m = mu[e0 + j]; kl += -logf(sigma) + 0.5f * (sigma * sigma + m * m) - 0.5f; }
             }
         }

@@ -74,6 +74,9 @@ class CollectiveTrace:
 
     def __init__(self, who, stream_ordered=None):
         self.who, self.ring, self.issued = who, collections.deque(maxlen=256), 0
+        # measure_waits (bench.py's instrumented pass, never the timed regions): an event pair around every stream-ordered wait - the stream does nothing between the two but
+        # wait for the collective, so their distance IS the exposed wait of that collective class ('reduce_scatter', 'all_reduce', 'all_gather'); read by exposed_waits()
+        self.measure_waits, self._wait_events, self._labels = False, [], {}
         if stream_ordered is None:
             stream_ordered = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
         self.stream_ordered = bool(stream_ordered)
@@ -81,7 +84,17 @@ class CollectiveTrace:
     def add(self, label, work):
         self.issued += 1
         self.ring.append((self.issued, label, work))
+        if self.measure_waits: self._labels[id(work)] = label
         return work
+
+    def exposed_waits(self):
+        """{collective class: total ms the stream sat waiting for it} since measure_waits was set; clears the record (synchronises the device)"""
+        out = {}
+        if self._wait_events: torch.cuda.synchronize()
+        for cls, e0, e1 in self._wait_events:
+            out[cls] = out.get(cls, 0.0) + e0.elapsed_time(e1)
+        self._wait_events, self._labels = [], {}
+        return out
 
     def describe(self):
         done = next((f"#{n} {lab}" for n, lab, w in reversed(self.ring) if _completed(w)), "none of the last %d" % len(self.ring))
@@ -90,8 +103,15 @@ class CollectiveTrace:
 
     def wait(self, work):
         if self.stream_ordered:
+            ev = None
+            if self.measure_waits and torch.cuda.is_available():
+                label = self._labels.pop(id(work), "")
+                cls = next((c for c in ("reduce_scatter", "all_gather", "all_reduce") if c in label), "other")
+                ev = (cls, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[1].record()
             try:
                 work.wait()      # orders the current stream behind the collective; the host does not block (a hang surfaces in `sync`, bounded)
+                if ev: ev[2].record(); self._wait_events.append(ev)
             except RuntimeError as ex:      # an RCCL error raised at the wait (communicator aborted, a peer gone) keeps the contract: a naming message, a non-zero exit
                 raise CollectiveTimeout(f"{self.who}: {type(ex).__name__}: {ex} [{self.describe()}]") from ex
             return

@@ -180,7 +180,8 @@ class Engine:
             cfg.dims[i] = d
         cfg.bayesian, cfg.input_mode, cfg.max_batch = int(self.bayesian), int(input_mode), self.max_batch
         cfg.ns, cfg.nsd, cfg.tpw, cfg.tnw, cfg.lr, cfg.seed, cfg.fused = max(self.ns, 0), NSD[nsd], float(tpw), float(tnw), float(lr), int(seed) & (2**64 - 1), int(bool(fused))
-        cfg.mfma = {None: 0, "default": 0, "f32": 1, "bf16x6": 2, "fp16x3": 3}[mfma] if not isinstance(mfma, int) or isinstance(mfma, bool) else int(mfma)
+        if mfma == "bf16x6": raise ValueError("mfma='bf16x6' was retired in round 6 (fp16x3, the default, has its accuracy at half the matrix work); use None or 'f32'")
+        cfg.mfma = {None: 0, "default": 0, "f32": 1, "fp16x3": 3}[mfma] if not isinstance(mfma, int) or isinstance(mfma, bool) else int(mfma)
         cfg.fuse_adam = int(fuse_adam)  # 0: flat Adam kernel; 1: inside the dW epilogue; 2: chunked beside the dW kernel on a side stream
         if expert_shard is not None or self.ep_world > 1:
             cfg.expert_lo, cfg.experts_global, cfg.ep_world = self.expert_lo, self.experts_global, self.ep_world

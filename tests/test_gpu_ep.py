@@ -181,13 +181,11 @@ def test_wide_minibatch_on_a_narrow_shard():
         else: np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=2e-6, err_msg=k)
 
 
-@pytest.mark.parametrize("dw_kernel", ["q", "p2"])
 @pytest.mark.parametrize("bayesian", [True, False])
-def test_split_k_weight_gradient_kernel_equals_the_unsplit_one(bayesian, dw_kernel, monkeypatch):
+def test_split_k_weight_gradient_kernel_equals_the_unsplit_one(bayesian, monkeypatch):
     """few expert tiles: the dW kernel's K (batch) range is split over workgroups and k_out_dw_finish runs the epilogue (gradient finalisation, fused Adam);
-    same sums in another order -> same update up to rounding, with and without the fused Adam, and the gradients themselves.  Both split forms: half-tile workgroups
-    (k_out_dw_q<.., SPLIT>: the default since round 5) and the one-workgroup-per-CU kernel (NTF_DW_KERNEL=0)"""
-    if dw_kernel == "p2": monkeypatch.setenv("NTF_DW_KERNEL", "0")
+    same sums in another order -> same update up to rounding, with and without the fused Adam, and the gradients themselves (half-tile workgroups,
+    k_out_dw_q<.., SPLIT>; the one-workgroup-per-CU split form k_out_dw_p2 was retired in round 6)"""
     ds = make_dataset("dblp", d=128, seed=6, n_rows=3000, n_experts=1300)     # 6 tiles of 256 experts, the last one ragged
     dims = [128, 128, ds["M"]]
     order = np.random.default_rng(1).permutation(ds["N"])[:1500].astype(np.int64)

@@ -83,7 +83,7 @@ def test_fnn_logits_vs_reference_golden(name, fused):
 
 
 @pytest.mark.parametrize("tag", ["imdb", "mid"])
-@pytest.mark.parametrize("fused", [False, True, "f32", "bf16x6"])
+@pytest.mark.parametrize("fused", [False, True, "f32"])
 def test_fnn_train_steps_vs_reference_golden(tag, fused):
     g = golden(f"g4_step_{tag}")
     sd = params_from(g, "p0.")
@@ -114,9 +114,9 @@ def _bnn_case(D, H, M, B, seed):
 
 @pytest.mark.parametrize("D,H,M,B", [(18, [32], 112, 19), (128, [128], 1500, 70), (40, [64, 32], 300, 33), (128, [128], 5000, 130),
                                      (24, [64], 777, 129), (16, [128], 13, 1), (16, [32], 63, 257), (50, [], 90, 21), (32, [], 100, 40)])
-@pytest.mark.parametrize("fused", [False, True, "f32", "bf16x6"])
+@pytest.mark.parametrize("fused", [False, True, "f32"])
 def test_bnn_step_vs_oracle_injected(D, H, M, B, fused):
-    """fused=True: the fused kernels in their default arithmetic (fp16x3 split products); "bf16x6": the three-way bf16 split; "f32": the
+    """fused=True: the fused kernels in their default arithmetic (fp16x3 split products); "f32": the
     exact-f32 MFMA kernels."""
     sd, X, y = _bnn_case(D, H, M, B, 5)
     e = _engine([D] + H + [M], bayesian=True, max_batch=B, ns=5, nsd="uniform", lr=1e-3, fused=bool(fused), mfma=fused if isinstance(fused, str) else None)
@@ -188,7 +188,7 @@ def test_multihot_first_layer_step_vs_oracle(bayesian, S, H, M, B):
             for k in sd: sd[k].copy_(torch.from_numpy(state[k]))
 
 
-@pytest.mark.parametrize("mfma", ["f32", "bf16x6", None])
+@pytest.mark.parametrize("mfma", ["f32", None])
 @pytest.mark.parametrize("bayesian", [False, True])
 def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian, mfma):
     """cfg.fuse_adam moves the output layer's Adam into the dW kernel's epilogue: same parameters, step for step."""
@@ -196,7 +196,7 @@ def test_adam_fused_into_dw_epilogue_equals_flat_adam(bayesian, mfma):
     if not bayesian:
         torch.manual_seed(3); sd = O.fnn_init(64, [128], 900)
     def run(fuse):
-        # the three modes share one product arithmetic (exact-f32 MFMA, bf16x6 or the default fp16x3): this test is about WHERE Adam runs
+        # the three modes share one product arithmetic (exact-f32 MFMA or the default fp16x3): this test is about WHERE Adam runs
         e = _engine([64, 128, 900], bayesian=bayesian, max_batch=150, ns=4, nsd="uniform", seed=21, lr=1e-2, fuse_adam=fuse, mfma=mfma)
         e.load_state_dict(sd); e.set_dense_input(X.numpy()); e.set_member(_csr_from_dense(y.numpy()))
         losses = [e.train_step(np.arange(150)) for _ in range(4)]
@@ -409,7 +409,7 @@ def test_forward_probs_topk_and_uncertainty():
 
 
 @pytest.mark.parametrize("bayesian", [True, False])
-@pytest.mark.parametrize("mfma", [None, "bf16x6", "f32"])
+@pytest.mark.parametrize("mfma", [None, "f32"])
 def test_forward_probs_uncertainty_h128(bayesian, mfma):
     """H = 128: in the split-product arithmetics the inference runs through the fused forward kernel (probabilities accumulated over the MC
     passes in a transposed buffer, no dense logits); mfma="f32" keeps the generic GEMM route.  Both against the oracle with injected noise."""

@@ -58,29 +58,6 @@ def test_operands_written_by_the_adam_epilogue_on_expert_shards(monkeypatch):
     for k in a[3]: assert np.array_equal(a[3][k], b[3][k]), k
 
 
-# ------------------------------------------------------------------------------------------ the dW + Adam kernel as two half-tile workgroups per CU (round 4)
-@pytest.mark.parametrize("bayesian,M,B", [(True, 70_000, 1000), (True, 3333, 333), (False, 70_001, 129), (True, 257, 64)])
-def test_half_tile_weight_gradient_kernel_equals_the_one_workgroup_per_cu_kernel(bayesian, M, B, monkeypatch):
-    """k_out_dw_q (NTF_DW_KERNEL=1, default: 128-expert workgroups, two per CU, h * s_in rebuilt from transposed s_in words) against k_out_dw_p2 (NTF_DW_KERNEL=0):
-    the same MFMA sequence per accumulator and the same epilogue - gradients (fuse_adam = 0) and the parameters after fused-Adam steps with the next step's operands
-    produced in the epilogue, bit for bit; ragged last expert tile, ragged last row block, a layer smaller than one old tile"""
-    ds = make_dataset("dblp", d=128, seed=17, n_rows=1500, n_experts=M)
-    dims = [128, 128, ds["M"]]
-    order = np.random.default_rng(8).permutation(ds["N"])[:2 * B + 5].astype(np.int64)
-    out = []
-    for k in ("0", "1"):
-        monkeypatch.setenv("NTF_DW_KERNEL", k)
-        e = _mk(ds, dims, bayesian, B, "uniform", fuse_adam=0)
-        loss = e.backward(order[:B]); g = e.grads(); e.close()
-        e = _mk(ds, dims, bayesian, B, "uniform")
-        l2 = _full_epoch(e, order, B)                    # three fused-Adam steps, the second and third on operands the first two epilogues produced
-        out.append((loss, g, l2, e.state_dict(), e.prefetched_steps())); e.close()
-    (la, ga, l2a, sa, pa), (lb, gb, l2b, sb, pb) = out
-    assert la == lb and abs(l2a - l2b) <= 1e-9 * abs(l2a) and pa == pb
-    for k in ga: assert np.array_equal(ga[k], gb[k]), k
-    for k in sa: assert np.array_equal(sa[k], sb[k]), k
-
-
 # ------------------------------------------------------------------------------------------ a step of the fully prefetched path that falls back to the exact-f32 kernels
 @pytest.mark.parametrize("what", ["sigma", "hidden", "in_range"])
 def test_flagged_steps_on_the_prefetched_path_equal_the_f32_engine(what, monkeypatch):
@@ -365,36 +342,6 @@ def test_uspt_unfiltered_expert_count_step_against_the_oracle():
     _full_size_oracle_step(D=256, H=128, M=3_508_807, B=64, S=6000, mean_s=6.29, mean_m=2.51, seed=17)
 
 
-# ------------------------------------------------------------------------------------------ the producer / consumer wave-pair forward kernel (k_out_fwd_h3p)
-@pytest.mark.parametrize("bayesian", [True, False])
-@pytest.mark.parametrize("M,B", [(70_000, 1000), (3000, 333), (70_001, 129), (40, 70)])     # ragged / empty last sub-tile, ragged last row block, one tile only
-def test_wave_pair_forward_equals_the_one_wave_kernel(bayesian, M, B, monkeypatch):
-    """k_out_fwd_h3p (a logit wave and a gradient wave per 32 rows, two waves per SIMD) against k_out_fwd_h3x (NTF_FWD_KERNEL=3): the same fp16x3 products and the
-    same epilogue arithmetic in the same order per accumulator - every gradient is bit-identical, and so is every parameter after three steps of the default path
-    (Adam in the dW epilogue, prefetched head); the loss differs in the order its terms are summed.  (Round 5's experiment that moved the sparse fix-up into the
-    wave-pair kernel summed d(hidden) in another order and had this test relaxed to rounding for the hidden layer; it measured slower and is gone - bit for bit again.)"""
-    ds = make_dataset("dblp", d=128, seed=13, n_rows=1500, n_experts=M)
-    dims = [128, 128, ds["M"]]
-    order = np.random.default_rng(6).permutation(ds["N"])[:2 * B].astype(np.int64)
-    out = []
-    for k in ("3", "5"):
-        monkeypatch.setenv("NTF_FWD_KERNEL", k)
-        e = _mk(ds, dims, bayesian, B, "uniform", fuse_adam=0)
-        loss = e.backward(order[:B])
-        g = e.grads()
-        l2 = [e.train_step(order[:B]), e.train_step(order[B:])]
-        sd = {n: np.array(v, copy=True) for n, v in e.state_dict().items()}; e.close()
-        # the default step (Adam and the next step's operands in the dW epilogue, the head of the next batch prefetched): three steps, parameters bit for bit
-        e = _mk(ds, dims, bayesian, B, "uniform")
-        l3 = [e.train_step(order[:B]), e.train_step(order[B:]), e.train_step(order[:B])]
-        sd3 = {n: np.array(v, copy=True) for n, v in e.state_dict().items()}; e.close()
-        out.append((loss, l2[0], l2[1], l3[0], l3[1], l3[2], g, sd, sd3))
-    a, b = out
-    for x, y in zip(a[:6], b[:6]): assert abs(x - y) <= 2e-6 * abs(x), (x, y)
-    for t in (6, 7, 8):
-        for k in a[t]: np.testing.assert_array_equal(np.asarray(a[t][k]), np.asarray(b[t][k]), err_msg=k)
-
-
 # ------------------------------------------------------------------------------------------ the evaluation-loss kernel (k_out_fwd_h3e, round 6)
 @pytest.mark.parametrize("bayesian", [True, False])
 @pytest.mark.parametrize("M,B", [(70_000, 1000), (3000, 333), (70_001, 129), (40, 70), (233_629, 257)])     # ragged / empty last sub-tile, a ragged and a half-empty 256-row block, one tile only
@@ -406,7 +353,7 @@ def test_eval_loss_kernel_equals_the_forward_only_kernel_of_round_5(bayesian, M,
     dims = [128, 128, ds["M"]]
     order = np.random.default_rng(8).permutation(ds["N"])[:2 * B + B // 3].astype(np.int64)
     out = []
-    for k, mfma in (("0", None), ("1", None), ("1", "f32")):
+    for k, mfma in (("0", None), ("2", None), ("2", "f32")):      # (2: the kernel also for the non-Bayesian model, whose default stays k_out_fwd_b6 - it measured faster there)
         monkeypatch.setenv("NTF_EVAL_KERNEL", k)
         e = _mk(ds, dims, bayesian, B, "uniform", mfma=mfma)
         ls = [e.eval_step(order[:B]), e.eval_step(order[B:2 * B]), e.eval_epoch(order, B)]
