@@ -699,6 +699,13 @@ __global__ __launch_bounds__(256, 1) void k_out_fwd_b6(OutFwd6Args pp) {   // NP
 // + two hand-over slots of 16 KiB = 129.5 KiB.  Sub-tile order, MFMA order per accumulator, epilogue arithmetic and the packed dz are the one-wave kernel's (dzT and
 // the dh slabs were bit-identical to it, the loss differs in the order of its sums).  An operand outside the fp16 window: the kernel returns (exact-f32 launch behind it).
 // ------------------------------------------------------------------------------------------------
+// static wave priorities for the whole kernel (round 6 experiment, MI355X_MICROARCH.md "static priority for the younger half"; profiles/r6_fwd_prio_ab.md): 0 = none
+#ifndef H3P_APRIO
+#define H3P_APRIO 0
+#endif
+#ifndef H3P_BPRIO
+#define H3P_BPRIO 0
+#endif
 template <bool BAYES, bool INJ, bool STAMP = false>      // STAMP (-DNTF_DIAG builds, NTF_FWD_ABL=9): cycle sums per wave and step segment into pp.stamps
 __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -758,6 +765,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     };
     if (role == 0) {
         // ================================================================ wave A: zT, logits, DMA
+        if (H3P_APRIO) __builtin_amdgcn_s_setprio(H3P_APRIO);
         u32x4 hp[NKS][2], hs[NKS][2];               // B operand of zT: fp16 planes of h[i][16 s + 8 half ..] and of h * s_in
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
@@ -936,6 +944,7 @@ __global__ __launch_bounds__(512) void k_out_fwd_h3p(OutFwd6Args pp) {
     }
 
     // ==================================================================== wave B: loss, dz, dh
+    if (H3P_BPRIO) __builtin_amdgcn_s_setprio(H3P_BPRIO);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // (the barrier behind wave A's first DMA)
     const float rscale_pos = row_ok ? p.tnw * p.inv_B * pp.dz_scale : 0.f;    // dz * dz_scale = this * sigmoid(l)   (z > 0), ...

@@ -20,7 +20,8 @@ def short(n):
 
 
 names = [short(r["Kernel_Name"]) for r in rows]
-fwd = [i for i, n in enumerate(names) if n.startswith("k_out_fwd_h3") ]
+fwd = [i for i, n in enumerate(names) if n.startswith("k_out_fwd_h3p") ]      # the TRAIN step's forward kernel (round 6: the run also ends with evaluation steps, k_out_fwd_h3e)
+while len(fwd) >= 3 and any(n.startswith("k_out_fwd_h3e") for n in names[fwd[-3]: fwd[-1]]): fwd.pop()      # (two whole train steps with no evaluation step between them)
 a, b = fwd[-3], fwd[-1]          # two whole steps: from one forward kernel to the one two steps later
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end, out = {}, []

@@ -9,7 +9,8 @@ W="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-r
 case "$1" in
   diag) F="$W -DNTF_DIAG"; out=$D/diag.so ;;
   ieee) F="$W -DNTF_ADAM_IEEE"; out=$D/adam_ieee.so ;;
-  *) echo "usage: $0 diag|ieee"; exit 2 ;;
+  def) F="$W $3"; out=$D/$2.so ;;      # profiles/mk_variants.sh def NAME "-DMACRO=value ..."  -> scratch/var/NAME.so (A/B of a compile-time choice)
+  *) echo "usage: $0 diag|ieee|def NAME FLAGS"; exit 2 ;;
 esac
 for f in ntf_kernels ntf_head ntf_engine ntf_metrics ntf_cooc ntf_n2v ntf_d2v; do hipcc $F -c $f.hip -o $D/obj/$f.o 2>/dev/null & done
 for f in ntf_fused ntf_special ntf_fused_dw; do hipcc $F -fno-slp-vectorize -c $f.hip -o $D/obj/$f.o 2>/dev/null & done
