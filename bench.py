@@ -462,8 +462,9 @@ def main():
             ev = None
             if breakdown and world == 1 and not a.ep_emulate and not a.dp_emulate:
                 kev = max(10, min(40, steps))
-                dp.eval_epoch(order[: 3 * gB], gB); e.synchronize()
-                t0 = time.perf_counter(); ev_loss = dp.eval_epoch(order[: kev * gB], gB); e.synchronize()
+                ev_run = e.eval_epoch if type(dp).__name__ == "DataParallel" else dp.eval_epoch      # (one GPU: ntf_eval_epoch, what the plugin's validation phase calls - its steps share the KL term and prefetch each other's operands)
+                ev_run(order[: 3 * gB], gB); e.synchronize()
+                t0 = time.perf_counter(); ev_loss = ev_run(order[: kev * gB], gB); e.synchronize()
                 ev = {"ms_per_step": (time.perf_counter() - t0) / kev * 1e3, "steps": kev, "mean_loss": ev_loss}
             res = {"par": par, "eval": ev, "collective_waits": waits, "ep": ep, "gB": gB, "eB": eB, "dt": dt, "regions": regions, "mean_loss": mean_loss, "region_losses": losses, "times": times, "evt_steps": evt_steps, "adam_in_dw": bool((world == 1 and not a.dp_emulate) or ep), "breakdown": bd, "k3": k3,
                    "Mloc": (shard[1] - shard[0]) if ep else model_dims[-1], "engine": e,

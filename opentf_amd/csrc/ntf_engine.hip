@@ -1824,9 +1824,13 @@ static int infer_pass_fused(ntf_engine* e, const int64_t* rows, int32_t B, const
     f.np = mfma_np(e); f.w_scale = kW16Scale; f.h_scale = kH16Scale; f.dz_scale = 1.f;
     if (e->cfg.bayesian) {
         e->pre_valid = false;   // this pass's operands overwrite any prefetched ones
+        // (lean: no f32 copy of sigma * eps - the passes read the planes; a raised range flag sends the whole call to the exact-f32 path, which makes its own operands.  Round 6
+        //  measured the producer of pass p + 1 beside the forward kernel of pass p, into a second plane buffer: -2 % on a call, +10 % on an evaluation step - removed,
+        //  profiles/r6_eval_prefetch_ab.md)
+        const bool nof32 = e->lean && !inj && mfma_np(e) == 2 && e->pl_wp && range_ptr(e);
         { Scope t(e, F_FLIPOUT_OPERAND);
           // (the planes of mu are the first pass's: the passes of one call run back to back on unchanged parameters, and the range flag they share is read behind the last)
-          launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), e->Wp[e->L - 1], 0.0, e->d_kl,
+          launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_WEIGHT], nullptr, lo.nw(), normal_spec(e, c, e->L - 1, T_EPS_W), nof32 ? nullptr : e->Wp[e->L - 1], 0.0, e->d_kl,
                                  e->pl_wp, pass == 0 ? e->pl_mu : nullptr, f.mu, lo.in, mfma_np(e), kW16Scale, range_ptr(e));
           launch_flipout_perturb(e->st, e->P + lo.off[NTF_P_RHO_BIAS], nullptr, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1], 0.0, e->d_kl); }
         f.wp = e->Wp[e->L - 1]; f.bp = e->bp[e->L - 1];
