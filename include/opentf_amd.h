@@ -270,7 +270,7 @@ void ntf_csr_result_free(ntf_csr_result* r);
  * torch_geometric.nn.Node2Vec with p = q = 1 as the reference configures it (src/mdl/emb/__config__.yaml:58-70): uniform random walks over
  * a homogeneous CSR graph (rowptr [num_nodes+1] int64, col int32), windows of `context` nodes, negatives = start node + uniformly random
  * nodes, loss = -mean log(sigmoid(<start, rest>) + 1e-15) - mean log(1 - sigmoid(.) + 1e-15), dense Adam on embedding.weight [num_nodes, d]
- * (d in {64, 128, 192, 256}; init_weight = the nn.Embedding initial draw, supplied by the host so that a seed reproduces torch's).
+ * (1 <= d <= 256: device rows are padded to a multiple of 64 floats, the pad stays zero; init_weight = the nn.Embedding initial draw, supplied by the host so that a seed reproduces torch's).
  * ntf_n2v_train_batch: one loader batch (gnn.py:416-419).  inj_pos / inj_neg non-NULL: the window rows [n, context] are given instead of
  * generated (parity tests); apply = 0 leaves the gradient in place (ntf_n2v_get(what = 1)) and skips Adam.  walk_length counts NODES per
  * walk (= cfg.wl, as Node2Vec's constructor takes it).  ntf_n2v_edge_bce: v_loss of gnn.py:420-431 before its second division. */

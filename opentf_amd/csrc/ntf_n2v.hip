@@ -19,7 +19,7 @@ using namespace ntf;
 
 struct ntf_n2v {
     int device = 0; hipStream_t st = nullptr;
-    int64_t n = 0; int d = 0; int64_t nnz = 0;
+    int64_t n = 0; int d = 0, d_user = 0; int64_t nnz = 0;      // d: the device row stride (a multiple of 64); d_user: the embedding size the host sees
     int64_t* rowptr = nullptr; int32_t* col = nullptr;
     float *W = nullptr, *G = nullptr, *M1 = nullptr, *V2 = nullptr;
     int64_t* d_batch = nullptr; int64_t batch_cap = 0;
@@ -155,7 +155,7 @@ extern "C" void ntf_n2v_destroy(ntf_n2v* h) {
 extern "C" int ntf_n2v_create(int device, int64_t num_nodes, int32_t d, const int64_t* rowptr, const int32_t* col, const float* init_weight, uint64_t seed, ntf_n2v** out) {
     if (!out) { g_n2v_create_error = "out is NULL"; return NTF_EINVAL; }
     *out = nullptr;
-    if (num_nodes < 1 || d < 64 || d > 256 || (d & 63) || !rowptr || !init_weight) { g_n2v_create_error = "n2v: need num_nodes >= 1, d in {64, 128, 192, 256}, a CSR graph and initial weights"; return NTF_EINVAL; }
+    if (num_nodes < 1 || d < 1 || d > 256 || !rowptr || !init_weight) { g_n2v_create_error = "n2v: need num_nodes >= 1, 1 <= d <= 256, a CSR graph and initial weights"; return NTF_EINVAL; }
     const int64_t nnz = rowptr[num_nodes];
     for (int64_t i = 0; i < num_nodes; ++i) if (rowptr[i + 1] < rowptr[i]) { g_n2v_create_error = "n2v: rowptr not monotone"; return NTF_EINVAL; }
     for (int64_t p = 0; p < nnz; ++p) if (col[p] < 0 || col[p] >= num_nodes) { g_n2v_create_error = "n2v: neighbour id out of range"; return NTF_EINVAL; }
@@ -163,7 +163,10 @@ extern "C" int ntf_n2v_create(int device, int64_t num_nodes, int32_t d, const in
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_n2v_create_error = "no such HIP device (there is no CPU fallback)"; return NTF_EHIP; }
     hipSetDevice(device);
     ntf_n2v* h = new ntf_n2v();
-    h->device = device; h->n = num_nodes; h->d = d; h->nnz = nnz; h->seed = seed;
+    // any embedding size 1..256 (round 6; data.embedding.d is free in the reference): a device row is padded to a multiple of 64 floats (h->d, what the kernels see); the pad
+    // columns of the table are zero and stay zero - their gradient is a multiple of another row's zero pad, and Adam leaves a zero parameter with zero moments where it is
+    h->device = device; h->n = num_nodes; h->d_user = d; h->d = (d + 63) / 64 * 64; h->nnz = nnz; h->seed = seed;
+    const int du = d; d = h->d;
     int rc = NTF_OK;
     auto A = [&](int r) { if (rc == NTF_OK) rc = r; };
     if (hipStreamCreate(&h->st) != hipSuccess) { g_n2v_create_error = "hipStreamCreate failed"; delete h; return NTF_EHIP; }
@@ -173,7 +176,8 @@ extern "C" int ntf_n2v_create(int device, int64_t num_nodes, int32_t d, const in
     if (rc != NTF_OK) { g_n2v_create_error = h->err; ntf_n2v_destroy(h); return rc; }
     hipMemcpy(h->rowptr, rowptr, (num_nodes + 1) * 8, hipMemcpyHostToDevice);
     if (nnz) hipMemcpy(h->col, col, nnz * 4, hipMemcpyHostToDevice);
-    hipMemcpy(h->W, init_weight, np * 4, hipMemcpyHostToDevice);
+    if (du != d) hipMemset(h->W, 0, np * 4);
+    hipMemcpy2D(h->W, (size_t)d * 4, init_weight, (size_t)du * 4, (size_t)du * 4, (size_t)num_nodes, hipMemcpyHostToDevice);
     hipMemsetAsync(h->G, 0, np * 4, h->st); hipMemsetAsync(h->M1, 0, np * 4, h->st); hipMemsetAsync(h->V2, 0, np * 4, h->st);
     if (hipStreamSynchronize(h->st) != hipSuccess) { g_n2v_create_error = "device initialisation failed"; ntf_n2v_destroy(h); return NTF_EHIP; }
     *out = h;
@@ -282,7 +286,7 @@ extern "C" int ntf_n2v_get(ntf_n2v* h, int what, float* host) {   // what: 0 = e
     if (!h || !host || what < 0 || what > 1) return NTF_EINVAL;
     NCHK(h, hipSetDevice(h->device));
     NCHK(h, hipStreamSynchronize(h->st));
-    NCHK(h, hipMemcpy(host, what ? h->G : h->W, (size_t)h->n * h->d * 4, hipMemcpyDeviceToHost));
+    NCHK(h, hipMemcpy2D(host, (size_t)h->d_user * 4, what ? h->G : h->W, (size_t)h->d * 4, (size_t)h->d_user * 4, (size_t)h->n, hipMemcpyDeviceToHost));
     if (what) NCHK(h, hipMemsetAsync(h->G, 0, (size_t)h->n * h->d * 4, h->st));   // reading the gradient consumes it
     return NTF_OK;
 }
