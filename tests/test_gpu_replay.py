@@ -81,7 +81,7 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
     # the pipelined default path really ran: steps 2.. started on operands the previous dW epilogue produced, with the head that ran beside that kernel
     if not pipelined: assert e.prefetched_steps() == pre0 and e.head_prefetch_hits() == hit0
     else: assert e.prefetched_steps() - pre0 >= nsteps - 1, (e.prefetched_steps(), pre0)
-    if not pipelined: pass
+    if not pipelined or pipelined == "planes_only": pass      # ("planes_only": an input width the one-kernel head does not serve - operands prefetched, head in its own step)
     elif multihot:      # (no one-kernel head for this input; instead: steps 2.. took their first-layer sigma * eps and KL term from the previous step's one-pass sweep)
         import os
         want = 0 if os.environ.get("NTF_L0_SWEEP") == "0" else nsteps - 1
@@ -128,7 +128,9 @@ def test_three_default_fnn_steps_replayed_through_the_oracle(pipe, monkeypatch):
     5's serial step.  Negatives are the device's own draws."""
     monkeypatch.setenv("NTF_FNN_PIPE", pipe)
     _replay(D=128, H=128, M=70_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=25, t0=3, bayesian=False, pipelined=pipe == "1")
-    if pipe == "1": _replay(D=128, H=128, M=233_629, B=1000, S=4000, mean_s=8.57, mean_m=3.06, seed=26, t0=8, bayesian=False)
+    if pipe == "1":
+        _replay(D=128, H=128, M=233_629, B=1000, S=4000, mean_s=8.57, mean_m=3.06, seed=26, t0=8, bayesian=False)
+        _replay(D=40, H=128, M=20_001, B=129, S=900, mean_s=5.0, mean_m=2.5, seed=27, t0=2, bayesian=False, pipelined="planes_only")      # d = 40: no k_head, the chain of kernels
 
 
 @pytest.mark.parametrize("sweep", ["1", "0"])
