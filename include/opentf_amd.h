@@ -108,7 +108,10 @@ int ntf_set_unigram(ntf_engine* e, const double* freq, int64_t n);              
 /* ---- state:  state_dict() / load_state_dict()                     src/mdl/fnn.py:101,160,168,187 */
 int ntf_set_param(ntf_engine* e, int layer, int kind, const float* host, int64_t count);
 int ntf_get_param(ntf_engine* e, int layer, int kind, float* host, int64_t count);
-int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int64_t count); /* p.grad after backward, fnn.py:137 */
+int ntf_get_grad(ntf_engine* e, int layer, int kind, float* host, int64_t count); /* p.grad after backward, fnn.py:137.  Valid after ntf_backward (or a step with fuse_adam = 0):
+                                                                                     a fused step (fuse_adam = 1, ntf_train_step) consumes the gradients of the tensors it updates in a kernel's
+                                                                                     epilogue - the output layer's weight / rho_weight (never written), a multi-hot Flipout first layer's (read and
+                                                                                     cleared by its one-pass update) - and this call then returns zeros or the previous backward's values for them */
 /* d loss / d z [B, M] of the output layer (z = its pre-activation) as the last backward / train step left it: what autograd holds for
  * `y_` of src/mdl/fnn.py:132 before leaky_relu.  The fused kernels' only dense product, exposed so that it can be checked element-wise. */
 int ntf_get_dlogits(ntf_engine* e, float* host, int64_t count);
