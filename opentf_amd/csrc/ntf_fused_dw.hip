@@ -66,7 +66,11 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t a, int il) {
 // k_flipout_perturb's (ntf_kernels.hip), so a step that follows reads bit for bit what the stand-alone producer would have written
 __device__ __forceinline__ void dw_produce_next(const DwArgs& p, int64_t idx0, const float (&mu4)[4], const float (&rho4)[4], float& kl, float& amax) {
     float z[4], ov[4];
+#if defined(DWQ_ABL) && (DWQ_ABL & 2)      // timing-only builds (profiles/mk_variants.sh def ...: results are garbage): the epilogue without the next step's draw
+    z[0] = z[1] = z[2] = z[3] = 1.f;
+#else
     normal4(p.nx_eps, idx0 >> 2, idx0, INT64_MAX, z);
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float ls;
@@ -498,7 +502,11 @@ __device__ __forceinline__ void dw_finish_ops(const DwArgs& p, int64_t idx0, con
     float o_mu[N], o_rho[N], z[4] = {0.f, 0.f, 0.f, 0.f};
     // d(sigma eps)/d rho = eps sigmoid(rho): eps of THIS step drawn again from its counter (or read from the injected tensor) - round 3 recovered it as wp / sigma from an
     // f32 copy of sigma eps that every step wrote (4 B) and read (4 B) per element for this one use
+#if defined(DWQ_ABL) && (DWQ_ABL & 1)      // timing-only builds: without this step's eps drawn again
+    z[0] = z[1] = z[2] = z[3] = 1.f;
+#else
     if (BAYES) normal4(p.cur_eps, idx0 >> 2, idx0, INT64_MAX, z);
+#endif
 #pragma unroll
     for (int jt = 0; jt < N; ++jt) {
         float gm = s1[jt], gr = 0.f, pm = 0.f, rh = 0.f;
