@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void k_flipout_perturb(const float* __restrict
             }
             if (out) *reinterpret_cast<float4*>(out + e0) = make_float4(ov[0], ov[1], ov[2], ov[3]);      // (null: the planes alone - a lean evaluation step; a range fallback makes the f32 copy itself)
             if (planes_w) {   // H % 4 == 0: the quad lies in one row
-                const int64_t row = e0 / H; const int j = (int)(e0 - row * H);
+                // (H a power of two - 128 on every fused path: a shift; the 64-bit division costs ~80 vector instructions of this loop's ~350)
+                const bool p2 = (H & (H - 1)) == 0;
+                const int64_t row = p2 ? (e0 >> (31 - __builtin_clz(H))) : e0 / H; const int j = p2 ? (int)(e0 & (H - 1)) : (int)(e0 - row * H);
                 const float4 m4 = planes_mu ? *reinterpret_cast<const float4*>(pmu + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (np == 3) {
                     planes_store_quad<3>(planes_w, row, j, H, ov[0], ov[1], ov[2], ov[3], 1.f);
@@ -896,7 +898,8 @@ __global__ __launch_bounds__(256) void k_flipout_sweep(FlipoutSweep a, float lr_
         const int64_t e0 = q * 4;
         float4 pm = reinterpret_cast<float4*>(a.mu)[q], pr = reinterpret_cast<float4*>(a.rho)[q];
         float4 m1 = reinterpret_cast<float4*>(a.m_mu)[q], v1 = reinterpret_cast<float4*>(a.v_mu)[q], m2 = reinterpret_cast<float4*>(a.m_rho)[q], v2 = reinterpret_cast<float4*>(a.v_rho)[q];
-        const bool t = a.touched ? a.touched[(uint64_t)e0 / (uint32_t)a.H] != 0 : true;      // (the quad lies in one row: H % 4 == 0)
+        const bool hp2 = (a.H & (a.H - 1)) == 0;
+        const bool t = a.touched ? a.touched[hp2 ? (uint64_t)e0 >> (31 - __builtin_clz(a.H)) : (uint64_t)e0 / (uint32_t)a.H] != 0 : true;      // (the quad lies in one row: H % 4 == 0)
         float4 gm = zero4, gr = zero4;
         if (t) {
             gm = reinterpret_cast<float4*>(a.g_mu)[q]; gr = reinterpret_cast<float4*>(a.g_rho)[q];
