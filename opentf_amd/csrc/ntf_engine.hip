@@ -132,6 +132,8 @@ struct ntf_engine {
     // starts on the output layer's prefetched operands: one validity protocol, pre_valid / pre_step); l0_swept: this step's Adam of the layer's weights ran in the sweep
     // (apply_adam leaves them out); g0_clean: the layer's gradient rows are all zero (the sweep clears what it reads: no memset in front of the scatter)
     int eval_kernel = 1;              // NTF_EVAL_KERNEL=0 (A/B runs, tests): evaluation steps on k_out_fwd_b6 as in round 5 instead of k_out_fwd_h3e
+    int mh_head = 1;                  // NTF_MH_HEAD=0 (A/B runs): a multi-hot step's head (first-layer operands, gather-sum, h images) inline in its own step as in rounds 1-5; 1 (round 6): as ONE
+                                      // unit (head_launch's multi-hot form) that the previous step issues for the next staged batch beside its dW kernel, behind the first layer's sweep
     int fnn_pipe = 1;                 // NTF_FNN_PIPE=0 (A/B runs): the non-Bayesian step as in round 5 - mu planes split at the head of every step (k_split_planes), hidden backward
                                       // on the main stream, no head prefetch.  1 (round 6): the dW + Adam epilogue writes the NEXT step's planes of mu (FusedDw.produce without the
                                       // Flipout half), the hidden backward and the next batch's head run on the side stream beside the dW kernel - the Bnn step's pipeline
@@ -269,6 +271,7 @@ extern "C" int ntf_engine_create(const ntf_config* cfg, ntf_engine** out) {
     if (const char* mb = getenv("NTF_MERGE_BIAS")) e->merge_bias = atoi(mb);
     if (const char* sw = getenv("NTF_L0_SWEEP")) e->l0_sweep = atoi(sw);
     if (const char* fp = getenv("NTF_FNN_PIPE")) e->fnn_pipe = atoi(fp);
+    if (const char* mh = getenv("NTF_MH_HEAD")) e->mh_head = atoi(mh);
     if (const char* ek = getenv("NTF_EVAL_KERNEL")) e->eval_kernel = atoi(ek);
     if (const char* fc = getenv("NTF_F32_COPY_MERGED")) e->f32_copy_merged = atoi(fc);
     if (const char* eh = getenv("NTF_EP_HEAD_PREFETCH")) e->ep_head_prefetch = atoi(eh);
@@ -797,7 +800,34 @@ static int side_stream(ntf_engine* e) {
 // gather -> hidden layer -> operand images of one batch as ONE kernel (ntf_head.hip) into workspace `ws`; `want_planes`: also the dW kernel's h planes / s_in words.
 // kl == null: no KL terms (they are in the step's sum already); with_bias: the extra workgroups that produce the output layer's bias operand; rflag: where an
 // activation beyond the fp16 window is reported (this step's flag, or the next step's slot for a prefetched head).
-static void head_launch(ntf_engine* e, hipStream_t st, const StepCtx& c, char* ws, bool want_planes, double* kl, bool with_bias, int* rflag, bool rows_part = true) {
+// the multi-hot input's head (round 6): no one-kernel form (the first layer is a gather-sum over 90 671 rows, not a 128-wide product) - the same chain of launches a step used to
+// issue inline, as a unit on stream `st` into workspace `ws`, so that it can be issued for the NEXT batch beside the dW kernel like k_head
+static bool mh_head_ok(const ntf_engine* e) {
+    return e->mh_head && e->head && e->L == 2 && e->cfg.input_mode == NTF_INPUT_MULTIHOT && e->cfg.bayesian && fused_ok(e) && e->layers[e->L - 1].in == 128 && e->pl_mu != nullptr &&
+           (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
+}
+static void head_launch_multihot(ntf_engine* e, hipStream_t st, const StepCtx& c, char* ws, bool want_planes, double* kl, bool with_bias, int* rflag, bool rows_part, bool skip_w0) {
+    const LayerInfo& l0 = e->layers[0]; const LayerInfo& lo = e->layers[e->L - 1];
+    const int M = e->cfg.dims[e->L];
+    float* W0 = e->P + l0.off[NTF_P_WEIGHT]; float* b0 = e->P + l0.off[NTF_P_BIAS];
+    if (rows_part) {
+        // Flipout operands of the first layer (k_flipout_perturb: + its KL terms unless they are in the step's sum already); the weights' come out of the previous step's sweep
+        if (!skip_w0) launch_flipout_perturb(st, e->P + l0.off[NTF_P_RHO_WEIGHT], kl ? W0 : nullptr, l0.nw(), normal_spec(e, c, 0, T_EPS_W), e->Wp[0], 1.0 / (double)l0.nw(), kl);
+        launch_flipout_perturb(st, e->P + l0.off[NTF_P_RHO_BIAS], kl ? b0 : nullptr, l0.out, normal_spec(e, c, 0, T_EPS_B), e->bp[0], 1.0 / (double)l0.out, kl);
+        launch_multihot_fwd(st, c.rows_dev, c.B, l0.in, l0.out, e->s_indptr, e->s_indices, W0, b0, e->Wp[0], e->bp[0], sign_spec(e, c, 0, T_S_IN, l0.in), sign_spec(e, c, 0, T_S_OUT, l0.out), e->act[1]);
+        // zero-padded h, h * s_in, the s_in words and the fp16x3 range check (k_prep_h: phase 1 of the fused forward with the planes marked ready), then the dW kernel's h planes
+        FusedOut f;
+        f.B = c.B; f.H = lo.in; f.M = M; f.bayes = 1; f.train = 1; f.h = e->act[1]; f.ws = ws;
+        f.s_in = sign_spec(e, c, e->L - 1, T_S_IN, lo.in); f.s_out = sign_spec(e, c, e->L - 1, T_S_OUT, lo.out);
+        f.bf16x6 = 1; f.np = mfma_np(e); f.h_scale = kH16Scale; f.w_scale = kW16Scale; f.planes_ready = 1; f.h_ready = 0; f.rflag = rflag;
+        launch_fused_out_fwd(st, f, 1);
+        if (want_planes) launch_fused_prep_planes(st, c.B, lo.in, M, 1, ws, mfma_np(e), kH16Scale, nullptr, 0, 2);
+    }
+    if (with_bias) launch_flipout_perturb(st, e->P + lo.off[NTF_P_RHO_BIAS], kl ? e->P + lo.off[NTF_P_BIAS] : nullptr, lo.out, normal_spec(e, c, e->L - 1, T_EPS_B), e->bp[e->L - 1], 1.0 / (double)e->Mg, kl);
+}
+
+static void head_launch(ntf_engine* e, hipStream_t st, const StepCtx& c, char* ws, bool want_planes, double* kl, bool with_bias, int* rflag, bool rows_part = true, bool skip_w0 = false) {
+    if (e->cfg.input_mode == NTF_INPUT_MULTIHOT) { head_launch_multihot(e, st, c, ws, want_planes, kl, with_bias, rflag, rows_part, skip_w0); return; }
     const LayerInfo& l0 = e->layers[0]; const LayerInfo& lo = e->layers[e->L - 1];
     const int M = e->cfg.dims[e->L];
     const FusedWsPtrs wp = fused_ws_ptrs(ws, c.B, lo.in, M);
@@ -906,8 +936,12 @@ static int prefetch_next_head(ntf_engine* e, const StepCtx& c, hipStream_t head_
     {   // Adam of the hidden layers: [0, first float of the output layer) - apply_adam then leaves that range alone
         Scope t(e, F_ADAM);
         const double b1 = 0.9, b2 = 0.999, tt = (double)(e->adam_t + 1);
-        const int64_t rg[2] = {0, lo.off[NTF_P_WEIGHT]};
-        launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, 1, e->lr, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)), (float)std::sqrt(1.0 - std::pow(b2, tt)));
+        int64_t rg[4] = {0, lo.off[NTF_P_WEIGHT], 0, 0}; int nrg = 1;
+        if (e->l0_swept) {      // (the first layer's weight / rho_weight segments took their update in launch_flipout_sweep: its bias up to rho_weight, and its rho_bias, remain - L == 2 here)
+            const LayerInfo& l0 = e->layers[0];
+            rg[0] = l0.off[NTF_P_BIAS]; rg[1] = l0.off[NTF_P_RHO_WEIGHT]; rg[2] = l0.off[NTF_P_RHO_BIAS]; rg[3] = lo.off[NTF_P_WEIGHT]; nrg = 2;
+        }
+        launch_adam_ranges(e->st, e->P, e->G, e->M1, e->V2, rg, nrg, e->lr, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)), (float)std::sqrt(1.0 - std::pow(b2, tt)));
         e->hidden_adam_done = true;
     }
     StepCtx n; n.rows_dev = e->hp_next_rows; n.B = e->hp_next_B; n.global_B = e->hp_next_B; n.step = c.step + 1; n.train = true; n.row0 = 0;
@@ -930,13 +964,13 @@ static int prefetch_next_head(ntf_engine* e, const StepCtx& c, hipStream_t head_
     }
     HIPCHK(e, hipEventRecord(e->ev_aux, e->st4));
     e->st = head_st;
-    { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr); }
+    { Scope t(e, F_GEMM_HIDDEN); head_launch(e, e->st, n, ws_next, true, e->d_kl + 2, false, range_ptr(e) ? e->d_range + 4 : nullptr, true, e->pre0_step == n.step); }
     e->hp.valid = true; e->hp.step = n.step; e->hp.rows = n.rows_dev; e->hp.B = n.B; e->hp.ub = ub_next;
     return NTF_OK;
 }
 static bool head_prefetch_possible(const ntf_engine* e, const StepCtx& c, int B) {
-    const bool can_head = e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
-                          (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
+    const bool can_head = (mh_head_ok(e) && !e->ep) || (e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
+                          (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3));
     if (!e->cfg.bayesian && !e->fnn_pipe) return false;
     return e->head_prefetch && can_head && c.fuse_adam && e->cfg.fuse_adam == 1 && e->pre_valid && e->pre_step == c.step + 1 && e->hp_next_B > 0 && !c.inj &&
            (e->cfg.nsd != NTF_NSD_UNIGRAM_B || e->hp_next_host != nullptr) && c.global_B == B;
@@ -953,8 +987,10 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
     const int64_t* neg = (e->cfg.nsd != NTF_NSD_NONE && e->cfg.ns > 0) ? e->d_neg_set[c.step & 1] : nullptr;
     bool prod_side = false, aux = false, swt_aux = false, loss_side = false, use_pre = false;
     // one kernel for gather -> hidden layer -> operand images (ntf_head.hip): one hidden layer of 128 units over a dense / mean-pooled input, native generators, fp16x3 planes
-    const bool use_head = fused && e->head && e->L == 2 && c.part <= 1 && !c.inj && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
-                          (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3);
+    // (round 6: the multi-hot input's head is such a unit too - head_launch_multihot - on one GPU)
+    const bool use_head = fused && c.part <= 1 && !c.inj &&
+                          ((mh_head_ok(e) && !e->ep) || (e->head && e->L == 2 && e->cfg.input_mode != NTF_INPUT_MULTIHOT && head_supported(e->cfg.dims[0], e->cfg.dims[1]) &&
+                                                         (e->cfg.mfma == NTF_MFMA_DEFAULT || e->cfg.mfma == NTF_MFMA_FP16X3)));
     // the hidden layers' backward (and the loss reduction) of a whole train step run on the side stream beside the output layer's dW kernel, see `backward:`
     // (round 5: also of a deferred-dW step - a data-parallel rank's - whose dW chunks the host launches right behind this call: the join then waits behind the last chunk, join_side)
     // (Fnn: the chain alone is too short to pay - it goes to the side stream when the next batch's head follows it there, round 6)
@@ -1040,6 +1076,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         e->use_pre0 = use_pre && e->pre0_step == c.step;      // (decided with use_pre: a step that drops the prefetched scalars drops the first layer's KL term with them)
         e->pre0_step = ~0ull;
         if (e->use_pre0) e->pre0_used += 1;
+        const bool skip_w0 = e->use_pre0;      // (the multi-hot head below takes the same decision forward_layers does)
         if (!use_head && (r = forward_layers(e, c, false, true))) { e->use_pre0 = false; return r; }
         e->use_pre0 = false;
         FusedOut f;
@@ -1072,7 +1109,7 @@ static int run_step(ntf_engine* e, const StepCtx& c, bool accumulate_epoch) {
         if (use_head) {
             Scope t(e, F_GEMM_HIDDEN);
             // (hp_hit: this batch's head ran beside the previous step's dW kernel; hp_stale: a head ran for another batch - redo it here, without the KL terms and the bias operand)
-            if (!hp_hit) head_launch(e, e->st, c, e->fws, c.train && e->cfg.mfma != NTF_MFMA_F32, hp_stale ? nullptr : e->d_kl, !hp_stale, f.rflag);
+            if (!hp_hit) head_launch(e, e->st, c, e->fws, c.train && e->cfg.mfma != NTF_MFMA_F32, hp_stale ? nullptr : e->d_kl, !hp_stale, f.rflag, true, skip_w0);
             f.h_ready = 1;
             if (!f.planes_ready) launch_fused_out_fwd(e->st, f, 1);   // (Fnn: the split planes of mu are made per step)
             if (c.train && e->cfg.mfma != NTF_MFMA_F32 && !swt_aux && !hp_hit) {   // (one stream: the s_out words were not made beside the head)
@@ -1383,8 +1420,9 @@ static int apply_adam(ntf_engine* e) {
     const LayerInfo& lo = e->layers[e->L - 1];
     const int64_t w0 = lo.off[NTF_P_WEIGHT], w1 = lo.off[NTF_P_BIAS];  // segments are laid out weight, bias, rho_weight, rho_bias
     int64_t rg[12]; int fin[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
-    if (e->l0_swept) {
+    if (e->l0_swept && !e->hidden_adam_done) {
         // the first layer's weight / rho_weight segments were updated by launch_flipout_sweep: its bias (up to rho_weight), its rho_bias and the later hidden layers remain
+        // (hidden_adam_done: the prefetched head's own Adam launch took them - prefetch_next_head)
         const LayerInfo& l0 = e->layers[0];
         rg[2 * n] = l0.off[NTF_P_BIAS]; rg[2 * n + 1] = l0.off[NTF_P_RHO_WEIGHT]; ++n;
         rg[2 * n] = l0.off[NTF_P_RHO_BIAS]; rg[2 * n + 1] = e->L > 2 ? e->layers[1].off[NTF_P_WEIGHT] : w0; ++n;

@@ -86,6 +86,7 @@ def _replay(D, H, M, B, S, mean_s, mean_m, seed, t0, nsteps=3, bad_frac=5e-4, ns
         import os
         want = 0 if os.environ.get("NTF_L0_SWEEP") == "0" else nsteps - 1
         assert e.first_layer_sweeps() - sw0 == want, (e.first_layer_sweeps(), sw0)
+        if os.environ.get("NTF_MH_HEAD") != "0": assert e.head_prefetch_hits() - hit0 >= nsteps - 1, (e.head_prefetch_hits(), hit0)      # (the multi-hot head runs beside the previous dW kernel too)
     else: assert e.head_prefetch_hits() - hit0 >= nsteps - 1, (e.head_prefetch_hits(), hit0)
     st = e.state_dict(); e.close()
 

@@ -120,19 +120,19 @@ def test_evaluation_steps_of_one_epoch_call_share_the_output_layers_kl_and_mu_pl
 
 
 # ------------------------------------------------------------------------------------------ head prefetch (round 4)
-@pytest.mark.parametrize("nsd,bayesian", [("uniform", True), ("unigram", True), ("uniform", False)])
-def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own_step(nsd, bayesian, monkeypatch):
+@pytest.mark.parametrize("nsd,bayesian,multihot", [("uniform", True, False), ("unigram", True, False), ("uniform", False, False), ("unigram", True, True)])
+def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own_step(nsd, bayesian, multihot, monkeypatch):
     """ntf_head_prefetch_hits: sampler, s_out words, gather -> hidden layer -> h images of batch t + 1 issued on the side stream of step t (behind its hidden-layer
     backward and Adam, into the other workspace set, KL terms and range flag in the next step's slots) against the same work at the head of step t + 1: the same
     kernels on the same inputs - parameters bit for bit, losses to the order of the KL sum's double atomics.  The sequence walks every way out of the fast path: a
     ragged last batch, an evaluation step behind a train step (head redone without its KL terms), parameters rewritten from outside, inference in between."""
     ds = make_dataset("dblp", d=128, seed=9, n_rows=3000, n_experts=70_000)
-    dims = [128, 128, ds["M"]]
+    dims = [ds["S"] if multihot else 128, 128, ds["M"]]      # (multihot, round 6: BASELINE config 3's input - the head is the chain head_launch_multihot issues, behind the first layer's sweep)
     order = np.random.default_rng(2).permutation(ds["N"])[:2500].astype(np.int64)
     out = []
     for hp in ("0", "1"):
         monkeypatch.setenv("NTF_HEAD_PREFETCH", hp)
-        e = _mk(ds, dims, bayesian, 1000, nsd)
+        e = _mk(ds, dims, bayesian, 1000, nsd, multihot=multihot)
         l1 = _full_epoch(e, order, 1000)                        # 1000, 1000, 500 rows: steps 2 and 3 find their head done
         v = _full_epoch(e, order[:700], 1000, train=False)      # (the train step before it had no next batch: nothing was issued)
         l2 = _full_epoch(e, order[::-1].copy(), 1000)
@@ -144,6 +144,14 @@ def test_head_run_beside_the_previous_steps_dw_kernel_equals_the_head_in_its_own
         out.append(((l1, v, l2, *v2, l3, l4), p, e.state_dict(), e.head_prefetch_hits())); e.close()
     (la, pa, sa, ha), (lb, pb, sb, hb) = out
     assert ha == 0 and hb == 2 + 2 + 1 + 1, (ha, hb)      # (round 6: Fnn steps run the same pipeline - planes of the updated mu from the dW epilogue, hidden backward and the next head on the side stream)
+    if multihot:      # (the first layer's gradient is a scatter of f32 atomic row adds: the order of its sums differs from run to run, with or without the prefetch)
+        # ... and Adam turns a last-bit difference of a near-zero gradient into a +-lr step of that weight (tests/test_gpu_replay.py, the same band): a fraction of the elements, bounded
+        for x, y in zip(la, lb): assert abs(x - y) <= 2e-5 * abs(x), (x, y)
+        np.testing.assert_allclose(pa, pb, rtol=5e-3, atol=1e-5)
+        for k in sa:
+            bad = np.abs(sa[k] - sb[k]) > (1e-3 * np.abs(sb[k]) + 2e-5)
+            assert float(bad.mean()) <= 1e-3, (k, float(bad.mean()))
+        return
     for x, y in zip(la, lb): assert abs(x - y) <= 1e-9 * abs(x), (x, y)
     assert np.array_equal(pa, pb)
     for k in sa: assert np.array_equal(sa[k], sb[k]), k
